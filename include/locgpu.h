@@ -1,0 +1,171 @@
+/* include/locgpu.h — C ABI of the MI355X-native registration hot path (liblocgpu.so).
+ *
+ * This is the drop-in boundary for the ONE path of maotian123/loc_lib this project accelerates:
+ * the KD-tree neighbour search + point-to-plane/-line/-point ICP and direct-NDT Gauss–Newton loop
+ * that slam_demo's front-ends run once per scan through LocUtils::MatchingInterface. The reference
+ * is plain C++ with no FFI; a maintainer binds these entry points from the reference's own matcher
+ * classes (see INTEGRATION.md and facade/). Every entry point names the reference interface it
+ * replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch/Eigen/PCL types cross this boundary;
+ *   - clouds are passed as (base pointer, point count, stride in BYTES); x,y,z are three consecutive
+ *     float32 at the start of each point (pcl::PointXYZI: stride 32; packed xyz: stride 12);
+ *   - poses are 7 doubles, quaternion (x,y,z,w) then translation (x,y,z): the memory layout of
+ *     Sophus::SE3d::data() (LocUtils/include/LocUtils/common/eigen_types.h:66, `using SE3 = Sophus::SE3d`);
+ *   - host-pointer entry points copy their inputs before returning (the reference deep-copies target
+ *     and source: icp_registration.cpp:16,259), are synchronous, and are not re-entrant per context
+ *     (the reference matcher is single-threaded per instance);
+ *   - every function returns LOCGPU_OK (0) or a negative locgpu_status; no exception crosses the boundary.
+ *     locgpu_last_error() gives the text. There is NO CPU fallback: without a HIP device every call fails.
+ */
+#ifndef LOCGPU_H_
+#define LOCGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOCGPU_API __attribute__((visibility("default")))
+
+typedef struct locgpu_ctx locgpu_ctx;     /* one matcher instance (tree / voxel grid + workspaces) on one GPU */
+typedef struct locgpu_batch locgpu_batch; /* a batch of scans resident in HBM */
+
+typedef enum locgpu_status {
+    LOCGPU_OK = 0,
+    LOCGPU_ERR_INVALID = -1,    /* bad argument */
+    LOCGPU_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime error */
+    LOCGPU_ERR_NO_TARGET = -3,  /* align/search before set_target */
+    LOCGPU_ERR_K_TOO_LARGE = -4,/* k > number of tree leaves (kdtree.cpp:149-153 logs an error and returns false) */
+    LOCGPU_ERR_DEPTH = -5,      /* tree deeper than the traversal stack supports */
+    LOCGPU_ERR_OOM = -6
+} locgpu_status;
+
+/* IcpMethod, LocUtils/include/LocUtils/model/matching/3d/icp/icp_registration.hpp:15-20 (PCLICP is not on the path). */
+typedef enum locgpu_icp_method { LOCGPU_P2P = 0, LOCGPU_P2LINE = 1, LOCGPU_P2PLANE = 2 } locgpu_icp_method;
+
+/* How correspondences are searched.
+ * TREE_FAITHFUL replays the reference's mean-split KD-tree and its DFS visit order bit for bit
+ * (kdtree.cpp:169-236), including the alpha-pruned approximate mode that is the reference default
+ * (kdtree.h:128-129). GRID_EXACT is the exact k-NN over a radix-sorted voxel grid: it equals the
+ * reference with KdtreeRegistration::SetEnableANN(false) (kdtree.cpp:285-288) up to ties in distance. */
+typedef enum locgpu_search_mode { LOCGPU_SEARCH_TREE_FAITHFUL = 0, LOCGPU_SEARCH_GRID_EXACT = 1 } locgpu_search_mode;
+
+/* IcpOptions, icp_registration.hpp:22-39 (same defaults via locgpu_icp_opts_default). */
+typedef struct locgpu_icp_opts {
+    int32_t method;            /* locgpu_icp_method; reference default P2P */
+    int32_t max_iteration;     /* 20 */
+    double max_nn_distance;    /* 1.0  (compared with a SQUARED distance, icp cpp:75) */
+    double max_plane_distance; /* 0.1 */
+    double max_line_distance;  /* 0.5 */
+    int32_t min_effective_pts; /* 10 */
+    double eps;                /* 1e-2 */
+    int32_t approximate;       /* 1: KdTree::approximate_ (kdtree.h:128) */
+    float ann_alpha;           /* 0.1f: KdTree::alpha_ (kdtree.h:129) */
+    int32_t search_mode;       /* locgpu_search_mode */
+} locgpu_icp_opts;
+
+/* NdtOptions, LocUtils/include/LocUtils/model/matching/3d/ndt/ndt_registration.hpp:27-42. */
+typedef struct locgpu_ndt_opts {
+    int32_t max_iteration;     /* 20 */
+    double voxel_size;         /* 1.0; inv_voxel_size_ is always recomputed as 1/voxel_size (ndt cpp:15,25) */
+    int32_t min_effective_pts; /* 10 */
+    int32_t min_pts_in_voxel;  /* 3 (a voxel is kept iff count > this) */
+    double eps;                /* 1e-2 */
+    double res_outlier_th;     /* 20.0 */
+    int32_t nearby_type;       /* 0 CENTER, 1 NEARBY6 (hpp:16-20) */
+} locgpu_ndt_opts;
+
+/* Per-scan result counters (the reference only logs these through glog). */
+typedef struct locgpu_align_stats {
+    int32_t iterations;        /* Gauss–Newton iterations executed (H,B evaluations) */
+    int32_t converged;         /* 1 if the loop left through |dx| < eps */
+    int32_t status;            /* 0 ok; 1 direct-NDT det(H)==0 ⇒ reference returns before writing result_pose (ndt cpp:435-436) */
+    int32_t reserved;
+    int64_t last_effective_num;
+    double last_dx_norm;
+} locgpu_align_stats;
+
+LOCGPU_API void locgpu_icp_opts_default(locgpu_icp_opts* o);
+LOCGPU_API void locgpu_ndt_opts_default(locgpu_ndt_opts* o);
+
+/* Lifetime. A context is what one IcpRegistration / NdtRegistration instance owns (icp_registration.hpp:41-142). */
+LOCGPU_API int locgpu_create(int device_id, locgpu_ctx** out);
+LOCGPU_API void locgpu_destroy(locgpu_ctx* ctx);
+LOCGPU_API const char* locgpu_last_error(const locgpu_ctx* ctx); /* ctx may be NULL: error of the last failed create */
+LOCGPU_API int locgpu_device_count(void);
+
+/* ---- ICP target: IcpRegistration::SetInputTarget (icp_registration.cpp:9-29) →
+ *      KdtreeRegistration::SetTargetCloud / KdTree::BuildTree (kdtree.cpp:261-270, 10-31). Host pointer. */
+LOCGPU_API int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes);
+/* out[0]=leaves (KdTree::size_), out[1]=tree nodes, out[2]=depth, out[3]=bytes of the packed tree in HBM */
+LOCGPU_API int locgpu_icp_target_info(const locgpu_ctx* ctx, int64_t out[4]);
+
+/* ---- SearchPointInterface::FindNearstPoints (search_point_interface.h:13; kdtree.cpp:272-283), many queries at once.
+ * queries: nq × 3 packed float32 (host). out_idx: nq × k int32 original point indices, ascending distance (host).
+ * visits (optional, host): nq × 2 uint32 {tree nodes visited, leaves visited} per query. */
+LOCGPU_API int locgpu_knn(locgpu_ctx* ctx, const float* queries, size_t nq, int k, int approximate, float alpha, int search_mode,
+                          int32_t* out_idx, uint32_t* visits);
+
+/* ---- MatchingInterface::CaculateMatrixHAndB (matching_interface.h:18-24; icp_registration.cpp:31-55): one
+ * evaluation of H (6×6 row-major) and B at `pose`. *ok receives the reference's bool (false: too few effective
+ * points or det(H)==0). Used by LoamRegistration (loam_registration.cpp:56,66). */
+LOCGPU_API int locgpu_icp_hb(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double pose[7],
+                             const locgpu_icp_opts* opts, double H[36], double B[6], int64_t* effective_num, int* ok);
+
+/* ---- IcpRegistration::ScanMatch minus the output cloud (icp_registration.cpp:216-239 → AlignP2P/P2Line/P2Plane :267-381). */
+LOCGPU_API int locgpu_icp_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7],
+                                const locgpu_icp_opts* opts, double out_pose[7], locgpu_align_stats* stats);
+
+/* ---- pcl::transformPointCloud(*src, *out, pose.matrix().cast<float>()) (icp_registration.cpp:241, ndt_registration.cpp:258).
+ * Writes x,y,z of each output point (float32 arithmetic); other fields of the output points are left untouched. */
+LOCGPU_API int locgpu_transform_cloud(locgpu_ctx* ctx, const double pose[7], const void* src, size_t n, size_t src_stride_bytes,
+                                      void* out, size_t out_stride_bytes);
+
+/* ---- Batched many-scans-vs-one-map mode (BASELINE.json config 4; no reference counterpart — the reference loops
+ * ScanMatch over scans). Scans are uploaded once and stay resident; each align call runs every scan's own GN loop. */
+LOCGPU_API int locgpu_batch_create(locgpu_ctx* ctx, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_scans,
+                                   locgpu_batch** out);
+LOCGPU_API void locgpu_batch_destroy(locgpu_batch* b);
+/* init_poses / out_poses: n_scans × 7 doubles (host). stats: n_scans entries or NULL. */
+LOCGPU_API int locgpu_icp_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const locgpu_icp_opts* opts,
+                                      double* out_poses, locgpu_align_stats* stats);
+LOCGPU_API int locgpu_ndt_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, double* out_poses,
+                                      locgpu_align_stats* stats);
+/* One H,B evaluation for every scan of the batch at the given poses (point-sharded multi-GPU mode: the caller
+ * all-reduces hb over ranks, then calls locgpu_gn_update). hb: n_scans × 44 doubles = H36, B6, effective_num, ok. */
+LOCGPU_API int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* poses, const locgpu_icp_opts* opts, double* hb);
+/* The update step of AlignP2Plane (icp_registration.cpp:362-375) on already-reduced normal equations:
+ * returns 1 in *stop when |dx| < eps. method selects the P2P "/16" quirk (icp cpp:287). */
+LOCGPU_API int locgpu_gn_update(const double hb[44], int method, int min_effective_pts, double eps, double pose[7], double dx[6],
+                                int* applied, int* stop);
+
+/* ---- NDT target: NdtRegistration::SetInputTarget → SetDirectNdtTargetCloud (ndt_registration.cpp:65-85, 87-148). */
+LOCGPU_API int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, const locgpu_ndt_opts* opts);
+/* out[0]=voxels kept, out[1]=hash-table capacity, out[2]=bytes in HBM */
+LOCGPU_API int locgpu_ndt_target_info(const locgpu_ctx* ctx, int64_t out[3]);
+/* Read the voxel table back (tests): keys n×3 int32, mu n×3 f64, info n×9 f64 row-major; returns count through *n_out. */
+LOCGPU_API int locgpu_ndt_dump(locgpu_ctx* ctx, int32_t* keys, double* mu, double* info, size_t cap, size_t* n_out);
+/* ---- NdtRegistration::ScanMatch minus the output cloud (ndt_registration.cpp:238-257 → AlignNdt :374-464).
+ * When stats->status == 1 the reference leaves result_pose unassigned; out_pose then holds init_pose. */
+LOCGPU_API int locgpu_ndt_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7],
+                                double out_pose[7], locgpu_align_stats* stats);
+
+/* ---- Measurement hooks (bench.py / tests; no reference counterpart). */
+/* Average device time in ms of each hot kernel over the calls since the last reset, measured with hipEvents on the
+ * context's stream: out[0]=search, out[1]=fit+accumulate, out[2]=solve/update, out[3..5]=their launch counts.
+ * Timing is only collected when enabled (it serialises launches with events). */
+LOCGPU_API int locgpu_profile_enable(locgpu_ctx* ctx, int on);
+LOCGPU_API int locgpu_profile_read(locgpu_ctx* ctx, double out[6], int reset);
+/* Total tree nodes / leaves visited by the search kernel of the NEXT align/hb call(s) when counting is on
+ * (separate instrumented kernel; never on in timed runs). out[0]=nodes, out[1]=leaves, out[2]=queries. */
+LOCGPU_API int locgpu_visit_count_enable(locgpu_ctx* ctx, int on);
+LOCGPU_API int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCGPU_H_ */

@@ -1,0 +1,69 @@
+// loc_lib_amd/csrc/context.hpp — host-side state behind the opaque handles of include/locgpu.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/locgpu.h"
+#include "device_math.hpp"
+#include "icp_kernels.hpp"
+
+struct NdtTable;  // ndt_kernels.hpp
+
+struct locgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ICP target: packed KD-tree in HBM (kdtree_build.cpp layout)
+    uint2* d_tree = nullptr;
+    size_t tree_slots = 0, num_leaves = 0, num_nodes = 0, num_points = 0;
+    int depth = 0;
+
+    // NDT target
+    NdtTable* ndt = nullptr;
+    locgpu_ndt_opts ndt_opts;
+
+    // reusable one-scan batch for the single-scan entry points
+    locgpu_batch* single = nullptr;
+    size_t single_cap = 0;
+
+    // measurement
+    bool profile = false;
+    std::vector<hipEvent_t> events;
+    double prof_ms[3] = {0, 0, 0};
+    long long prof_n[3] = {0, 0, 0};
+    bool count_visits = false;
+    unsigned long long* d_visits = nullptr;
+};
+
+struct locgpu_batch {
+    locgpu_ctx* ctx = nullptr;
+    int n_scans = 0, max_n = 0, blocks_per_scan = 0;
+    size_t pitch = 0;  // n_scans * max_n
+    float4* d_src = nullptr;
+    int* d_counts = nullptr;
+    locgpu::PoseState* d_state = nullptr;
+    uint32_t* d_nn = nullptr;      // [5][pitch]
+    double* d_partials = nullptr;  // [n_scans][blocks_per_scan][kAccW]
+    double* d_hb = nullptr;        // [n_scans][44]
+    locgpu::PoseState* h_state = nullptr;  // pinned
+    double* h_hb = nullptr;                // pinned
+    std::vector<int> counts;
+};
+
+namespace locgpu {
+
+int fail(locgpu_ctx* ctx, int code, const std::string& msg);
+bool hip_ok(locgpu_ctx* ctx, hipError_t e, const char* what);
+
+// ndt_api.hip
+void ndt_free(locgpu_ctx* ctx);
+
+}  // namespace locgpu
+
+#define LOCGPU_HIP(ctx, expr)                                                    \
+    do {                                                                         \
+        if (!locgpu::hip_ok((ctx), (expr), #expr)) return LOCGPU_ERR_NO_DEVICE;  \
+    } while (0)

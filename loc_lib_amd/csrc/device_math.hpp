@@ -1,0 +1,187 @@
+// loc_lib_amd/csrc/device_math.hpp
+//
+// Device-side fixed-size FP64 algebra for the registration kernels (gfx950). All device code in this
+// library is compiled with -ffp-contract=off: the float32 search arithmetic must round exactly like the
+// reference's FMA-free x86-64 build (kdtree.cpp:197-236), and keeping FP64 un-fused as well makes the
+// per-point math reproducible against the CPU oracle to the last bit (only summation order differs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace locgpu {
+
+struct D3 { double x, y, z; };
+
+__device__ __forceinline__ D3 operator+(const D3& a, const D3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ D3 operator-(const D3& a, const D3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ D3 operator*(double s, const D3& a) { return {s * a.x, s * a.y, s * a.z}; }
+// Eigen's fixed-size-3 reduction order: x0 + (x1 + x2).
+__device__ __forceinline__ double dot3(const D3& a, const D3& b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ D3 cross3(const D3& a, const D3& b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// Per-scan pose state kept in HBM between Gauss–Newton iterations.
+struct PoseState {
+    double q[4];   // x y z w  (Sophus::SE3d::data() order)
+    double t[3];
+    double R[9];   // row-major rotation matrix of q (refreshed by the solve kernel)
+    double last_dx_norm;
+    long long last_eff;
+    int iterations;  // H,B evaluations so far
+    int converged;   // left through |dx| < eps
+    int done;        // 1: no further iterations for this scan
+    int status;      // 0 ok, 1 NDT det(H)==0 (reference returns before writing result_pose)
+};
+
+// SE3 * p the way Sophus 1.0 does it: Eigen Quaternion::_transformVector, then + t
+// (call sites: icp_registration.cpp:68,113,169; ndt_registration.cpp:403).
+__device__ __forceinline__ D3 se3_apply(const double* q, const double* t, const D3& v) {
+    const D3 qv{q[0], q[1], q[2]};
+    D3 uv = cross3(qv, v);
+    uv = uv + uv;
+    const D3 r = (v + q[3] * uv) + cross3(qv, uv);
+    return {r.x + t[0], r.y + t[1], r.z + t[2]};
+}
+
+// Eigen::Quaternion::toRotationMatrix.
+__device__ __host__ inline void quat_to_R(const double* q, double* R) {
+    const double tx = 2.0 * q[0], ty = 2.0 * q[1], tz = 2.0 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+// One-sided (Hestenes) Jacobi SVD, M×N, columns in a[N][M], right vectors accumulated in v[N][N].
+// Fully unrolled over (p,q) so both arrays live in VGPRs; the sweep loop exits per lane when a sweep
+// made no rotation (same rule as the oracle, so the iterates match bit for bit).
+template <int M, int N>
+__device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&v)[N][N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < N - 1; ++p) {
+#pragma unroll
+            for (int q = p + 1; q < N; ++q) {
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    alpha += a[p][i] * a[p][i];
+                    beta += a[q][i] * a[q][i];
+                    gamma += a[p][i] * a[q][i];
+                }
+                if (!(gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
+                    rotated = true;
+                    const double zeta = (beta - alpha) / (2.0 * gamma);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + t * t);
+                    const double s = c * t;
+#pragma unroll
+                    for (int i = 0; i < M; ++i) {
+                        const double ap = a[p][i], aq = a[q][i];
+                        a[p][i] = c * ap - s * aq;
+                        a[q][i] = s * ap + c * aq;
+                    }
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const double vp = v[p][i], vq = v[q][i];
+                        v[p][i] = c * vp - s * vq;
+                        v[q][i] = s * vp + c * vq;
+                    }
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+}
+
+// 6×6 partial-pivot LU: determinant and (if non-zero) solution of H x = b. What Eigen's fixed-size
+// 6×6 determinant()/inverse() do (icp_registration.cpp:210,364). Runs in one thread.
+__device__ __host__ inline double lu6_det_solve(const double* H, const double* b, double* x) {
+    double a[36];
+    for (int i = 0; i < 36; ++i) a[i] = H[i];
+    int perm[6];
+    for (int i = 0; i < 6; ++i) perm[i] = i;
+    double det = 1.0;
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        double best = fabs(a[6 * k + k]);
+        for (int r = k + 1; r < 6; ++r) {
+            const double val = fabs(a[6 * r + k]);
+            if (val > best) { best = val; piv = r; }
+        }
+        if (piv != k) {
+            for (int c = 0; c < 6; ++c) { const double tmp = a[6 * k + c]; a[6 * k + c] = a[6 * piv + c]; a[6 * piv + c] = tmp; }
+            const int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
+            det = -det;
+        }
+        const double d = a[6 * k + k];
+        det *= d;
+        if (d == 0.0) continue;
+        for (int r = k + 1; r < 6; ++r) {
+            const double f = a[6 * r + k] / d;
+            a[6 * r + k] = f;
+            for (int c = k + 1; c < 6; ++c) a[6 * r + c] -= f * a[6 * k + c];
+        }
+    }
+    if (det == 0.0) return det;
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = b[perm[i]];
+        for (int j = 0; j < i; ++j) s -= a[6 * i + j] * y[j];
+        y[i] = s;
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+        for (int j = i + 1; j < 6; ++j) s -= a[6 * i + j] * x[j];
+        x[i] = s / a[6 * i + i];
+    }
+    return det;
+}
+
+// pose.so3() = pose.so3() * SO3::exp(dx.head<3>()); pose.translation() += dx.tail<3>()
+// (icp_registration.cpp:365-366) — Sophus SO3::exp with its small-angle Taylor branch and the
+// first-order renormalisation of the quaternion product.
+__device__ __host__ inline void se3_apply_update(double* q, double* t, const double* dx) {
+    const double theta_sq = dx[0] * dx[0] + (dx[1] * dx[1] + dx[2] * dx[2]);
+    double imag, real;
+    if (theta_sq < 1e-10 * 1e-10) {
+        const double theta_po4 = theta_sq * theta_sq;
+        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
+        real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
+    } else {
+        const double theta = sqrt(theta_sq);
+        const double half = 0.5 * theta;
+        imag = sin(half) / theta;
+        real = cos(half);
+    }
+    const double bx = imag * dx[0], by = imag * dx[1], bz = imag * dx[2], bw = real;
+    const double ax = q[0], ay = q[1], az = q[2], aw = q[3];
+    double rw = aw * bw - ax * bx - ay * by - az * bz;
+    double rx = aw * bx + ax * bw + ay * bz - az * by;
+    double ry = aw * by + ay * bw + az * bx - ax * bz;
+    double rz = aw * bz + az * bw + ax * by - ay * bx;
+    const double sq = rx * rx + ry * ry + rz * rz + rw * rw;
+    if (sq != 1.0) {
+        const double scale = 2.0 / (1.0 + sq);
+        rx *= scale; ry *= scale; rz *= scale; rw *= scale;
+    }
+    q[0] = rx; q[1] = ry; q[2] = rz; q[3] = rw;
+    t[0] += dx[3]; t[1] += dx[4]; t[2] += dx[5];
+}
+
+// 64-lane butterfly sum of a double (two 32-bit DPP/permute moves per step).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace locgpu

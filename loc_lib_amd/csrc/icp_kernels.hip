@@ -1,0 +1,457 @@
+// loc_lib_amd/csrc/icp_kernels.hip — kernel bodies + launchers of the ICP hot path (see icp_kernels.hpp).
+#include "icp_kernels.hpp"
+#include "launch.hpp"
+
+namespace locgpu {
+
+// ---------------------------------------------------------------------------------------------
+// K1: one thread per source point. Grid (ceil(max_n/256), n_scans).
+template <int KMAX, int D, bool COUNT>
+__global__ __launch_bounds__(kBlock) void icp_search_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+                                                            const int* __restrict__ counts, const PoseState* __restrict__ st,
+                                                            uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, int k, float alpha_eff,
+                                                            int skip_nonfinite, unsigned long long* __restrict__ visit_totals) {
+    __shared__ uint32_t s_far[D][kBlock];
+    __shared__ float s_d2[D][kBlock];
+    const int scan = blockIdx.y;
+    if (st[scan].done) return;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    if (i >= counts[scan]) return;
+    const size_t gi = (size_t)scan * max_n + i;
+    const float4 p = src[gi];
+    uint32_t out[KMAX];
+    int cnt = 0;
+    uint32_t nvis = 0, lvis = 0;
+    const bool finite = !skip_nonfinite || (isfinite(p.x) && isfinite(p.y) && isfinite(p.z));  // pcl::isFinite, icp cpp:64 (P2P only)
+    if (finite) {
+        const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
+        KnnHeap<KMAX> heap;
+        tree_knn<KMAX, D, COUNT>(tree, (float)qs.x, (float)qs.y, (float)qs.z, k, alpha_eff, s_far, s_d2, tid, heap, nvis, lvis);
+        heap_to_sorted<KMAX>(heap, out, cnt);
+    } else {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) out[j] = kInvalidSlot;
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+        if (j < k) nn[(size_t)j * nn_pitch + gi] = out[j];
+    if (COUNT) {
+        atomicAdd(&visit_totals[0], (unsigned long long)nvis);
+        atomicAdd(&visit_totals[1], (unsigned long long)lvis);
+        atomicAdd(&visit_totals[2], 1ull);
+    }
+}
+
+// Plain k-NN over given queries (SearchPointInterface::FindNearstPoints). 1-D grid.
+template <int KMAX, int D>
+__global__ __launch_bounds__(kBlock) void knn_query_kernel(const uint2* __restrict__ tree, const float* __restrict__ queries, size_t nq,
+                                                           int k, float alpha_eff, int32_t* __restrict__ out_idx,
+                                                           uint32_t* __restrict__ visits) {
+    __shared__ uint32_t s_far[D][kBlock];
+    __shared__ float s_d2[D][kBlock];
+    const int tid = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * kBlock + tid;
+    if (i >= nq) return;
+    KnnHeap<KMAX> heap;
+    uint32_t nvis = 0, lvis = 0;
+    tree_knn<KMAX, D, true>(tree, queries[3 * i], queries[3 * i + 1], queries[3 * i + 2], k, alpha_eff, s_far, s_d2, tid, heap, nvis, lvis);
+    uint32_t out[KMAX];
+    int cnt;
+    heap_to_sorted<KMAX>(heap, out, cnt);
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+        if (j < k) out_idx[i * k + j] = (out[j] == kInvalidSlot) ? -1 : (int32_t)(tree[out[j]].y & 0x3FFFFFFFu);  // original point index
+    if (visits) { visits[2 * i] = nvis; visits[2 * i + 1] = lvis; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block reduction of `acc[0..NV)` → partials[block][0..NV). Wave butterfly, then LDS across the 4 waves.
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double* __restrict__ dst) {
+    __shared__ double s_part[kBlock / 64][kAccW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const double s = wave_sum(acc[v]);
+        if (lane == 0) s_part[wave][v] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = s_part[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) s += s_part[w][threadIdx.x];
+        dst[threadIdx.x] = s;
+    }
+}
+
+// acc layout: [0..20] upper triangle of H row by row (00 01 .. 05 11 12 .. 55), [21..26] B, [27] effective_num.
+template <int ROWS>
+__device__ __forceinline__ void add_rows(double (&acc)[28], const double (&J)[ROWS][6], const double (&e)[ROWS]) {
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            double s = J[0][i] * J[0][j];
+#pragma unroll
+            for (int r = 1; r < ROWS; ++r) s += J[r][i] * J[r][j];
+            acc[o++] += s;
+        }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = -J[0][i] * e[0];
+#pragma unroll
+        for (int r = 1; r < ROWS; ++r) s += -J[r][i] * e[r];
+        acc[21 + i] += s;
+    }
+}
+
+// R·hat(q), coefficient order of the oracle's left-to-right 3×3 product (zeros of hat() drop out exactly).
+__device__ __forceinline__ void R_hat(const double* R, const D3& q, double (&Rh)[3][3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        Rh[r][0] = R[3 * r + 1] * q.z - R[3 * r + 2] * q.y;
+        Rh[r][1] = R[3 * r + 2] * q.x - R[3 * r + 0] * q.z;
+        Rh[r][2] = R[3 * r + 0] * q.y - R[3 * r + 1] * q.x;
+    }
+}
+
+// K2, P2Plane: IcpRegistration::CaculateMatrixHAndBP2Plane (icp_registration.cpp:161-213) + math::FitPlane (math_utils.h:112-136).
+__global__ __launch_bounds__(kBlock) void icp_plane_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+                                                                 const int* __restrict__ counts, const PoseState* __restrict__ st,
+                                                                 const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
+                                                                 double max_plane_distance, double* __restrict__ partials) {
+    const int scan = blockIdx.y;
+    if (st[scan].done) return;  // uniform per block
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    double acc[28];
+#pragma unroll
+    for (int v = 0; v < 28; ++v) acc[v] = 0.0;
+    if (i < counts[scan]) {
+        const size_t gi = (size_t)scan * max_n + i;
+        const uint32_t s4 = nn[4 * nn_pitch + gi];
+        if (s4 != kInvalidSlot) {  // nn.size() > 3: k=5 yields 5 or (k > size_) none
+            const float4 p = src[gi];
+            const D3 q{(double)p.x, (double)p.y, (double)p.z};
+            const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
+            D3 nb[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, j == 4 ? s4 : nn[(size_t)j * nn_pitch + gi]);
+            double a[4][5], v[4][4];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { a[0][j] = nb[j].x; a[1][j] = nb[j].y; a[2][j] = nb[j].z; a[3][j] = 1.0; }
+            jacobi_svd_onesided<5, 4>(a, v);
+            int best = 0;
+            double bn = 1e300;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double s = 0.0;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) s += a[c][r] * a[c][r];
+                if (s < bn) { bn = s; best = c; }
+            }
+            double n4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) n4[r] = best == 0 ? v[0][r] : (best == 1 ? v[1][r] : (best == 2 ? v[2][r] : v[3][r]));
+            const D3 n3{n4[0], n4[1], n4[2]};
+            bool fit = true;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const double err = dot3(n3, nb[j]) + n4[3];
+                if (err * err > 1e-2) fit = false;
+            }
+            if (fit) {
+                acc[27] = 1.0;  // effective_num++ before the residual gate (icp cpp:184)
+                const double dis = dot3(n3, qs) + n4[3];
+                if (!(fabs(dis) > max_plane_distance)) {
+                    const double* R = st[scan].R;
+                    double nR[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) nR[c] = (-n3.x * R[c] + -n3.y * R[3 + c]) + -n3.z * R[6 + c];
+                    double J[1][6];
+                    J[0][0] = nR[1] * q.z - nR[2] * q.y;
+                    J[0][1] = nR[2] * q.x - nR[0] * q.z;
+                    J[0][2] = nR[0] * q.y - nR[1] * q.x;
+                    J[0][3] = n3.x; J[0][4] = n3.y; J[0][5] = n3.z;
+                    const double e[1] = {dis};
+                    add_rows<1>(acc, J, e);
+                }
+            }
+        }
+    }
+    block_reduce_store<28>(acc, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
+}
+
+// K2', P2P: CaculateMatrixHAndBP2P (icp_registration.cpp:57-103), including the /16 on the rotation block.
+__global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+                                                                 const int* __restrict__ counts, const PoseState* __restrict__ st,
+                                                                 const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
+                                                                 double max_nn_distance, double* __restrict__ partials) {
+    const int scan = blockIdx.y;
+    if (st[scan].done) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    double acc[28];
+#pragma unroll
+    for (int v = 0; v < 28; ++v) acc[v] = 0.0;
+    if (i < counts[scan]) {
+        const size_t gi = (size_t)scan * max_n + i;
+        const uint32_t s0 = nn[gi];
+        if (s0 != kInvalidSlot) {
+            const float4 p = src[gi];
+            const D3 q{(double)p.x, (double)p.y, (double)p.z};
+            const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
+            const D3 e3 = leaf_point(tree, s0) - qs;
+            const double dis2 = dot3(e3, e3);
+            if (!(dis2 > max_nn_distance)) {
+                acc[27] = 1.0;
+                double Rh[3][3];
+                R_hat(st[scan].R, q, Rh);
+                double J[3][6];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { J[r][c] = Rh[r][c] / 16; J[r][3 + c] = (r == c) ? -1.0 : 0.0; }
+                const double e[3] = {e3.x, e3.y, e3.z};
+                add_rows<3>(acc, J, e);
+            }
+        }
+    }
+    block_reduce_store<28>(acc, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
+}
+
+// K2', P2Line: CaculateMatrixHAndBP2Line (icp_registration.cpp:105-159) + math::FitLine (math_utils.h:138-163).
+__global__ __launch_bounds__(kBlock) void icp_line_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+                                                                const int* __restrict__ counts, const PoseState* __restrict__ st,
+                                                                const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
+                                                                double max_line_distance, double* __restrict__ partials) {
+    const int scan = blockIdx.y;
+    if (st[scan].done) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    double acc[28];
+#pragma unroll
+    for (int v = 0; v < 28; ++v) acc[v] = 0.0;
+    if (i < counts[scan]) {
+        const size_t gi = (size_t)scan * max_n + i;
+        const uint32_t s4 = nn[4 * nn_pitch + gi];
+        if (s4 != kInvalidSlot) {  // nn.size() == 5
+            const float4 p = src[gi];
+            const D3 q{(double)p.x, (double)p.y, (double)p.z};
+            const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
+            D3 nb[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, j == 4 ? s4 : nn[(size_t)j * nn_pitch + gi]);
+            D3 sum{0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 5; ++j) sum = sum + nb[j];
+            const D3 p0{sum.x / 5.0, sum.y / 5.0, sum.z / 5.0};
+            double a[3][5], v[3][3];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { const D3 d = nb[j] - p0; a[0][j] = d.x; a[1][j] = d.y; a[2][j] = d.z; }
+            jacobi_svd_onesided<5, 3>(a, v);
+            int best = 0;
+            double bn = -1.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double s = 0.0;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) s += a[c][r] * a[c][r];
+                if (s > bn) { bn = s; best = c; }
+            }
+            D3 d;
+            d.x = best == 0 ? v[0][0] : (best == 1 ? v[1][0] : v[2][0]);
+            d.y = best == 0 ? v[0][1] : (best == 1 ? v[1][1] : v[2][1]);
+            d.z = best == 0 ? v[0][2] : (best == 1 ? v[1][2] : v[2][2]);
+            bool fit = true;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const D3 c = cross3(d, nb[j] - p0);
+                if (dot3(c, c) > max_line_distance) fit = false;
+            }
+            if (fit) {
+                acc[27] = 1.0;
+                const D3 e3 = cross3(d, qs - p0);  // SO3::hat(d) * (qs - p0)
+                if (!(sqrt(dot3(e3, e3)) > max_line_distance)) {
+                    const double hd[3][3] = {{0.0, -d.z, d.y}, {d.z, 0.0, -d.x}, {-d.y, d.x, 0.0}};
+                    const double hq[3][3] = {{0.0, -q.z, q.y}, {q.z, 0.0, -q.x}, {-q.y, q.x, 0.0}};
+                    const double* R = st[scan].R;
+                    double hR[3][3], A[3][3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            double s = hd[r][0] * R[c];
+                            s += hd[r][1] * R[3 + c];
+                            s += hd[r][2] * R[6 + c];
+                            hR[r][c] = s;
+                        }
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            double s = hR[r][0] * hq[0][c];
+                            s += hR[r][1] * hq[1][c];
+                            s += hR[r][2] * hq[2][c];
+                            A[r][c] = s;
+                        }
+                    double J[3][6];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { J[r][c] = -A[r][c]; J[r][3 + c] = hd[r][c]; }
+                    const double e[3] = {e3.x, e3.y, e3.z};
+                    add_rows<3>(acc, J, e);
+                }
+            }
+        }
+    }
+    block_reduce_store<28>(acc, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: one 256-thread block per scan. Sums the block partials in a fixed order, then thread 0 runs the
+// reference's checks and update (icp_registration.cpp:204-211 + 362-375; ndt_registration.cpp:435-459).
+// hb_out (optional): per scan 44 doubles = H (36, row-major), B (6), effective_num, ok.
+__global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restrict__ partials, int blocks_per_scan, PoseState* __restrict__ st,
+                                                          GnParams prm, int do_update, double* __restrict__ hb_out) {
+    __shared__ double s_sum[kBlock / kAccW][kAccW];
+    const int scan = blockIdx.x;
+    if (st[scan].done) return;
+    const int col = threadIdx.x & (kAccW - 1), chunk = threadIdx.x / kAccW;
+    constexpr int kChunks = kBlock / kAccW;
+    double s = 0.0;
+    if (col < 28)
+        for (int b = chunk; b < blocks_per_scan; b += kChunks) s += partials[((size_t)scan * blocks_per_scan + b) * kAccW + col];
+    s_sum[chunk][col] = s;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double tot[28];
+    for (int v = 0; v < 28; ++v) {
+        double t = s_sum[0][v];
+        for (int c = 1; c < kChunks; ++c) t += s_sum[c][v];
+        tot[v] = t;
+    }
+    double H[36], B[6], dx[6] = {0, 0, 0, 0, 0, 0};
+    int o = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { H[6 * i + j] = tot[o]; H[6 * j + i] = tot[o]; ++o; }
+    for (int i = 0; i < 6; ++i) B[i] = tot[21 + i];
+    const long long eff = (long long)tot[27];
+    PoseState& ps = st[scan];
+    bool ok;
+    const double det = lu6_det_solve(H, B, dx);
+    if (prm.method == 3) {
+        // direct NDT: det(H)==0 is tested FIRST and aborts the whole alignment (ndt cpp:435-436)
+        if (det == 0.0) {
+            ps.status = 1; ps.done = 1; ps.iterations += 1; ps.last_eff = eff;
+            if (hb_out) { for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i]; for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i]; hb_out[44 * scan + 42] = (double)eff; hb_out[44 * scan + 43] = 0.0; }
+            return;
+        }
+        ok = eff >= prm.min_effective_pts;
+    } else {
+        ok = (eff >= prm.min_effective_pts) && !(det == 0.0);
+    }
+    if (hb_out) {
+        for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i];
+        for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i];
+        hb_out[44 * scan + 42] = (double)eff;
+        hb_out[44 * scan + 43] = ok ? 1.0 : 0.0;
+    }
+    ps.last_eff = eff;
+    if (!do_update) return;
+    ps.iterations += 1;
+    if (ok) {
+        if (prm.method == 0)
+            for (int i = 0; i < 6; ++i) dx[i] = dx[i] / 16;  // dx = H.inverse()/16 * err (icp cpp:287)
+        se3_apply_update(ps.q, ps.t, dx);
+        quat_to_R(ps.q, ps.R);
+        double n2 = 0.0;
+        for (int i = 0; i < 6; ++i) n2 += dx[i] * dx[i];
+        const double nrm = sqrt(n2);
+        ps.last_dx_norm = nrm;
+        if (nrm < prm.eps) { ps.converged = 1; ps.done = 1; }
+    }
+    if (ps.iterations >= prm.max_iteration) ps.done = 1;
+}
+
+// pcl::transformPointCloud with the float32 4×4 (icp_registration.cpp:241): ((m0·x + m1·y) + m2·z) + m3 per row.
+__global__ __launch_bounds__(kBlock) void transform_cloud_kernel(const float4* __restrict__ src, size_t n, const float* __restrict__ m12,
+                                                                 float4* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = src[i];
+    float4 o;
+    o.x = ((m12[0] * p.x + m12[1] * p.y) + m12[2] * p.z) + m12[3];
+    o.y = ((m12[4] * p.x + m12[5] * p.y) + m12[6] * p.z) + m12[7];
+    o.z = ((m12[8] * p.x + m12[9] * p.y) + m12[10] * p.z) + m12[11];
+    o.w = p.w;
+    dst[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launchers (declared in launch.hpp).
+template <int KMAX, int D>
+static void launch_search_kd(const SearchArgs& a, hipStream_t s) {
+    dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
+    if (a.visit_totals)
+        hipLaunchKernelGGL((icp_search_kernel<KMAX, D, true>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+                           a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals);
+    else
+        hipLaunchKernelGGL((icp_search_kernel<KMAX, D, false>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+                           a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals);
+}
+template <int KMAX>
+static bool launch_search_k(const SearchArgs& a, hipStream_t s) {
+    if (a.depth <= 32) launch_search_kd<KMAX, 32>(a, s);
+    else if (a.depth <= 40) launch_search_kd<KMAX, 40>(a, s);
+    else if (a.depth <= 64) launch_search_kd<KMAX, 64>(a, s);
+    else return false;
+    return true;
+}
+bool launch_icp_search(const SearchArgs& a, hipStream_t s) {
+    if (a.k == 1) return launch_search_k<1>(a, s);
+    if (a.k == 5) return launch_search_k<5>(a, s);
+    return false;
+}
+
+template <int KMAX>
+static bool launch_knn_k(const uint2* tree, int depth, const float* q, size_t nq, int k, float alpha_eff, int32_t* out, uint32_t* visits,
+                         hipStream_t s) {
+    dim3 grid((unsigned)((nq + kBlock - 1) / kBlock));
+    if (depth <= 32) hipLaunchKernelGGL((knn_query_kernel<KMAX, 32>), grid, dim3(kBlock), 0, s, tree, q, nq, k, alpha_eff, out, visits);
+    else if (depth <= 40) hipLaunchKernelGGL((knn_query_kernel<KMAX, 40>), grid, dim3(kBlock), 0, s, tree, q, nq, k, alpha_eff, out, visits);
+    else if (depth <= 64) hipLaunchKernelGGL((knn_query_kernel<KMAX, 64>), grid, dim3(kBlock), 0, s, tree, q, nq, k, alpha_eff, out, visits);
+    else return false;
+    return true;
+}
+bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, int k, float alpha_eff, int32_t* out, uint32_t* visits,
+                      hipStream_t s) {
+    if (k == 1) return launch_knn_k<1>(tree, depth, q, nq, k, alpha_eff, out, visits, s);
+    if (k <= 5) return launch_knn_k<5>(tree, depth, q, nq, k, alpha_eff, out, visits, s);
+    if (k <= 8) return launch_knn_k<8>(tree, depth, q, nq, k, alpha_eff, out, visits, s);
+    return false;
+}
+
+void launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
+    dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
+    if (method == 2)
+        hipLaunchKernelGGL(icp_plane_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate,
+                           a.partials);
+    else if (method == 1)
+        hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate,
+                           a.partials);
+    else
+        hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate,
+                           a.partials);
+}
+
+void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(gn_solve_kernel, dim3(n_scans), dim3(kBlock), 0, s, partials, blocks_per_scan, st, prm, do_update, hb_out);
+}
+
+void launch_transform_cloud(const float4* src, size_t n, const float* m12, float4* dst, hipStream_t s) {
+    hipLaunchKernelGGL(transform_cloud_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, src, n, m12, dst);
+}
+
+}  // namespace locgpu

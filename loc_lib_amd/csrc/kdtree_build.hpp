@@ -1,0 +1,21 @@
+// loc_lib_amd/csrc/kdtree_build.hpp — host-side packed KD-tree ingest (see kdtree_build.cpp).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace locgpu {
+
+struct PackedKdTree {
+    std::vector<uint64_t> slots;  // 8-byte slots, preorder (layout in kdtree_build.cpp)
+    size_t num_leaves = 0;        // KdTree::size_ (kdtree.h:124)
+    size_t num_nodes = 0;         // internal + leaf nodes
+    size_t num_points = 0;
+    int depth = 0;                // root = level 1
+};
+
+// xyz: n packed float32 triples. Returns false and sets err on failure.
+bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::string& err);
+
+}  // namespace locgpu

@@ -1,0 +1,46 @@
+// loc_lib_amd/csrc/launch.hpp — host-callable launchers of the kernels in icp_kernels.hip / ndt_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.hpp"
+
+namespace locgpu {
+
+struct GnParams;
+
+struct SearchArgs {
+    const uint2* tree;
+    int depth;
+    const float4* src;
+    const int* counts;
+    const PoseState* st;
+    uint32_t* nn;
+    size_t nn_pitch;
+    int max_n, n_scans, k;
+    float alpha_eff;
+    int skip_nonfinite;
+    unsigned long long* visit_totals;  // null unless visit counting is on
+};
+
+struct AccumArgs {
+    const uint2* tree;
+    const float4* src;
+    const int* counts;
+    const PoseState* st;
+    const uint32_t* nn;
+    size_t nn_pitch;
+    int max_n, n_scans;
+    double gate;        // max_plane / max_line / max_nn distance
+    double* partials;   // [n_scans][blocks_per_scan][kAccW]
+};
+
+bool launch_icp_search(const SearchArgs& a, hipStream_t s);
+bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, int k, float alpha_eff, int32_t* out, uint32_t* visits,
+                      hipStream_t s);
+void launch_icp_accum(int method, const AccumArgs& a, hipStream_t s);
+void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
+                     hipStream_t s);
+void launch_transform_cloud(const float4* src, size_t n, const float* m12, float4* dst, hipStream_t s);
+
+}  // namespace locgpu

@@ -1,0 +1,658 @@
+// loc_lib_amd/csrc/locgpu_api.hip — C ABI of include/locgpu.h: context, ICP target ingest, search, H/B, align, batch.
+//
+// Host control flow mirrors the reference's matcher (IcpRegistration, icp_registration.cpp): SetInputTarget
+// builds the search structure once per map; ScanMatch runs the Gauss–Newton loop. Here the loop body is three
+// kernel launches per iteration on one HIP stream and the convergence test lives on the device, so the host only
+// reads back the small per-scan state every `kChunk` iterations.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "context.hpp"
+#include "kdtree_build.hpp"
+#include "launch.hpp"
+
+using namespace locgpu;
+
+namespace {
+std::string g_create_err;
+constexpr int kChunk = 2;  // GN iterations enqueued between two host reads of the convergence flags
+}  // namespace
+
+namespace locgpu {
+int fail(locgpu_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    else g_create_err = msg;
+    return code;
+}
+bool hip_ok(locgpu_ctx* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+}  // namespace locgpu
+
+static void free_batch(locgpu_batch* b) {
+    if (!b) return;
+    if (b->d_src) (void)hipFree(b->d_src);
+    if (b->d_counts) (void)hipFree(b->d_counts);
+    if (b->d_state) (void)hipFree(b->d_state);
+    if (b->d_nn) (void)hipFree(b->d_nn);
+    if (b->d_partials) (void)hipFree(b->d_partials);
+    if (b->d_hb) (void)hipFree(b->d_hb);
+    if (b->h_state) (void)hipHostFree(b->h_state);
+    if (b->h_hb) (void)hipHostFree(b->h_hb);
+    delete b;
+}
+
+extern "C" {
+
+void locgpu_icp_opts_default(locgpu_icp_opts* o) {
+    if (!o) return;
+    o->method = LOCGPU_P2P;  // IcpOptions::method_{IcpMethod::P2P}, icp_registration.hpp:38
+    o->max_iteration = 20;
+    o->max_nn_distance = 1.0;
+    o->max_plane_distance = 0.1;
+    o->max_line_distance = 0.5;
+    o->min_effective_pts = 10;
+    o->eps = 1e-2;
+    o->approximate = 1;
+    o->ann_alpha = 0.1f;
+    o->search_mode = LOCGPU_SEARCH_TREE_FAITHFUL;
+}
+
+void locgpu_ndt_opts_default(locgpu_ndt_opts* o) {
+    if (!o) return;
+    o->max_iteration = 20;
+    o->voxel_size = 1.0;
+    o->min_effective_pts = 10;
+    o->min_pts_in_voxel = 3;
+    o->eps = 1e-2;
+    o->res_outlier_th = 20.0;
+    o->nearby_type = 1;
+}
+
+int locgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int locgpu_create(int device_id, locgpu_ctx** out) {
+    if (!out) return fail(nullptr, LOCGPU_ERR_INVALID, "locgpu_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, LOCGPU_ERR_NO_DEVICE, std::string("no HIP device available (there is no CPU fallback): ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, LOCGPU_ERR_INVALID, "locgpu_create: device_id out of range");
+    auto* ctx = new locgpu_ctx();
+    ctx->device = device_id;
+    locgpu_ndt_opts_default(&ctx->ndt_opts);
+    if (!hip_ok(nullptr, hipSetDevice(device_id), "hipSetDevice") ||
+        !hip_ok(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate")) {
+        delete ctx;
+        return LOCGPU_ERR_NO_DEVICE;
+    }
+    *out = ctx;
+    return LOCGPU_OK;
+}
+
+void locgpu_destroy(locgpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_batch(ctx->single);
+    if (ctx->d_tree) (void)hipFree(ctx->d_tree);
+    if (ctx->d_visits) (void)hipFree(ctx->d_visits);
+    ndt_free(ctx);
+    for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* locgpu_last_error(const locgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+// --------------------------------------------------------------------------------------------- target
+int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!pts || n == 0 || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: empty cloud or stride < 12");
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    // deep copy (icp_registration.cpp:16 + kdtree.cpp:267 copy too): pack xyz
+    std::vector<float> xyz(3 * n);
+    const char* base = (const char*)pts;
+    for (size_t i = 0; i < n; ++i) std::memcpy(&xyz[3 * i], base + i * stride_bytes, 12);
+    PackedKdTree t;
+    std::string err;
+    if (!build_packed_kdtree(xyz.data(), n, t, err)) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: " + err);
+    if (t.depth > 64) return fail(ctx, LOCGPU_ERR_DEPTH, "icp_set_target: KD-tree depth " + std::to_string(t.depth) + " exceeds the 64-entry traversal stack");
+    if (ctx->d_tree) { LOCGPU_HIP(ctx, hipFree(ctx->d_tree)); ctx->d_tree = nullptr; }
+    LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_tree, t.slots.size() * sizeof(uint64_t)));
+    LOCGPU_HIP(ctx, hipMemcpy(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    ctx->tree_slots = t.slots.size();
+    ctx->num_leaves = t.num_leaves;
+    ctx->num_nodes = t.num_nodes;
+    ctx->num_points = t.num_points;
+    ctx->depth = t.depth;
+    return LOCGPU_OK;
+}
+
+int locgpu_icp_target_info(const locgpu_ctx* ctx, int64_t out[4]) {
+    if (!ctx || !out) return LOCGPU_ERR_INVALID;
+    out[0] = (int64_t)ctx->num_leaves;
+    out[1] = (int64_t)ctx->num_nodes;
+    out[2] = ctx->depth;
+    out[3] = (int64_t)(ctx->tree_slots * sizeof(uint64_t));
+    return ctx->d_tree ? LOCGPU_OK : LOCGPU_ERR_NO_TARGET;
+}
+
+// --------------------------------------------------------------------------------------------- k-NN
+int locgpu_knn(locgpu_ctx* ctx, const float* queries, size_t nq, int k, int approximate, float alpha, int search_mode, int32_t* out_idx,
+               uint32_t* visits) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!ctx->d_tree) return fail(ctx, LOCGPU_ERR_NO_TARGET, "knn: no target set");
+    if (!queries || !out_idx || k < 1 || k > 8) return fail(ctx, LOCGPU_ERR_INVALID, "knn: bad arguments (1 <= k <= 8)");
+    if (search_mode != LOCGPU_SEARCH_TREE_FAITHFUL) return fail(ctx, LOCGPU_ERR_INVALID, "knn: search mode not available");
+    if ((size_t)k > ctx->num_leaves) return fail(ctx, LOCGPU_ERR_K_TOO_LARGE, "knn: k larger than the number of tree leaves");
+    if (nq == 0) return LOCGPU_OK;
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    float* d_q = nullptr;
+    int32_t* d_out = nullptr;
+    uint32_t* d_vis = nullptr;
+    int rc = LOCGPU_OK;
+    auto cleanup = [&]() { if (d_q) (void)hipFree(d_q); if (d_out) (void)hipFree(d_out); if (d_vis) (void)hipFree(d_vis); };
+    if (!hip_ok(ctx, hipMalloc((void**)&d_q, nq * 12), "hipMalloc") || !hip_ok(ctx, hipMalloc((void**)&d_out, nq * k * 4), "hipMalloc") ||
+        (visits && !hip_ok(ctx, hipMalloc((void**)&d_vis, nq * 8), "hipMalloc"))) {
+        cleanup();
+        return LOCGPU_ERR_OOM;
+    }
+    if (!hip_ok(ctx, hipMemcpyAsync(d_q, queries, nq * 12, hipMemcpyHostToDevice, ctx->stream), "H2D")) rc = LOCGPU_ERR_NO_DEVICE;
+    if (rc == LOCGPU_OK && !launch_knn_query(ctx->d_tree, ctx->depth, d_q, nq, k, approximate ? alpha : 1.0f, d_out, d_vis, ctx->stream))
+        rc = fail(ctx, LOCGPU_ERR_DEPTH, "knn: unsupported k/depth");
+    if (rc == LOCGPU_OK && !hip_ok(ctx, hipGetLastError(), "knn launch")) rc = LOCGPU_ERR_NO_DEVICE;
+    if (rc == LOCGPU_OK && !hip_ok(ctx, hipMemcpyAsync(out_idx, d_out, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream), "D2H")) rc = LOCGPU_ERR_NO_DEVICE;
+    if (rc == LOCGPU_OK && visits && !hip_ok(ctx, hipMemcpyAsync(visits, d_vis, nq * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H")) rc = LOCGPU_ERR_NO_DEVICE;
+    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync") && rc == LOCGPU_OK) rc = LOCGPU_ERR_NO_DEVICE;
+    cleanup();
+    return rc;
+}
+
+// --------------------------------------------------------------------------------------------- batches
+static int make_batch(locgpu_ctx* ctx, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_scans, locgpu_batch** out) {
+    if (!ctx || !out) return LOCGPU_ERR_INVALID;
+    *out = nullptr;
+    if (n_scans <= 0 || !srcs || !counts || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: bad arguments");
+    if (n_scans > 65535) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: at most 65535 scans per batch");
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    size_t max_n = 0;
+    for (int s = 0; s < n_scans; ++s) max_n = std::max(max_n, counts[s]);
+    if (max_n == 0 || max_n > 0x7FFFFF00u) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: scans are empty or too large");
+    auto* b = new locgpu_batch();
+    b->ctx = ctx;
+    b->n_scans = n_scans;
+    b->max_n = (int)max_n;
+    b->blocks_per_scan = (int)((max_n + kBlock - 1) / kBlock);
+    b->pitch = (size_t)n_scans * max_n;
+    b->counts.resize(n_scans);
+    for (int s = 0; s < n_scans; ++s) b->counts[s] = (int)counts[s];
+    bool ok = hip_ok(ctx, hipMalloc((void**)&b->d_src, b->pitch * sizeof(float4)), "hipMalloc src") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_counts, n_scans * sizeof(int)), "hipMalloc counts") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_state, n_scans * sizeof(PoseState)), "hipMalloc state") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_nn, 5 * b->pitch * sizeof(uint32_t)), "hipMalloc nn") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_partials, (size_t)n_scans * b->blocks_per_scan * kAccW * sizeof(double)), "hipMalloc partials") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_hb, (size_t)n_scans * 44 * sizeof(double)), "hipMalloc hb") &&
+              hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_scans * sizeof(PoseState)), "hipHostMalloc state") &&
+              hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_scans * 44 * sizeof(double)), "hipHostMalloc hb");
+    if (!ok) { free_batch(b); return LOCGPU_ERR_OOM; }
+    // deep copy of the sources (icp_registration.cpp:259): pack to float4 {x,y,z,0}
+    std::vector<float4> host(b->pitch, float4{0.f, 0.f, 0.f, 0.f});
+    for (int s = 0; s < n_scans; ++s) {
+        const char* base = (const char*)srcs[s];
+        if (!base && counts[s]) { free_batch(b); return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: NULL scan pointer"); }
+        float4* dst = host.data() + (size_t)s * max_n;
+        for (size_t i = 0; i < counts[s]; ++i) std::memcpy(&dst[i], base + i * stride_bytes, 12);
+    }
+    ok = hip_ok(ctx, hipMemcpy(b->d_src, host.data(), b->pitch * sizeof(float4), hipMemcpyHostToDevice), "H2D src") &&
+         hip_ok(ctx, hipMemcpy(b->d_counts, b->counts.data(), n_scans * sizeof(int), hipMemcpyHostToDevice), "H2D counts");
+    if (!ok) { free_batch(b); return LOCGPU_ERR_NO_DEVICE; }
+    *out = b;
+    return LOCGPU_OK;
+}
+
+int locgpu_batch_create(locgpu_ctx* ctx, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_scans, locgpu_batch** out) {
+    return make_batch(ctx, srcs, counts, stride_bytes, n_scans, out);
+}
+
+void locgpu_batch_destroy(locgpu_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    free_batch(b);
+}
+
+}  // extern "C"
+
+// --------------------------------------------------------------------------------------------- GN driver
+namespace locgpu {
+
+static void init_states(locgpu_batch* b, const double* poses) {
+    for (int s = 0; s < b->n_scans; ++s) {
+        PoseState& ps = b->h_state[s];
+        std::memset(&ps, 0, sizeof(ps));
+        for (int i = 0; i < 4; ++i) ps.q[i] = poses[7 * s + i];
+        for (int i = 0; i < 3; ++i) ps.t[i] = poses[7 * s + 4 + i];
+        quat_to_R(ps.q, ps.R);
+        if (b->counts[s] == 0) ps.done = 0;  // an empty scan still runs the loop: effective_num < min ⇒ no-op iterations
+    }
+}
+
+static hipEvent_t get_event(locgpu_ctx* ctx, size_t i) {
+    while (ctx->events.size() <= i) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        ctx->events.push_back(ev);
+    }
+    return ctx->events[i];
+}
+
+struct IterLauncher {
+    locgpu_ctx* ctx;
+    locgpu_batch* b;
+    GnParams prm;
+    int k;
+    float alpha_eff;
+    size_t ev_used = 0;
+
+    // One GN iteration = search + accumulate + solve. Returns false on a launch error.
+    bool ndt = false;
+    bool launch(int do_update);
+    void collect_profile();
+};
+
+}  // namespace locgpu
+
+#include "ndt_kernels.hpp"
+
+namespace locgpu {
+
+bool IterLauncher::launch(int do_update) {
+    hipStream_t s = ctx->stream;
+    const bool prof = ctx->profile;
+    auto mark = [&]() {
+        if (!prof) return;
+        hipEvent_t ev = get_event(ctx, ev_used);
+        if (ev) { (void)hipEventRecord(ev, s); ev_used++; }
+    };
+    mark();
+    if (!ndt) {
+        SearchArgs sa{ctx->d_tree, ctx->depth, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, k, alpha_eff,
+                      prm.method == LOCGPU_P2P ? 1 : 0, ctx->count_visits ? ctx->d_visits : nullptr};
+        if (!launch_icp_search(sa, s)) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
+        mark();
+        const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
+        AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
+        launch_icp_accum(prm.method, aa, s);
+    } else {
+        mark();  // NDT has no separate search kernel: search slot stays empty
+        launch_ndt_accum(ctx->ndt, b->d_src, b->d_counts, b->d_state, b->max_n, b->n_scans, b->d_partials, s);
+    }
+    mark();
+    launch_gn_solve(b->d_partials, b->blocks_per_scan, b->d_state, b->n_scans, prm, do_update, b->d_hb, s);
+    mark();
+    return hip_ok(ctx, hipGetLastError(), "kernel launch");
+}
+
+void IterLauncher::collect_profile() {
+    // launch() records four events per iteration: [0,1] search, [1,2] fit+accumulate, [2,3] solve.
+    if (ctx->profile) {
+        for (size_t i = 0; i + 3 < ev_used; i += 4)
+            for (int j = 0; j < 3; ++j) {
+                if (ndt && j == 0) continue;  // NDT has no search kernel
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ctx->events[i + j], ctx->events[i + j + 1]) == hipSuccess) {
+                    ctx->prof_ms[j] += ms;
+                    ctx->prof_n[j] += 1;
+                }
+            }
+    }
+    ev_used = 0;
+}
+
+static int run_align(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt,
+                     double* out_poses, locgpu_align_stats* stats) {
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    init_states(b, init_poses);
+    hipStream_t s = ctx->stream;
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_scans * sizeof(PoseState), hipMemcpyHostToDevice, s));
+    IterLauncher it{ctx, b, prm, k, alpha_eff};
+    it.ndt = ndt;
+    int launched = 0;
+    bool all_done = prm.max_iteration <= 0;
+    while (!all_done) {
+        const int todo = std::min(kChunk, prm.max_iteration - launched);
+        for (int c = 0; c < todo; ++c)
+            if (!it.launch(1)) return LOCGPU_ERR_NO_DEVICE;
+        launched += todo;
+        LOCGPU_HIP(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_scans * sizeof(PoseState), hipMemcpyDeviceToHost, s));
+        LOCGPU_HIP(ctx, hipStreamSynchronize(s));
+        it.collect_profile();
+        all_done = true;
+        for (int i = 0; i < b->n_scans; ++i)
+            if (!b->h_state[i].done) { all_done = false; break; }
+        if (launched >= prm.max_iteration) all_done = true;
+    }
+    for (int i = 0; i < b->n_scans; ++i) {
+        const PoseState& ps = b->h_state[i];
+        if (ps.status == 1) {  // direct NDT aborted: reference leaves result_pose unassigned; hand back init_pose
+            for (int j = 0; j < 7; ++j) out_poses[7 * i + j] = init_poses[7 * i + j];
+        } else {
+            for (int j = 0; j < 4; ++j) out_poses[7 * i + j] = ps.q[j];
+            for (int j = 0; j < 3; ++j) out_poses[7 * i + 4 + j] = ps.t[j];
+        }
+        if (stats) {
+            stats[i].iterations = ps.iterations;
+            stats[i].converged = ps.converged;
+            stats[i].status = ps.status;
+            stats[i].reserved = 0;
+            stats[i].last_effective_num = ps.last_eff;
+            stats[i].last_dx_norm = ps.last_dx_norm;
+        }
+    }
+    return LOCGPU_OK;
+}
+
+static int check_icp(locgpu_ctx* ctx, const locgpu_icp_opts* o, GnParams& prm, int& k, float& alpha_eff) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!o) return fail(ctx, LOCGPU_ERR_INVALID, "icp: opts is NULL");
+    if (!ctx->d_tree) return fail(ctx, LOCGPU_ERR_NO_TARGET, "icp: SetInputTarget has not been called");
+    if (o->method < LOCGPU_P2P || o->method > LOCGPU_P2PLANE) return fail(ctx, LOCGPU_ERR_INVALID, "icp: unknown method");
+    if (o->search_mode != LOCGPU_SEARCH_TREE_FAITHFUL) return fail(ctx, LOCGPU_ERR_INVALID, "icp: search mode not available in this build");
+    prm.method = o->method;
+    prm.max_iteration = o->max_iteration;
+    prm.min_effective_pts = o->min_effective_pts;
+    prm.eps = o->eps;
+    prm.max_nn_distance = o->max_nn_distance;
+    prm.max_plane_distance = o->max_plane_distance;
+    prm.max_line_distance = o->max_line_distance;
+    k = o->method == LOCGPU_P2P ? 1 : 5;
+    alpha_eff = o->approximate ? o->ann_alpha : 1.0f;
+    // k > size_: GetClosestPoint logs an error and returns nothing (kdtree.cpp:149-153) ⇒ no correspondences at all.
+    // The search kernel reproduces that by never filling the k-th slot; nothing to reject here.
+    return LOCGPU_OK;
+}
+
+static int single_batch(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, locgpu_batch** out) {
+    // The reference deep-copies the source on every call (SetSource, icp_registration.cpp:252-265); so do we.
+    if (ctx->single) { free_batch(ctx->single); ctx->single = nullptr; }
+    const void* srcs[1] = {src};
+    const size_t counts[1] = {n};
+    if (n == 0) return fail(ctx, LOCGPU_ERR_INVALID, "source cloud is empty");
+    const int rc = make_batch(ctx, srcs, counts, stride_bytes, 1, &ctx->single);
+    *out = ctx->single;
+    return rc;
+}
+
+}  // namespace locgpu
+
+extern "C" {
+
+int locgpu_icp_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const locgpu_icp_opts* opts, double* out_poses,
+                           locgpu_align_stats* stats) {
+    GnParams prm;
+    int k;
+    float alpha_eff;
+    const int rc = check_icp(ctx, opts, prm, k, alpha_eff);
+    if (rc != LOCGPU_OK) return rc;
+    if (!b || b->ctx != ctx || !init_poses || !out_poses) return fail(ctx, LOCGPU_ERR_INVALID, "icp_align_batch: bad arguments");
+    return run_align(ctx, b, init_poses, prm, k, alpha_eff, false, out_poses, stats);
+}
+
+int locgpu_icp_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7], const locgpu_icp_opts* opts,
+                     double out_pose[7], locgpu_align_stats* stats) {
+    GnParams prm;
+    int k;
+    float alpha_eff;
+    int rc = check_icp(ctx, opts, prm, k, alpha_eff);
+    if (rc != LOCGPU_OK) return rc;
+    if (!src || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "icp_align: bad arguments");
+    locgpu_batch* b = nullptr;
+    rc = single_batch(ctx, src, n, stride_bytes, &b);
+    if (rc != LOCGPU_OK) return rc;
+    return run_align(ctx, b, init_pose, prm, k, alpha_eff, false, out_pose, stats);
+}
+
+int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* poses, const locgpu_icp_opts* opts, double* hb) {
+    GnParams prm;
+    int k;
+    float alpha_eff;
+    const int rc = check_icp(ctx, opts, prm, k, alpha_eff);
+    if (rc != LOCGPU_OK) return rc;
+    if (!b || b->ctx != ctx || !poses || !hb) return fail(ctx, LOCGPU_ERR_INVALID, "icp_hb_batch: bad arguments");
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    init_states(b, poses);
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_scans * sizeof(PoseState), hipMemcpyHostToDevice, ctx->stream));
+    IterLauncher it{ctx, b, prm, k, alpha_eff};
+    if (!it.launch(0)) return LOCGPU_ERR_NO_DEVICE;
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->h_hb, b->d_hb, (size_t)b->n_scans * 44 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    it.collect_profile();
+    std::memcpy(hb, b->h_hb, (size_t)b->n_scans * 44 * sizeof(double));
+    return LOCGPU_OK;
+}
+
+int locgpu_icp_hb(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double pose[7], const locgpu_icp_opts* opts, double H[36],
+                  double B[6], int64_t* effective_num, int* ok) {
+    GnParams prm;
+    int k;
+    float alpha_eff;
+    int rc = check_icp(ctx, opts, prm, k, alpha_eff);
+    if (rc != LOCGPU_OK) return rc;
+    if (!src || !pose || !H || !B) return fail(ctx, LOCGPU_ERR_INVALID, "icp_hb: bad arguments");
+    locgpu_batch* b = nullptr;
+    rc = single_batch(ctx, src, n, stride_bytes, &b);
+    if (rc != LOCGPU_OK) return rc;
+    double hb[44];
+    rc = locgpu_icp_hb_batch(ctx, b, pose, opts, hb);
+    if (rc != LOCGPU_OK) return rc;
+    std::memcpy(H, hb, 36 * sizeof(double));
+    std::memcpy(B, hb + 36, 6 * sizeof(double));
+    if (effective_num) *effective_num = (int64_t)hb[42];
+    if (ok) *ok = hb[43] != 0.0;
+    return LOCGPU_OK;
+}
+
+int locgpu_gn_update(const double hb[44], int method, int min_effective_pts, double eps, double pose[7], double dx[6], int* applied, int* stop) {
+    if (!hb || !pose || !dx) return LOCGPU_ERR_INVALID;
+    for (int i = 0; i < 6; ++i) dx[i] = 0.0;
+    if (applied) *applied = 0;
+    if (stop) *stop = 0;
+    const double det = lu6_det_solve(hb, hb + 36, dx);
+    const bool ok = ((long long)hb[42] >= min_effective_pts) && !(det == 0.0);
+    if (!ok) { for (int i = 0; i < 6; ++i) dx[i] = 0.0; return LOCGPU_OK; }
+    if (method == LOCGPU_P2P)
+        for (int i = 0; i < 6; ++i) dx[i] = dx[i] / 16;
+    se3_apply_update(pose, pose + 4, dx);
+    double n2 = 0.0;
+    for (int i = 0; i < 6; ++i) n2 += dx[i] * dx[i];
+    if (applied) *applied = 1;
+    if (stop) *stop = std::sqrt(n2) < eps;
+    return LOCGPU_OK;
+}
+
+int locgpu_transform_cloud(locgpu_ctx* ctx, const double pose[7], const void* src, size_t n, size_t src_stride_bytes, void* out,
+                           size_t out_stride_bytes) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!pose || (n && (!src || !out)) || src_stride_bytes < 12 || out_stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "transform_cloud: bad arguments");
+    if (n == 0) return LOCGPU_OK;
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    double R[9];
+    quat_to_R(pose, R);
+    float m12[12];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) m12[4 * r + c] = (float)R[3 * r + c];
+        m12[4 * r + 3] = (float)pose[4 + r];
+    }
+    std::vector<float4> host(n);
+    const char* base = (const char*)src;
+    for (size_t i = 0; i < n; ++i) { host[i] = float4{0.f, 0.f, 0.f, 0.f}; std::memcpy(&host[i], base + i * src_stride_bytes, 12); }
+    float4 *d_in = nullptr, *d_out = nullptr;
+    float* d_m = nullptr;
+    int rc = LOCGPU_OK;
+    if (!hip_ok(ctx, hipMalloc((void**)&d_in, n * sizeof(float4)), "hipMalloc") || !hip_ok(ctx, hipMalloc((void**)&d_out, n * sizeof(float4)), "hipMalloc") ||
+        !hip_ok(ctx, hipMalloc((void**)&d_m, sizeof(m12)), "hipMalloc"))
+        rc = LOCGPU_ERR_OOM;
+    if (rc == LOCGPU_OK) {
+        hipStream_t s = ctx->stream;
+        bool ok = hip_ok(ctx, hipMemcpyAsync(d_in, host.data(), n * sizeof(float4), hipMemcpyHostToDevice, s), "H2D") &&
+                  hip_ok(ctx, hipMemcpyAsync(d_m, m12, sizeof(m12), hipMemcpyHostToDevice, s), "H2D");
+        if (ok) {
+            launch_transform_cloud(d_in, n, d_m, d_out, s);
+            ok = hip_ok(ctx, hipGetLastError(), "transform launch") &&
+                 hip_ok(ctx, hipMemcpyAsync(host.data(), d_out, n * sizeof(float4), hipMemcpyDeviceToHost, s), "D2H") &&
+                 hip_ok(ctx, hipStreamSynchronize(s), "sync");
+        }
+        if (!ok) rc = LOCGPU_ERR_NO_DEVICE;
+    }
+    if (rc == LOCGPU_OK) {
+        char* ob = (char*)out;
+        for (size_t i = 0; i < n; ++i) std::memcpy(ob + i * out_stride_bytes, &host[i], 12);
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_m) (void)hipFree(d_m);
+    return rc;
+}
+
+// --------------------------------------------------------------------------------------------- measurement
+int locgpu_profile_enable(locgpu_ctx* ctx, int on) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    ctx->profile = on != 0;
+    return LOCGPU_OK;
+}
+
+int locgpu_profile_read(locgpu_ctx* ctx, double out[6], int reset) {
+    if (!ctx || !out) return LOCGPU_ERR_INVALID;
+    for (int j = 0; j < 3; ++j) {
+        out[j] = ctx->prof_n[j] ? ctx->prof_ms[j] / (double)ctx->prof_n[j] : 0.0;
+        out[3 + j] = (double)ctx->prof_n[j];
+    }
+    if (reset)
+        for (int j = 0; j < 3; ++j) { ctx->prof_ms[j] = 0; ctx->prof_n[j] = 0; }
+    return LOCGPU_OK;
+}
+
+int locgpu_visit_count_enable(locgpu_ctx* ctx, int on) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    if (on && !ctx->d_visits) {
+        LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_visits, 3 * sizeof(unsigned long long)));
+        LOCGPU_HIP(ctx, hipMemset(ctx->d_visits, 0, 3 * sizeof(unsigned long long)));
+    }
+    ctx->count_visits = on != 0;
+    return LOCGPU_OK;
+}
+
+int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset) {
+    if (!ctx || !out) return LOCGPU_ERR_INVALID;
+    out[0] = out[1] = out[2] = 0;
+    if (!ctx->d_visits) return LOCGPU_OK;
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long h[3];
+    LOCGPU_HIP(ctx, hipMemcpy(h, ctx->d_visits, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    if (reset) LOCGPU_HIP(ctx, hipMemset(ctx->d_visits, 0, sizeof(h)));
+    return LOCGPU_OK;
+}
+
+}  // extern "C"
+
+// --------------------------------------------------------------------------------------------- NDT
+namespace locgpu {
+void ndt_free(locgpu_ctx* ctx) {
+    if (ctx->ndt) { ndt_table_free(*ctx->ndt); delete ctx->ndt; ctx->ndt = nullptr; }
+}
+static int check_ndt(locgpu_ctx* ctx, GnParams& prm) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!ctx->ndt) return fail(ctx, LOCGPU_ERR_NO_TARGET, "ndt: SetInputTarget has not been called");
+    prm.method = 3;
+    prm.max_iteration = ctx->ndt_opts.max_iteration;
+    prm.min_effective_pts = ctx->ndt_opts.min_effective_pts;
+    prm.eps = ctx->ndt_opts.eps;
+    prm.max_nn_distance = prm.max_plane_distance = prm.max_line_distance = 0.0;
+    return LOCGPU_OK;
+}
+}  // namespace locgpu
+
+extern "C" {
+
+int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, const locgpu_ndt_opts* opts) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!pts || n == 0 || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: empty cloud or stride < 12");
+    locgpu_ndt_opts o;
+    if (opts) o = *opts; else locgpu_ndt_opts_default(&o);
+    if (!(o.voxel_size > 0.0) || (o.nearby_type != 0 && o.nearby_type != 1)) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: bad options");
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<float4> host(n);
+    const char* base = (const char*)pts;
+    for (size_t i = 0; i < n; ++i) { host[i] = float4{0.f, 0.f, 0.f, 0.f}; std::memcpy(&host[i], base + i * stride_bytes, 12); }
+    float4* d_pts = nullptr;
+    LOCGPU_HIP(ctx, hipMalloc((void**)&d_pts, n * sizeof(float4)));
+    if (!hip_ok(ctx, hipMemcpy(d_pts, host.data(), n * sizeof(float4), hipMemcpyHostToDevice), "H2D map")) { (void)hipFree(d_pts); return LOCGPU_ERR_NO_DEVICE; }
+    if (!ctx->ndt) ctx->ndt = new NdtTable();
+    bool bad_key = false;
+    const hipError_t e = ndt_build(*ctx->ndt, d_pts, n, o.voxel_size, o.min_pts_in_voxel, ctx->stream, &bad_key);
+    (void)hipFree(d_pts);
+    if (e != hipSuccess) { ndt_free(ctx); hip_ok(ctx, e, "ndt_build"); return LOCGPU_ERR_NO_DEVICE; }
+    if (bad_key) { ndt_free(ctx); return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: a point lies outside the +-2^20-voxel key range"); }
+    ctx->ndt->res_outlier_th = o.res_outlier_th;
+    ctx->ndt->n_nearby = o.nearby_type == 0 ? 1 : 7;
+    ctx->ndt_opts = o;
+    return LOCGPU_OK;
+}
+
+int locgpu_ndt_target_info(const locgpu_ctx* ctx, int64_t out[3]) {
+    if (!ctx || !out) return LOCGPU_ERR_INVALID;
+    if (!ctx->ndt) { out[0] = out[1] = out[2] = 0; return LOCGPU_ERR_NO_TARGET; }
+    out[0] = (int64_t)ctx->ndt->n_vox;
+    out[1] = (int64_t)ctx->ndt->cap;
+    out[2] = (int64_t)(ctx->ndt->cap * 12 + ctx->ndt->n_vox * (3 + 9) * 8 + ctx->ndt->n_vox * 12);
+    return LOCGPU_OK;
+}
+
+int locgpu_ndt_dump(locgpu_ctx* ctx, int32_t* keys, double* mu, double* info, size_t cap, size_t* n_out) {
+    if (!ctx || !n_out) return LOCGPU_ERR_INVALID;
+    if (!ctx->ndt) return fail(ctx, LOCGPU_ERR_NO_TARGET, "ndt_dump: no target");
+    *n_out = ctx->ndt->n_vox;
+    const size_t n = std::min(cap, ctx->ndt->n_vox);
+    if (n == 0) return LOCGPU_OK;
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    if (keys) LOCGPU_HIP(ctx, hipMemcpy(keys, ctx->ndt->d_vox_key, n * 3 * sizeof(int), hipMemcpyDeviceToHost));
+    if (mu) LOCGPU_HIP(ctx, hipMemcpy(mu, ctx->ndt->d_mu, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (info) LOCGPU_HIP(ctx, hipMemcpy(info, ctx->ndt->d_info, n * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    return LOCGPU_OK;
+}
+
+int locgpu_ndt_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, double* out_poses, locgpu_align_stats* stats) {
+    GnParams prm;
+    const int rc = check_ndt(ctx, prm);
+    if (rc != LOCGPU_OK) return rc;
+    if (!b || b->ctx != ctx || !init_poses || !out_poses) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_batch: bad arguments");
+    return run_align(ctx, b, init_poses, prm, 0, 1.0f, true, out_poses, stats);
+}
+
+int locgpu_ndt_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7], double out_pose[7],
+                     locgpu_align_stats* stats) {
+    GnParams prm;
+    int rc = check_ndt(ctx, prm);
+    if (rc != LOCGPU_OK) return rc;
+    if (!src || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align: bad arguments");
+    locgpu_batch* b = nullptr;
+    rc = single_batch(ctx, src, n, stride_bytes, &b);
+    if (rc != LOCGPU_OK) return rc;
+    return run_align(ctx, b, init_pose, prm, 0, 1.0f, true, out_pose, stats);
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+// oracle/locref_math.hpp
+//
+// TEST INFRASTRUCTURE ONLY — the CPU oracle. Nothing under oracle/ is shipped, linked or
+// called by the product path (loc_lib_amd/, include/). Only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may use it, and there only as the checker.
+//
+// PARITY UNPINNED: the reference (maotian123/loc_lib) holds no golden vectors, known-answer
+// tests or fixtures for this path and cannot be compiled in this image (Eigen/Sophus/PCL
+// absent). The third-party arithmetic it leans on is restated here from the
+// libraries' published algorithms:
+//   * Eigen 3.3.x (Ubuntu 18.04 ⇒ 3.3.4, unpinned by the reference's CMake):
+//       - fixed-size reductions (`squaredNorm`, `dot`) of length 3 use redux_novec_unroller,
+//         i.e. x0 + (x1 + x2)  (Eigen/src/Core/Redux.h);
+//       - Quaternion::_transformVector: uv = 2 (q.vec × v); v + w·uv + q.vec × uv;
+//       - Quaternion::toRotationMatrix;
+//       - 6×6 inverse()/determinant(): PartialPivLU;
+//       - JacobiSVD: any backward-stable SVD — restated as a one-sided (Hestenes) Jacobi.
+//   * Sophus 1.0.x (unpinned): SO3::exp (Taylor branch below 1e-10), SO3·SO3 = quaternion
+//     product with first-order renormalisation, SE3·p = R p + t, SO3::hat.
+//
+// Small dependency-free fixed-size linear algebra in FP64. Compile with -ffp-contract=off:
+// the reference's x86-64 build (g++ -O3, no -march) has no FMA.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace locref {
+
+struct V3 {
+    double x, y, z;
+};
+inline V3 operator+(const V3& a, const V3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(double s, const V3& a) { return {s * a.x, s * a.y, s * a.z}; }
+// Eigen fixed-size-3 reduction order: x0 + (x1 + x2).
+inline double dot(const V3& a, const V3& b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+inline V3 cross(const V3& a, const V3& b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+inline double norm(const V3& a) { return std::sqrt(dot(a, a)); }
+
+// Row-major 3×3.
+struct M3 {
+    double m[9];
+    double operator()(int r, int c) const { return m[3 * r + c]; }
+    double& operator()(int r, int c) { return m[3 * r + c]; }
+};
+inline M3 hat(const V3& v) {  // Sophus SO3::hat
+    return {{0.0, -v.z, v.y, v.z, 0.0, -v.x, -v.y, v.x, 0.0}};
+}
+inline M3 mul(const M3& a, const M3& b) {
+    M3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            // Eigen coefficient-based product: left-to-right accumulation.
+            double s = a(i, 0) * b(0, j);
+            s += a(i, 1) * b(1, j);
+            s += a(i, 2) * b(2, j);
+            r(i, j) = s;
+        }
+    return r;
+}
+inline V3 mul(const M3& a, const V3& v) {
+    return {(a(0, 0) * v.x + a(0, 1) * v.y) + a(0, 2) * v.z, (a(1, 0) * v.x + a(1, 1) * v.y) + a(1, 2) * v.z,
+            (a(2, 0) * v.x + a(2, 1) * v.y) + a(2, 2) * v.z};
+}
+
+// SE3 = unit quaternion (x, y, z, w) + translation: the memory layout of Sophus::SE3d::data().
+struct SE3 {
+    double qx, qy, qz, qw;
+    V3 t;
+};
+inline SE3 se3_from_array(const double* p) { return {p[0], p[1], p[2], p[3], {p[4], p[5], p[6]}}; }
+inline void se3_to_array(const SE3& T, double* p) {
+    p[0] = T.qx; p[1] = T.qy; p[2] = T.qz; p[3] = T.qw; p[4] = T.t.x; p[5] = T.t.y; p[6] = T.t.z;
+}
+
+// Eigen::Quaternion::toRotationMatrix (Eigen/src/Geometry/Quaternion.h).
+inline M3 rotation_matrix(const SE3& T) {
+    const double tx = 2.0 * T.qx, ty = 2.0 * T.qy, tz = 2.0 * T.qz;
+    const double twx = tx * T.qw, twy = ty * T.qw, twz = tz * T.qw;
+    const double txx = tx * T.qx, txy = ty * T.qx, txz = tz * T.qx;
+    const double tyy = ty * T.qy, tyz = tz * T.qy, tzz = tz * T.qz;
+    M3 r;
+    r(0, 0) = 1.0 - (tyy + tzz); r(0, 1) = txy - twz;         r(0, 2) = txz + twy;
+    r(1, 0) = txy + twz;         r(1, 1) = 1.0 - (txx + tzz); r(1, 2) = tyz - twx;
+    r(2, 0) = txz - twy;         r(2, 1) = tyz + twx;         r(2, 2) = 1.0 - (txx + tyy);
+    return r;
+}
+
+// SE3 * point: Sophus SO3::operator*(point) = unit_quaternion()._transformVector(p), + t.
+// (reference call sites: icp_registration.cpp:68,113,169; ndt_registration.cpp:293,403)
+inline V3 transform(const SE3& T, const V3& v) {
+    const V3 qv{T.qx, T.qy, T.qz};
+    V3 uv = cross(qv, v);
+    uv = uv + uv;
+    const V3 r = (v + T.qw * uv) + cross(qv, uv);
+    return r + T.t;
+}
+
+// Sophus SO3::exp + right-multiplication, translation added separately
+// (icp_registration.cpp:365-366: pose.so3() = pose.so3() * SO3::exp(dx.head<3>()); t += dx.tail<3>()).
+inline void apply_update(SE3& T, const double dx[6]) {
+    const V3 w{dx[0], dx[1], dx[2]};
+    const double theta_sq = dot(w, w);
+    double imag, real;
+    if (theta_sq < 1e-10 * 1e-10) {
+        const double theta_po4 = theta_sq * theta_sq;
+        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
+        real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
+    } else {
+        const double theta = std::sqrt(theta_sq);
+        const double half = 0.5 * theta;
+        imag = std::sin(half) / theta;
+        real = std::cos(half);
+    }
+    const double bx = imag * w.x, by = imag * w.y, bz = imag * w.z, bw = real;
+    const double ax = T.qx, ay = T.qy, az = T.qz, aw = T.qw;
+    // Eigen quaternion product a*b.
+    double rw = aw * bw - ax * bx - ay * by - az * bz;
+    double rx = aw * bx + ax * bw + ay * bz - az * by;
+    double ry = aw * by + ay * bw + az * bx - ax * bz;
+    double rz = aw * bz + az * bw + ax * by - ay * bx;
+    // Sophus SO3 product: first-order renormalisation when the squared norm drifted.
+    const double sq = rx * rx + ry * ry + rz * rz + rw * rw;
+    if (sq != 1.0) {
+        const double scale = 2.0 / (1.0 + sq);
+        rx *= scale; ry *= scale; rz *= scale; rw *= scale;
+    }
+    T.qx = rx; T.qy = ry; T.qz = rz; T.qw = rw;
+    T.t.x += dx[3]; T.t.y += dx[4]; T.t.z += dx[5];
+}
+
+// 6×6 partial-pivot LU (what Eigen's fixed 6×6 inverse()/determinant() use).
+// Returns det; if det != 0 also solves H x = b.
+inline double lu6_det_solve(const double H[36], const double b[6], double x[6]) {
+    double a[36];
+    std::memcpy(a, H, sizeof(a));
+    int perm[6];
+    for (int i = 0; i < 6; ++i) perm[i] = i;
+    double det = 1.0;
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        double best = std::fabs(a[6 * k + k]);
+        for (int r = k + 1; r < 6; ++r) {
+            const double v = std::fabs(a[6 * r + k]);
+            if (v > best) { best = v; piv = r; }
+        }
+        if (piv != k) {
+            for (int c = 0; c < 6; ++c) { const double tmp = a[6 * k + c]; a[6 * k + c] = a[6 * piv + c]; a[6 * piv + c] = tmp; }
+            const int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
+            det = -det;
+        }
+        const double d = a[6 * k + k];
+        det *= d;
+        if (d == 0.0) continue;  // singular: det becomes 0, skip elimination for this column
+        for (int r = k + 1; r < 6; ++r) {
+            const double f = a[6 * r + k] / d;
+            a[6 * r + k] = f;
+            for (int c = k + 1; c < 6; ++c) a[6 * r + c] -= f * a[6 * k + c];
+        }
+    }
+    if (det == 0.0) return det;
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = b[perm[i]];
+        for (int j = 0; j < i; ++j) s -= a[6 * i + j] * y[j];
+        y[i] = s;
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+        for (int j = i + 1; j < 6; ++j) s -= a[6 * i + j] * x[j];
+        x[i] = s / a[6 * i + i];
+    }
+    return det;
+}
+
+// One-sided (Hestenes) Jacobi SVD of an M×N matrix stored column-major in a[N][M]; V (N×N,
+// column-major v[N][N]) accumulates the right rotations. On exit the columns of `a` are
+// U·Σ (mutually orthogonal), their norms the singular values (unsorted).
+template <int M, int N>
+inline void jacobi_svd_onesided(double a[N][M], double v[N][N]) {
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < N - 1; ++p)
+            for (int q = p + 1; q < N; ++q) {
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int i = 0; i < M; ++i) {
+                    alpha += a[p][i] * a[p][i];
+                    beta += a[q][i] * a[q][i];
+                    gamma += a[p][i] * a[q][i];
+                }
+                if (gamma == 0.0 || std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t);
+                const double s = c * t;
+                for (int i = 0; i < M; ++i) {
+                    const double ap = a[p][i], aq = a[q][i];
+                    a[p][i] = c * ap - s * aq;
+                    a[q][i] = s * ap + c * aq;
+                }
+                for (int i = 0; i < N; ++i) {
+                    const double vp = v[p][i], vq = v[q][i];
+                    v[p][i] = c * vp - s * vq;
+                    v[q][i] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+}
+
+}  // namespace locref

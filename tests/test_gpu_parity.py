@@ -1,0 +1,297 @@
+"""GPU parity tests: the HIP path (through the C ABI, liblocgpu.so) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): index work bit-exact; poses within 1e-4 m / 1e-4 rad of the reference CPU path
+(the observed differences are ~1e-10: only FP64 summation order differs).
+"""
+import numpy as np
+import pytest
+
+from conftest import pose_delta
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4    # north_star tolerance, metres
+POSE_TOL_RAD = 1e-4  # north_star tolerance, radians
+HB_RTOL = 1e-9       # FP64 sums differ by summation order only
+
+
+def _hb_close(Hg, Bg, Ho, Bo):
+    scale = max(np.abs(Ho).max(), 1e-300)
+    assert np.abs(Hg - Ho).max() <= HB_RTOL * scale
+    scale_b = max(np.abs(Bo).max(), np.abs(Ho).max() * 1e-6, 1e-300)
+    assert np.abs(Bg - Bo).max() <= 1e-8 * scale_b
+
+
+# ----------------------------------------------------------------------------------------------- search
+@pytest.mark.parametrize("k", [1, 5])
+@pytest.mark.parametrize("approximate", [True, False])
+def test_knn_indices_and_visits_bit_exact(gpu_ctx, locref, small_world, k, approximate):
+    m = small_world["map"]
+    rng = np.random.RandomState(100 + k)
+    q = (m[rng.choice(len(m), 4000, replace=False), :3] + rng.randn(4000, 3).astype(np.float32) * 0.05).astype(np.float32)
+    gpu_ctx.icp_set_target(m)
+    tree = locref.KdTree(m)
+    info = gpu_ctx.icp_target_info()
+    assert (info["num_leaves"], info["num_nodes"], info["depth"]) == (tree.num_leaves, tree.num_nodes, tree.depth)
+    got, vis = gpu_ctx.knn(q, k=k, approximate=approximate, alpha=0.1, with_visits=True)
+    ref, st = tree.knn(q, k=k, approximate=approximate, alpha=0.1, with_stats=True)
+    np.testing.assert_array_equal(got, ref)
+    assert int(vis[:, 0].sum()) == int(st[0]) and int(vis[:, 1].sum()) == int(st[1])
+
+
+def test_knn_other_k_and_alpha(gpu_ctx, locref, small_world):
+    m = small_world["map"]
+    q = small_world["scan2k"][:500, :3] * 0.5 + m[:500, :3] * 0.5
+    gpu_ctx.icp_set_target(m)
+    tree = locref.KdTree(m)
+    for k, alpha in ((3, 0.3), (8, 0.05), (2, 1.0)):
+        np.testing.assert_array_equal(gpu_ctx.knn(q, k=k, approximate=True, alpha=alpha), tree.knn(q, k=k, approximate=True, alpha=alpha))
+
+
+def test_knn_duplicates_and_tiny_tree(gpu_ctx, locref, api):
+    pts = np.random.RandomState(5).rand(64, 3).astype(np.float32)
+    pts[10:20] = pts[10]  # duplicates collapse into one leaf (kdtree.cpp:76-81)
+    gpu_ctx.icp_set_target(pts)
+    tree = locref.KdTree(pts)
+    assert gpu_ctx.icp_target_info()["num_leaves"] == tree.num_leaves == 55
+    q = np.random.RandomState(6).rand(200, 3).astype(np.float32)
+    np.testing.assert_array_equal(gpu_ctx.knn(q, k=5), tree.knn(q, k=5))
+    gpu_ctx.icp_set_target(pts[:3])
+    with pytest.raises(api.LocGpuError) as e:  # k > size_: kdtree.cpp:149-153
+        gpu_ctx.knn(q, k=5)
+    assert e.value.code == -4
+
+
+def test_knn_ties_follow_libstdcxx_heap(gpu_ctx, locref):
+    """Lattice points ⇒ many exactly equal float32 distances: order/eviction must follow std::priority_queue."""
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(6), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    q = (g[::7] + 0.5).astype(np.float32)
+    gpu_ctx.icp_set_target(g)
+    tree = locref.KdTree(g)
+    for approx in (True, False):
+        np.testing.assert_array_equal(gpu_ctx.knn(q, k=5, approximate=approx), tree.knn(q, k=5, approximate=approx))
+
+
+# ----------------------------------------------------------------------------------------------- H, B
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_icp_hb_matches_oracle(gpu_ctx, api, locref, small_world, method):
+    m, s, pose = small_world["map"], small_world["scan10k"], small_world["init_pose"]
+    gpu_ctx.icp_set_target(m)
+    icp = locref.Icp(method=method)
+    icp.set_target(m)
+    ok_o, Ho, Bo, eff_o = icp.hb(s, pose)
+    ok_g, Hg, Bg, eff_g = gpu_ctx.icp_hb(s, pose, api.icp_opts(method=method))
+    assert ok_g == ok_o and eff_g == eff_o
+    _hb_close(Hg, Bg, Ho, Bo)
+    np.testing.assert_array_equal(Hg, Hg.T)
+
+
+def test_icp_hb_exact_search_mode_of_the_tree(gpu_ctx, api, locref, small_world):
+    """SetEnableANN(false) (kdtree.cpp:285-288): exact pruning rule through the same tree."""
+    m, s, pose = small_world["map"], small_world["scan2k"], small_world["init_pose"]
+    gpu_ctx.icp_set_target(m)
+    icp = locref.Icp(method=2, use_ann=False)
+    icp.set_target(m)
+    ok_o, Ho, Bo, eff_o = icp.hb(s, pose)
+    ok_g, Hg, Bg, eff_g = gpu_ctx.icp_hb(s, pose, api.icp_opts(method=2, approximate=0))
+    assert ok_g == ok_o and eff_g == eff_o
+    _hb_close(Hg, Bg, Ho, Bo)
+
+
+def test_icp_hb_too_few_points_is_false(gpu_ctx, api, locref, small_world):
+    m = small_world["map"]
+    gpu_ctx.icp_set_target(m)
+    s = small_world["scan2k"][:5]
+    ok_g, Hg, Bg, eff_g = gpu_ctx.icp_hb(s, small_world["init_pose"], api.icp_opts(method=2))
+    icp = locref.Icp(method=2)
+    icp.set_target(m)
+    ok_o, Ho, Bo, eff_o = icp.hb(s, small_world["init_pose"])
+    assert ok_g == ok_o == False and eff_g == eff_o  # noqa: E712  effective_num < min_effective_pts_ (icp cpp:204)
+
+
+# ----------------------------------------------------------------------------------------------- align
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_icp_align_matches_oracle(gpu_ctx, api, locref, small_world, method):
+    m, s, init = small_world["map"], small_world["scan10k"], small_world["init_pose"]
+    gpu_ctx.icp_set_target(m)
+    icp = locref.Icp(method=method)
+    icp.set_target(m)
+    ro = icp.align(s, init)
+    pg, st = gpu_ctx.icp_align(s, init, api.icp_opts(method=method))
+    dt, dr = pose_delta(pg, ro["pose"])
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+    assert st["iterations"] == ro["iters"]
+    assert st["last_effective_num"] == int(ro["trace"][-1, 48])
+    assert dt < 1e-8 and dr < 1e-8  # what we actually expect: summation-order noise only
+
+
+def test_icp_align_nonconverging_runs_max_iterations(gpu_ctx, api, locref, small_world):
+    m, s, init = small_world["map"], small_world["scan2k"], small_world["init_pose"]
+    gpu_ctx.icp_set_target(m)
+    opts = api.icp_opts(method=2, eps=1e-12, max_iteration=7)
+    icp = locref.Icp(method=2, eps=1e-12, max_iteration=7)
+    icp.set_target(m)
+    ro = icp.align(s, init)
+    pg, st = gpu_ctx.icp_align(s, init, opts)
+    assert st["iterations"] == ro["iters"] == 7 and not st["converged"]
+    dt, dr = pose_delta(pg, ro["pose"])
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
+def test_icp_align_batch_ragged(gpu_ctx, api, locref, synth):
+    """Batch of scans of different sizes and poses vs one map: each scan's result equals its own single-scan oracle run."""
+    m = synth.make_local_map(80000, 5, half=25.0)
+    scans = [synth.make_scan(5, subsample=n, crop_half=22.0) for n in (3000, 1000, 2500, 257)]
+    _, init = synth.make_pose(5)
+    inits = np.stack([init, init, init, init])
+    inits[1, 4:] += [0.05, -0.05, 0.02]
+    inits[2, 4:] -= [0.1, 0.0, 0.05]
+    gpu_ctx.icp_set_target(m)
+    b = gpu_ctx.batch(scans)
+    out, stats = gpu_ctx.icp_align_batch(b, inits, api.icp_opts(method=2))
+    icp = locref.Icp(method=2)
+    icp.set_target(m)
+    for i, s in enumerate(scans):
+        ro = icp.align(s, inits[i])
+        dt, dr = pose_delta(out[i], ro["pose"])
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (i, dt, dr)
+        assert stats[i]["iterations"] == ro["iters"]
+    b.close()
+
+
+def test_p2p_skips_nonfinite_source_points(gpu_ctx, api, locref, small_world):
+    m, s, init = small_world["map"], small_world["scan2k"].copy(), small_world["init_pose"]
+    s[::50, 0] = np.nan  # pcl::isFinite skip exists only in P2P (icp cpp:64)
+    gpu_ctx.icp_set_target(m)
+    icp = locref.Icp(method=0)
+    icp.set_target(m)
+    ok_o, Ho, Bo, eff_o = icp.hb(s, init)
+    ok_g, Hg, Bg, eff_g = gpu_ctx.icp_hb(s, init, api.icp_opts(method=0))
+    assert ok_g == ok_o and eff_g == eff_o
+    _hb_close(Hg, Bg, Ho, Bo)
+
+
+def test_point_sharded_hb_sum_equals_full(gpu_ctx, api, small_world):
+    """Point-sharding (multi-GPU mode with a real exchange): per-shard H,B summed = H,B of the whole scan."""
+    m, s, init = small_world["map"], small_world["scan10k"], small_world["init_pose"]
+    gpu_ctx.icp_set_target(m)
+    opts = api.icp_opts(method=2)
+    b_full = gpu_ctx.batch([s])
+    full = gpu_ctx.icp_hb_batch(b_full, init, opts)[0]
+    b_sh = gpu_ctx.batch([s[:6000], s[6000:]])
+    parts = gpu_ctx.icp_hb_batch(b_sh, np.stack([init, init]), opts)
+    summed = parts[:, :43].sum(0)
+    np.testing.assert_allclose(summed[:36], full[:36], rtol=1e-10, atol=1e-12 * np.abs(full[:36]).max())
+    np.testing.assert_allclose(summed[36:42], full[36:42], rtol=1e-8, atol=1e-10 * np.abs(full[:36]).max())
+    assert summed[42] == full[42]
+
+
+# ----------------------------------------------------------------------------------------------- output cloud
+def test_transform_cloud_bit_exact(gpu_ctx, locref, small_world):
+    s = np.zeros((2000, 8), dtype=np.float32)  # pcl::PointXYZI stride (32 bytes)
+    s[:, :3] = small_world["scan2k"][:, :3]
+    s[:, 4] = np.arange(2000)                  # intensity survives
+    pose = small_world["init_pose"]
+    out_g = gpu_ctx.transform_cloud(pose, s)
+    out_o = locref.transform_cloud_f32(pose, s)
+    np.testing.assert_array_equal(out_g.view(np.uint32), out_o.view(np.uint32))
+    np.testing.assert_array_equal(out_g[:, 4], s[:, 4])
+
+
+# ----------------------------------------------------------------------------------------------- NDT
+def test_ndt_voxel_table_matches_oracle(gpu_ctx, locref, small_world):
+    m = small_world["map"]
+    gpu_ctx.ndt_set_target(m)
+    ndt = locref.Ndt()
+    ndt.set_target(m)
+    kg, mug, ig = gpu_ctx.ndt_dump()
+    ko, muo, io = ndt.dump()
+    assert len(kg) == len(ko) == gpu_ctx.ndt_target_info()["num_voxels"]
+    og, oo = np.lexsort(kg.T[::-1]), np.lexsort(ko.T[::-1])
+    np.testing.assert_array_equal(kg[og], ko[oo])
+    np.testing.assert_allclose(mug[og], muo[oo], rtol=0, atol=1e-10)
+    scale = np.abs(io[oo]).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(ig[og] - io[oo]) / scale).max() < 1e-7
+
+
+@pytest.mark.parametrize("nearby", [1, 0])
+def test_ndt_align_matches_oracle(gpu_ctx, api, locref, small_world, nearby):
+    m, s, init = small_world["map"], small_world["scan10k"], small_world["init_pose"]
+    gpu_ctx.ndt_set_target(m, api.ndt_opts(nearby_type=nearby))
+    ndt = locref.Ndt(nearby_type=nearby)
+    ndt.set_target(m)
+    ro = ndt.align(s, init)
+    pg, st = gpu_ctx.ndt_align(s, init)
+    assert st["status"] == ro["status"] == 0
+    assert st["iterations"] == ro["iters"]
+    dt, dr = pose_delta(pg, ro["pose"])
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+
+
+def test_ndt_det_zero_returns_init_pose(gpu_ctx, locref):
+    rng = np.random.RandomState(11)
+    m = (rng.rand(200, 3) * 100).astype(np.float32)
+    gpu_ctx.ndt_set_target(m)
+    init = np.array([0, 0, 0, 1.0, 1, 2, 3])
+    pg, st = gpu_ctx.ndt_align(m[:50], init)
+    assert st["status"] == 1 and st["iterations"] == 1  # ndt cpp:435-436
+    np.testing.assert_array_equal(pg, init)
+
+
+def test_ndt_negative_coordinates_truncate_toward_zero(gpu_ctx, locref):
+    """Cells touching 0 are double width (A22): a dense blob across the origin lands in ONE voxel per axis sign pair."""
+    rng = np.random.RandomState(12)
+    m = (rng.rand(4000, 3) * 1.8 - 0.9).astype(np.float32)
+    gpu_ctx.ndt_set_target(m)
+    ndt = locref.Ndt()
+    ndt.set_target(m)
+    kg, _, _ = gpu_ctx.ndt_dump()
+    ko, _, _ = ndt.dump()
+    assert len(kg) == len(ko) == 1 and tuple(kg[0]) == (0, 0, 0)
+
+
+# ----------------------------------------------------------------------------------------------- golden fixtures
+def test_golden_fixture_gpu(gpu_ctx, api):
+    """Committed golden vectors (tests/golden/make_golden.py, generated with the oracle in the build container)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "icp_small.npz"))
+    gpu_ctx.icp_set_target(g["map"])
+    np.testing.assert_array_equal(gpu_ctx.knn(g["queries"], k=5, approximate=True), g["knn_ann"])
+    np.testing.assert_array_equal(gpu_ctx.knn(g["queries"], k=5, approximate=False), g["knn_exact"])
+    for method, name in ((0, "p2p"), (1, "p2line"), (2, "p2plane")):
+        pg, st = gpu_ctx.icp_align(g["scan"], g["init_pose"], api.icp_opts(method=method))
+        dt, dr = pose_delta(pg, g["pose_" + name])
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+        assert st["iterations"] == int(g["iters_" + name])
+        ok, H, B, eff = gpu_ctx.icp_hb(g["scan"], g["init_pose"], api.icp_opts(method=method))
+        _hb_close(H, B, g["H0_" + name], g["B0_" + name])
+    gpu_ctx.ndt_set_target(g["map"])
+    pg, st = gpu_ctx.ndt_align(g["scan"], g["init_pose"])
+    dt, dr = pose_delta(pg, g["pose_ndt"])
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and st["iterations"] == int(g["iters_ndt"])
+
+
+# ----------------------------------------------------------------------------------------------- properties at full size
+def test_full_size_properties(gpu_ctx, api, synth):
+    """BASELINE config 2 size (115 200-pt scan vs 1 M-pt map): size-independent properties, no oracle needed.
+    (a) exact k-NN distances are sorted and the 1-NN of a map point is itself; (b) H is symmetric PSD;
+    (c) aligning an already aligned scan moves it by less than the stopping tolerance; (d) determinism."""
+    m = synth.make_map(1_000_000)
+    s = synth.make_scan(7)
+    true_pose, init = synth.make_pose(7)
+    assert len(s) == 115200
+    gpu_ctx.icp_set_target(m)
+    q = m[::997, :3]
+    idx = gpu_ctx.knn(q, k=5, approximate=False)
+    d = ((q[:, None, :].astype(np.float64) - m[idx, :3].astype(np.float64)) ** 2).sum(-1)
+    assert np.all(np.diff(d, axis=1) >= 0) and np.all(d[:, 0] == 0)
+    opts = api.icp_opts(method=2)
+    ok, H, B, eff = gpu_ctx.icp_hb(s, init, opts)
+    assert ok and np.array_equal(H, H.T) and np.linalg.eigvalsh(H).min() > 0
+    p1, st1 = gpu_ctx.icp_align(s, init, opts)
+    p2, st2 = gpu_ctx.icp_align(s, init, opts)
+    np.testing.assert_array_equal(p1, p2)  # fixed reduction order ⇒ bitwise reproducible
+    p3, st3 = gpu_ctx.icp_align(s, p1, opts)
+    dt, dr = pose_delta(p3, p1)
+    # restarting from the result: the loop stops again within a few small steps (each |dx| ≈ eps = 1e-2 or less)
+    assert st3["iterations"] <= 4 and dt < 5e-2 and dr < 1e-2
