@@ -165,6 +165,10 @@ LOCGPU_API int locgpu_profile_read(locgpu_ctx* ctx, double out[6], int reset);
 LOCGPU_API int locgpu_visit_count_enable(locgpu_ctx* ctx, int on);
 LOCGPU_API int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset);
 
+/* Search bookkeeping since the last reset (enabled by the first call): out[0] = queries handled by the fast search
+ * kernel's launches, out[1] = queries it handed to the exact redo kernel (distance ties / near-misses on the top tree levels). */
+LOCGPU_API int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[2], int reset);
+
 #ifdef __cplusplus
 }
 #endif

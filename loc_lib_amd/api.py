@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "locgpu_transform_cloud", "locgpu_batch_create", "locgpu_batch_destroy", "locgpu_icp_align_batch", "locgpu_ndt_align_batch",
     "locgpu_icp_hb_batch", "locgpu_gn_update", "locgpu_ndt_set_target", "locgpu_ndt_target_info", "locgpu_ndt_dump",
     "locgpu_ndt_align", "locgpu_profile_enable", "locgpu_profile_read", "locgpu_visit_count_enable", "locgpu_visit_count_read",
+    "locgpu_search_stats_read",
 ]
 
 
@@ -90,6 +91,7 @@ def lib():
             "locgpu_ndt_dump": (i32, [vp, vp, vp, vp, sz, vp]), "locgpu_ndt_align": (i32, [vp, vp, sz, sz, vp, vp, vp]),
             "locgpu_profile_enable": (i32, [vp, i32]), "locgpu_profile_read": (i32, [vp, vp, i32]),
             "locgpu_visit_count_enable": (i32, [vp, i32]), "locgpu_visit_count_read": (i32, [vp, vp, i32]),
+            "locgpu_search_stats_read": (i32, [vp, vp, i32]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -276,6 +278,12 @@ class Context:
         out = np.zeros(3, dtype=np.uint64)
         self._check(lib().locgpu_visit_count_read(self._h, out.ctypes.data, int(reset)))
         return dict(nodes=int(out[0]), leaves=int(out[1]), queries=int(out[2]))
+
+
+    def search_stats_read(self, reset=True):
+        out = np.zeros(2, dtype=np.uint64)
+        self._check(lib().locgpu_search_stats_read(self._h, out.ctypes.data, int(reset)))
+        return dict(searched=int(out[0]), redone=int(out[1]))
 
 
 class Batch:

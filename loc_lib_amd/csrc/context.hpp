@@ -36,6 +36,7 @@ struct locgpu_ctx {
     long long prof_n[3] = {0, 0, 0};
     bool count_visits = false;
     unsigned long long* d_visits = nullptr;
+    unsigned long long* d_search_stats = nullptr;  // [2]: queries searched / queries redone by the exact kernel
 };
 
 struct locgpu_batch {
@@ -48,6 +49,8 @@ struct locgpu_batch {
     uint32_t* d_nn = nullptr;      // [5][pitch]
     double* d_partials = nullptr;  // [n_scans][blocks_per_scan][kAccW]
     double* d_hb = nullptr;        // [n_scans][44]
+    uint32_t* d_redo_list = nullptr;      // [pitch]
+    unsigned int* d_redo_count = nullptr;
     locgpu::PoseState* h_state = nullptr;  // pinned
     double* h_hb = nullptr;                // pinned
     std::vector<int> counts;

@@ -2,11 +2,13 @@
 #include "icp_kernels.hpp"
 #include "launch.hpp"
 
+#include <cstdlib>
+
 namespace locgpu {
 
 // ---------------------------------------------------------------------------------------------
 // K1: one thread per source point. Grid (ceil(max_n/256), n_scans).
-template <int KMAX, int D, bool COUNT>
+template <int KMAX, int D, bool COUNT, int VARIANT = 0>
 __global__ __launch_bounds__(kBlock) void icp_search_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                             const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                             uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, int k, float alpha_eff,
@@ -27,7 +29,8 @@ __global__ __launch_bounds__(kBlock) void icp_search_kernel(const uint2* __restr
     if (finite) {
         const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
         KnnHeap<KMAX> heap;
-        tree_knn<KMAX, D, COUNT>(tree, (float)qs.x, (float)qs.y, (float)qs.z, k, alpha_eff, s_far, s_d2, tid, heap, nvis, lvis);
+        if (VARIANT != 9) tree_knn_flat<KMAX, D, COUNT>(tree, (float)qs.x, (float)qs.y, (float)qs.z, k, alpha_eff, s_far, s_d2, tid, heap, nvis, lvis);
+        else tree_knn<KMAX, D, COUNT>(tree, (float)qs.x, (float)qs.y, (float)qs.z, k, alpha_eff, s_far, s_d2, tid, heap, nvis, lvis);
         heap_to_sorted<KMAX>(heap, out, cnt);
     } else {
 #pragma unroll
@@ -40,6 +43,68 @@ __global__ __launch_bounds__(kBlock) void icp_search_kernel(const uint2* __restr
         atomicAdd(&visit_totals[0], (unsigned long long)nvis);
         atomicAdd(&visit_totals[1], (unsigned long long)lvis);
         atomicAdd(&visit_totals[2], 1ull);
+    }
+}
+
+// K1 fast path (see tree_knn_fast): exact for every query it completes; the others go to redo_list.
+// search_stats[0] += queries handled here, search_stats[1] += queries handed to the exact redo kernel.
+template <int K, int DF>
+__global__ __launch_bounds__(kBlock) void icp_search_fast_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+                                                                 const int* __restrict__ counts, const PoseState* __restrict__ st,
+                                                                 uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, float alpha_eff, int T,
+                                                                 unsigned int tree_bytes, int skip_nonfinite, uint32_t* __restrict__ redo_list,
+                                                                 unsigned int* __restrict__ redo_count,
+                                                                 unsigned long long* __restrict__ search_stats) {
+    __shared__ uint2 s_stack[DF][kBlock];
+    const int scan = blockIdx.y;
+    if (st[scan].done) return;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    if (i >= counts[scan]) return;
+    const size_t gi = (size_t)scan * max_n + i;
+    const float4 p = src[gi];
+    if (skip_nonfinite && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {  // pcl::isFinite, icp cpp:64 (P2P only)
+#pragma unroll
+        for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = kInvalidSlot;
+        return;
+    }
+    if (search_stats) atomicAdd(&search_stats[0], 1ull);  // one aggregated add per wave; only when stats were requested
+    const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
+    SortedSet<K> set;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
+    const bool slow = tree_knn_fast<K, DF>(rsrc, (float)qs.x, (float)qs.y, (float)qs.z, alpha_eff, T, s_stack, tid, set);
+    if (slow) {
+        redo_list[atomicAdd(redo_count, 1u)] = (uint32_t)gi;
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = set.id[j];
+    }
+}
+
+// Exact recomputation of the queries the fast kernel could not finish. Persistent-style 1-D grid over the list.
+template <int KMAX, int D>
+__global__ __launch_bounds__(kBlock) void icp_search_redo_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+                                                                 const PoseState* __restrict__ st, uint32_t* __restrict__ nn, size_t nn_pitch,
+                                                                 int max_n, int k, float alpha_eff, const uint32_t* __restrict__ redo_list,
+                                                                 const unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats) {
+    __shared__ uint32_t s_far[D][kBlock];
+    __shared__ float s_d2[D][kBlock];
+    const unsigned int n = *redo_count;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0 && search_stats) atomicAdd(&search_stats[1], (unsigned long long)n);
+    for (unsigned int r = blockIdx.x * kBlock + tid; r < n; r += gridDim.x * kBlock) {
+        const size_t gi = redo_list[r];
+        const int scan = (int)(gi / (size_t)max_n);
+        const float4 p = src[gi];
+        const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
+        KnnHeap<KMAX> heap;
+        uint32_t nvis = 0, lvis = 0, out[KMAX];
+        int cnt;
+        tree_knn_flat<KMAX, D, false>(tree, (float)qs.x, (float)qs.y, (float)qs.z, k, alpha_eff, s_far, s_d2, tid, heap, nvis, lvis);
+        heap_to_sorted<KMAX>(heap, out, cnt);
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            if (j < k) nn[(size_t)j * nn_pitch + gi] = out[j];
     }
 }
 
@@ -400,15 +465,68 @@ static void launch_search_kd(const SearchArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((icp_search_kernel<KMAX, D, false>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                            a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals);
 }
+// EXPERIMENT hook (timing only; variants 2-4 truncate the stack and give wrong neighbours): LOCGPU_SEARCH_VARIANT
+template <int KMAX, int D, int V>
+static void launch_search_exp(const SearchArgs& a, hipStream_t s) {
+    dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
+    hipLaunchKernelGGL((icp_search_kernel<KMAX, D, false, V>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+                       a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals);
+}
+static int search_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LOCGPU_SEARCH_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 template <int KMAX>
 static bool launch_search_k(const SearchArgs& a, hipStream_t s) {
+    if (KMAX == 5 && !a.visit_totals && a.depth <= 32) {
+        switch (search_variant()) {
+            case 1: launch_search_exp<5, 32, 1>(a, s); return true;
+            case 9: launch_search_exp<5, 32, 9>(a, s); return true;
+            case 2: launch_search_exp<5, 16, 1>(a, s); return true;
+            case 3: launch_search_exp<5, 8, 1>(a, s); return true;
+            case 4: launch_search_exp<5, 16, 0>(a, s); return true;
+            case 5: launch_search_exp<5, 8, 0>(a, s); return true;
+            default: break;
+        }
+    }
     if (a.depth <= 32) launch_search_kd<KMAX, 32>(a, s);
     else if (a.depth <= 40) launch_search_kd<KMAX, 40>(a, s);
     else if (a.depth <= 64) launch_search_kd<KMAX, 64>(a, s);
     else return false;
     return true;
 }
+constexpr int kFastStack = 16;  // LDS stack entries per thread in the fast kernel (8 B each → 32 KB per workgroup, 5 workgroups per CU)
+
+template <int K, int D>
+static void launch_fast_kd(const SearchArgs& a, int T, hipStream_t s) {
+    constexpr int DF = kFastStack;
+    dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
+    (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);
+    hipLaunchKernelGGL((icp_search_fast_kernel<K, DF>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+                       a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
+    hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(512), dim3(kBlock), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
+                       a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
+}
+template <int K>
+static bool launch_fast_k(const SearchArgs& a, hipStream_t s) {
+    const int T = a.depth > kFastStack ? a.depth - kFastStack : 0;  // leading stack positions the fast kernel does not store
+    if (a.depth <= 32) launch_fast_kd<K, 32>(a, T, s);
+    else if (a.depth <= 40) launch_fast_kd<K, 40>(a, T, s);
+    else if (a.depth <= 64) launch_fast_kd<K, 64>(a, T, s);
+    else return false;
+    return true;
+}
+
 bool launch_icp_search(const SearchArgs& a, hipStream_t s) {
+    // Instrumented (visit-counting) runs and LOCGPU_SEARCH_VARIANT experiments use the exact one-pass kernel.
+    const bool exact_only = a.visit_totals != nullptr || search_variant() != 0 || !a.redo_list;
+    if (!exact_only) {
+        if (a.k == 1) return launch_fast_k<1>(a, s);
+        if (a.k == 5) return launch_fast_k<5>(a, s);
+        return false;
+    }
     if (a.k == 1) return launch_search_k<1>(a, s);
     if (a.k == 5) return launch_search_k<5>(a, s);
     return false;

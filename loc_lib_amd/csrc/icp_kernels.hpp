@@ -185,6 +185,211 @@ __device__ __forceinline__ void tree_knn(const uint2* __restrict__ tree, float q
     }
 }
 
+// Same traversal as tree_knn, written as ONE loop in which every live lane visits exactly one node per trip
+// (load → leaf: result-set update + backtrack | internal: push far side, step to the near side). All lanes of a wave
+// issue their node load at the same point, so a wave keeps up to 64 loads in flight instead of serialising the
+// descend / backtrack phases of different lanes.
+template <int KMAX, int D, bool COUNT>
+__device__ __forceinline__ void tree_knn_flat(const uint2* __restrict__ tree, float qx, float qy, float qz, int k, float alpha_eff,
+                                              uint32_t (*s_far)[kBlock], float (*s_d2)[kBlock], int tid, KnnHeap<KMAX>& heap,
+                                              uint32_t& nvis, uint32_t& lvis) {
+    heap.n = 0;
+    int sp = 0;
+    uint32_t cur = 0;
+    bool live = true;
+    while (live) {
+        uint4 w;
+        __builtin_memcpy(&w, tree + cur, 16);
+        if (COUNT) nvis++;
+        const uint32_t meta = w.y;
+        const uint32_t tag = meta >> 30;
+        if (tag == 3u) {
+            if (COUNT) lvis++;
+            const float dx = qx - as_f32(w.x), dy = qy - as_f32(w.z), dz = qz - as_f32(w.w);
+            const float dis2 = dx * dx + (dy * dy + dz * dz);
+            if (heap.n < k) {
+                heap.push(dis2, cur);
+            } else if (dis2 < heap.top()) {
+                heap.push(dis2, cur);
+                heap.pop();
+            }
+            live = false;
+            const float bound = heap.top() * alpha_eff;
+            const bool open = heap.n < k;
+            while (sp > 0) {
+                sp--;
+                if (open || s_d2[sp][tid] < bound) {
+                    cur = s_far[sp][tid];
+                    live = true;
+                    break;
+                }
+            }
+        } else {
+            const float th = as_f32(w.x);
+            const float qa = tag == 0u ? qx : (tag == 1u ? qy : qz);
+            const float dd = qa - th;
+            const float d2 = dd * dd;
+            const uint32_t right = meta & 0x3FFFFFFFu;
+            const bool go_left = qa < th;
+            if (heap.n < k || d2 < heap.top() * alpha_eff) {
+                s_far[sp][tid] = go_left ? right : cur + 1u;
+                s_d2[sp][tid] = d2;
+                sp = sp + 1 < D ? sp + 1 : D - 1;
+            }
+            cur = go_left ? cur + 1u : right;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast path of the same traversal. Two things make the exact kernel above slow: the libstdc++ heap emulation
+// (hundreds of select instructions whenever any lane of the wave sits on a leaf) and the 8-byte × depth LDS stack
+// that caps occupancy at two workgroups per CU. Both are only needed in rare situations, which this kernel detects:
+//   * result set: a sorted array with insertion (≈40 instructions). It keeps exactly the elements and the final
+//     order std::priority_queue would as long as no two distances in the set are ever equal; an insertion that ties
+//     with a resident element raises `slow`.
+//   * stack: the first T pushes of a query are always the top T tree levels of its first descent (the result set is
+//     empty, NeedExpand is unconditionally true). They are popped last, against the final bound, and are almost never
+//     expanded — so they are not stored at all, only the minimum of their d². When the stack drains down to them:
+//     if min d² ≥ top·alpha (and the set is full) every one of them would be rejected and the query is finished,
+//     exactly; otherwise `slow`.
+// A query that raised `slow` is appended to a redo list and recomputed by the exact kernel.
+template <int K>
+struct SortedSet {  // ascending: d[0] ≤ … ≤ d[K-1]; empty slots hold +inf / kInvalidSlot
+    float d[K];
+    uint32_t id[K];
+    int n;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < K; ++j) { d[j] = __builtin_inff(); id[j] = kInvalidSlot; }
+        n = 0;
+    }
+    __device__ __forceinline__ float top() const { return d[K - 1]; }
+    // returns true when the insertion tied with a resident distance (⇒ heap layout would matter)
+    __device__ __forceinline__ bool insert(float x, uint32_t w) {
+        bool tie = false;
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) tie |= (x == d[j]);
+        d[K - 1] = x;
+        id[K - 1] = w;
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+            const bool sw = d[j] < d[j - 1];
+            const float lo = sw ? d[j] : d[j - 1], hi = sw ? d[j - 1] : d[j];
+            const uint32_t ilo = sw ? id[j] : id[j - 1], ihi = sw ? id[j - 1] : id[j];
+            d[j - 1] = lo; d[j] = hi; id[j - 1] = ilo; id[j] = ihi;
+        }
+        n = n < K ? n + 1 : K;
+        return tie;
+    }
+};
+
+// Returns true when the query must be redone by the exact kernel. T = number of un-stored leading stack positions.
+//
+// Replay: when the stack drains down to the un-stored entries and one of them could still pass NeedExpand
+// (min d² < top·alpha, or the set is not full), the top levels are walked again from the root — the same `<`
+// decisions, hence the same path — pushing entries under the pruning rule with the CURRENT bound (valid because the
+// bound only shrinks). `sp` such entries were pending, all from levels 0..sp-1 of the first descent, so exactly `sp`
+// levels are replayed; from then on every position is stored (T = 0). Decisions and visit order stay those of the
+// recursion.
+//
+// The loop body is written branch-free (selects) except for the LDS push and the backtrack block: the kernel is
+// bound by instruction issue — 64 lanes sit in different phases, so a branchy body executes every side anyway and
+// pays the exec-mask bookkeeping on top. `tree_rsrc` is a buffer descriptor over the packed tree: one
+// buffer_load_dwordx4 (32-bit offset) returns a node together with the slot behind it (a whole leaf).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int K, int DF>
+__device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, float qx, float qy, float qz, float alpha_eff, int T,
+                                              uint2 (*s_stack)[kBlock], int tid, SortedSet<K>& set) {
+    set.init();
+    int sp = 0, replay = 0;
+    uint32_t cur = 0;
+    float min_drop = __builtin_inff();
+    bool slow = false, live = true, need_pop = false;
+    while (live) {
+        if (!need_pop) {  // ------------------------------------------------ VISIT one node
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(tree_rsrc, (int)(cur << 3), 0, 0);
+            const uint32_t meta = w.y;
+            const uint32_t tag = meta >> 30;
+            const bool is_leaf = tag == 3u;
+            const bool full = set.n >= K;
+            const float top = set.top();
+
+            // leaf side (ComputeDisForLeaf, kdtree.cpp:197-212), predicated on is_leaf
+            const float dx = qx - as_f32(w.x), dy = qy - as_f32(w.z), dz = qz - as_f32(w.w);
+            const float dis2 = dx * dx + (dy * dy + dz * dz);
+            const bool ins = is_leaf && (dis2 < top);  // n<K: top is +inf; n==K: strict `<` (kdtree.cpp:207)
+            slow |= is_leaf && !ins && !full;           // inf/NaN distance while filling: the exact kernel decides
+            bool tie = false;
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) tie |= (dis2 == set.d[j]);
+            slow |= ins && tie;
+            set.d[K - 1] = ins ? dis2 : set.d[K - 1];
+            set.id[K - 1] = ins ? cur : set.id[K - 1];
+#pragma unroll
+            for (int j = K - 1; j > 0; --j) {  // one bubble pass; a no-op when nothing was inserted
+                const bool sw = set.d[j] < set.d[j - 1];
+                const float lo = sw ? set.d[j] : set.d[j - 1], hi = sw ? set.d[j - 1] : set.d[j];
+                const uint32_t ilo = sw ? set.id[j] : set.id[j - 1], ihi = sw ? set.id[j - 1] : set.id[j];
+                set.d[j - 1] = lo; set.d[j] = hi; set.id[j - 1] = ilo; set.id[j] = ihi;
+            }
+            set.n += (ins && !full) ? 1 : 0;
+
+            // internal side (Knn, kdtree.cpp:177-194), predicated on !is_leaf
+            const float th = as_f32(w.x);
+            const float qa = tag == 0u ? qx : (tag == 1u ? qy : qz);
+            const float dd = qa - th;
+            const float d2 = dd * dd;
+            const uint32_t right = meta & 0x3FFFFFFFu;
+            const bool go_left = qa < th;
+            const uint32_t far_slot = go_left ? right : cur + 1u;
+            const bool push = !is_leaf && (!full || d2 < top * alpha_eff);  // else NeedExpand can never come true later
+            const bool drop = push && sp < T;
+            const bool store = push && !drop && (sp - T) < DF;
+            slow |= (push && !drop && !store) || (drop && !(d2 == d2));    // deeper than the fast stack / NaN coordinate
+            min_drop = (drop && d2 < min_drop) ? d2 : min_drop;
+            if (store) s_stack[sp - T][tid] = make_uint2(far_slot, __float_as_uint(d2));
+            sp += push ? 1 : 0;
+            const bool replaying = !is_leaf && replay > 0;
+            replay -= replaying ? 1 : 0;
+            need_pop = is_leaf || (replaying && replay == 0);  // after a leaf, or once the top levels are re-pushed
+            cur = go_left ? cur + 1u : right;
+        }
+        if (need_pop) {  // ------------------------------------------------- POP: NeedExpand (kdtree.cpp:214-236), youngest first
+            const bool open = set.n < K;
+            const float bound = set.top() * alpha_eff;
+            const int avail = sp - T;
+            if (avail <= 0) {
+                // nothing stored is left. sp > 0: only un-stored first-descent entries (levels 0..sp-1) remain.
+                const bool may_pass = sp > 0 && (open || !(min_drop >= bound));
+                replay = may_pass ? sp : 0;  // replay them from the root …
+                live = may_pass;             // … or finish: every one of them is rejected by the final bound
+                T = may_pass ? 0 : T;
+                sp = 0;
+                cur = 0;
+                need_pop = false;
+            } else {
+                // up to four entries per LDS round trip, examined youngest first
+                uint2 e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = s_stack[avail - 1 - j >= 0 ? avail - 1 - j : 0][tid];
+                int hit = 4;
+#pragma unroll
+                for (int j = 3; j >= 0; --j) hit = (j < avail && (open || as_f32(e[j].y) < bound)) ? j : hit;
+                const uint32_t far_hit = hit == 0 ? e[0].x : (hit == 1 ? e[1].x : (hit == 2 ? e[2].x : e[3].x));
+                const bool found = hit < 4;
+                const int used = found ? hit + 1 : (avail < 4 ? avail : 4);
+                sp -= used;
+                cur = found ? far_hit : cur;
+                need_pop = !found;
+            }
+        }
+        live = live && !slow;
+    }
+    return slow;
+}
+
 // Pops the heap into ascending-distance order (kdtree.cpp:160-165).
 template <int KMAX>
 __device__ __forceinline__ void heap_to_sorted(KnnHeap<KMAX>& heap, uint32_t (&out)[KMAX], int& count) {

@@ -110,7 +110,8 @@ struct Piece {  // a node of the serially built top of the tree, or a deferred s
 bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::string& err) {
     out = PackedKdTree();
     if (n == 0) { err = "empty target cloud"; return false; }
-    if (n >= (1ull << 30) / 3) { err = "target cloud too large for 30-bit slot indices"; return false; }
+    // 3n-1 slots of 8 bytes must stay below 4 GiB: the search kernel addresses the tree through a 32-bit buffer offset
+    if (n >= (1ull << 29) / 3) { err = "target cloud too large (the packed tree must stay below 4 GiB)"; return false; }
     Builder b;
     b.pts = xyz;
     std::vector<int32_t> idx(n), tmp(n);

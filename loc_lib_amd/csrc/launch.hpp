@@ -11,6 +11,7 @@ struct GnParams;
 
 struct SearchArgs {
     const uint2* tree;
+    size_t tree_bytes;
     int depth;
     const float4* src;
     const int* counts;
@@ -21,6 +22,9 @@ struct SearchArgs {
     float alpha_eff;
     int skip_nonfinite;
     unsigned long long* visit_totals;  // null unless visit counting is on
+    uint32_t* redo_list;               // [n_scans*max_n] queries the fast kernel hands to the exact kernel
+    unsigned int* redo_count;
+    unsigned long long* search_stats;  // [2] cumulative: queries searched, queries redone exactly (may be null)
 };
 
 struct AccumArgs {

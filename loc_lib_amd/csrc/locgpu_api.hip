@@ -42,6 +42,8 @@ static void free_batch(locgpu_batch* b) {
     if (b->d_nn) (void)hipFree(b->d_nn);
     if (b->d_partials) (void)hipFree(b->d_partials);
     if (b->d_hb) (void)hipFree(b->d_hb);
+    if (b->d_redo_list) (void)hipFree(b->d_redo_list);
+    if (b->d_redo_count) (void)hipFree(b->d_redo_count);
     if (b->h_state) (void)hipHostFree(b->h_state);
     if (b->h_hb) (void)hipHostFree(b->h_hb);
     delete b;
@@ -107,6 +109,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     free_batch(ctx->single);
     if (ctx->d_tree) (void)hipFree(ctx->d_tree);
     if (ctx->d_visits) (void)hipFree(ctx->d_visits);
+    if (ctx->d_search_stats) (void)hipFree(ctx->d_search_stats);
     ndt_free(ctx);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -188,7 +191,8 @@ static int make_batch(locgpu_ctx* ctx, const void* const* srcs, const size_t* co
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     size_t max_n = 0;
     for (int s = 0; s < n_scans; ++s) max_n = std::max(max_n, counts[s]);
-    if (max_n == 0 || max_n > 0x7FFFFF00u) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: scans are empty or too large");
+    if (max_n == 0 || max_n > 0x7FFFFF00u || (size_t)n_scans * max_n > 0xFFFFFFF0ull)
+        return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: scans are empty or the batch exceeds 2^32 points");
     auto* b = new locgpu_batch();
     b->ctx = ctx;
     b->n_scans = n_scans;
@@ -203,6 +207,8 @@ static int make_batch(locgpu_ctx* ctx, const void* const* srcs, const size_t* co
               hip_ok(ctx, hipMalloc((void**)&b->d_nn, 5 * b->pitch * sizeof(uint32_t)), "hipMalloc nn") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_partials, (size_t)n_scans * b->blocks_per_scan * kAccW * sizeof(double)), "hipMalloc partials") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_hb, (size_t)n_scans * 44 * sizeof(double)), "hipMalloc hb") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_redo_list, b->pitch * sizeof(uint32_t)), "hipMalloc redo") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, sizeof(unsigned int)), "hipMalloc redo") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_scans * sizeof(PoseState)), "hipHostMalloc state") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_scans * 44 * sizeof(double)), "hipHostMalloc hb");
     if (!ok) { free_batch(b); return LOCGPU_ERR_OOM; }
@@ -287,8 +293,9 @@ bool IterLauncher::launch(int do_update) {
     };
     mark();
     if (!ndt) {
-        SearchArgs sa{ctx->d_tree, ctx->depth, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, k, alpha_eff,
-                      prm.method == LOCGPU_P2P ? 1 : 0, ctx->count_visits ? ctx->d_visits : nullptr};
+        SearchArgs sa{ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ctx->depth, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, k, alpha_eff,
+                      prm.method == LOCGPU_P2P ? 1 : 0, ctx->count_visits ? ctx->d_visits : nullptr, b->d_redo_list, b->d_redo_count,
+                      ctx->d_search_stats};
         if (!launch_icp_search(sa, s)) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
         mark();
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
@@ -540,6 +547,21 @@ int locgpu_profile_read(locgpu_ctx* ctx, double out[6], int reset) {
     }
     if (reset)
         for (int j = 0; j < 3; ++j) { ctx->prof_ms[j] = 0; ctx->prof_n[j] = 0; }
+    return LOCGPU_OK;
+}
+
+int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[2], int reset) {
+    if (!ctx || !out) return LOCGPU_ERR_INVALID;
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_search_stats) {
+        LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_search_stats, 2 * sizeof(unsigned long long)));
+        LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, 2 * sizeof(unsigned long long)));
+    }
+    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long h[2];
+    LOCGPU_HIP(ctx, hipMemcpy(h, ctx->d_search_stats, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = h[0]; out[1] = h[1];
+    if (reset) LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, sizeof(h)));
     return LOCGPU_OK;
 }
 
