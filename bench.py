@@ -141,7 +141,7 @@ def main():
         t_accum = prof["accum_ms"] * prof["accum_n"] / args.steps
         t_solve = prof["solve_ms"] * prof["solve_n"] / args.steps
         if t_search >= t_accum:
-            kname, kbytes, kt, kn, kavg = "icp_search_kernel", search_bytes, t_search, prof["search_n"], prof["search_ms"]
+            kname, kbytes, kt, kn, kavg = "icp_search_fast_kernel(+redo)", search_bytes, t_search, prof["search_n"], prof["search_ms"]
         else:
             kname, kbytes, kt, kn, kavg = "icp_plane_accum_kernel", accum_bytes, t_accum, prof["accum_n"], prof["accum_ms"]
         launches_per_step = kn / args.steps

@@ -48,18 +48,18 @@ __global__ __launch_bounds__(kBlock) void icp_search_kernel(const uint2* __restr
 
 // K1 fast path (see tree_knn_fast): exact for every query it completes; the others go to redo_list.
 // search_stats[0] += queries handled here, search_stats[1] += queries handed to the exact redo kernel.
-template <int K, int DF>
-__global__ __launch_bounds__(kBlock) void icp_search_fast_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+template <int K, int DF, int BLK>
+__global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, float alpha_eff, int T,
                                                                  unsigned int tree_bytes, int skip_nonfinite, uint32_t* __restrict__ redo_list,
                                                                  unsigned int* __restrict__ redo_count,
                                                                  unsigned long long* __restrict__ search_stats) {
-    __shared__ uint2 s_stack[DF][kBlock];
+    __shared__ uint2 s_stack[DF][BLK];
     const int scan = blockIdx.y;
     if (st[scan].done) return;
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * kBlock + tid;
+    const int i = blockIdx.x * BLK + tid;
     if (i >= counts[scan]) return;
     const size_t gi = (size_t)scan * max_n + i;
     const float4 p = src[gi];
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void icp_search_fast_kernel(const uint2* __
     const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
     SortedSet<K> set;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
-    const bool slow = tree_knn_fast<K, DF>(rsrc, (float)qs.x, (float)qs.y, (float)qs.z, alpha_eff, T, s_stack, tid, set);
+    const bool slow = tree_knn_fast<K, DF, BLK>(rsrc, (float)qs.x, (float)qs.y, (float)qs.z, alpha_eff, T, s_stack, tid, set);
     if (slow) {
         redo_list[atomicAdd(redo_count, 1u)] = (uint32_t)gi;
     } else {
@@ -497,24 +497,51 @@ static bool launch_search_k(const SearchArgs& a, hipStream_t s) {
     else return false;
     return true;
 }
-constexpr int kFastStack = 16;  // LDS stack entries per thread in the fast kernel (8 B each → 32 KB per workgroup, 5 workgroups per CU)
+// LDS stack entries per thread in the fast kernel (8 B each): 20 → 40 KB per 256-thread workgroup, 4 workgroups per CU.
+// Default workgroup = one wave (64 threads, 10 KB LDS): waves retire independently. LOCGPU_FAST_STACK=16|24 and
+// LOCGPU_FAST_BLOCK=128|256 select other shapes for experiments.
+static int fast_stack_depth() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LOCGPU_FAST_STACK"); v = e ? atoi(e) : 20; if (v != 16 && v != 24) v = 20; }
+    return v;
+}
 
-template <int K, int D>
-static void launch_fast_kd(const SearchArgs& a, int T, hipStream_t s) {
-    constexpr int DF = kFastStack;
-    dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
+template <int K, int D, int DF>
+static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
+    const int T = a.depth > DF ? a.depth - DF : 0;  // leading stack positions the fast kernel does not store
+    static const int blk = [] { const char* e = getenv("LOCGPU_FAST_BLOCK"); const int v = e ? atoi(e) : 64; return (v == 256 || v == 128) ? v : 64; }();
     (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);
-    hipLaunchKernelGGL((icp_search_fast_kernel<K, DF>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+    if (blk != 256) {
+        dim3 g2((a.max_n + blk - 1) / blk, a.n_scans);
+        if (blk == 64)
+            hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 64>), g2, dim3(64), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+                               a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
+        else
+            hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 128>), g2, dim3(128), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+                               a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
+        hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(512), dim3(kBlock), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
+                           a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
+        return;
+    }
+    dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
+    hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, kBlock>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                        a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
     hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(512), dim3(kBlock), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                        a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
 }
+template <int K, int D>
+static void launch_fast_d(const SearchArgs& a, hipStream_t s) {
+    switch (fast_stack_depth()) {
+        case 16: launch_fast_kd<K, D, 16>(a, s); break;
+        case 24: launch_fast_kd<K, D, 24>(a, s); break;
+        default: launch_fast_kd<K, D, 20>(a, s); break;
+    }
+}
 template <int K>
 static bool launch_fast_k(const SearchArgs& a, hipStream_t s) {
-    const int T = a.depth > kFastStack ? a.depth - kFastStack : 0;  // leading stack positions the fast kernel does not store
-    if (a.depth <= 32) launch_fast_kd<K, 32>(a, T, s);
-    else if (a.depth <= 40) launch_fast_kd<K, 40>(a, T, s);
-    else if (a.depth <= 64) launch_fast_kd<K, 64>(a, T, s);
+    if (a.depth <= 32) launch_fast_d<K, 32>(a, s);
+    else if (a.depth <= 40) launch_fast_d<K, 40>(a, s);
+    else if (a.depth <= 64) launch_fast_d<K, 64>(a, s);
     else return false;
     return true;
 }

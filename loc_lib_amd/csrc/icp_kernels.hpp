@@ -299,9 +299,9 @@ struct SortedSet {  // ascending: d[0] ≤ … ≤ d[K-1]; empty slots hold +inf
 // buffer_load_dwordx4 (32-bit offset) returns a node together with the slot behind it (a whole leaf).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int K, int DF>
+template <int K, int DF, int BLK>
 __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, float qx, float qy, float qz, float alpha_eff, int T,
-                                              uint2 (*s_stack)[kBlock], int tid, SortedSet<K>& set) {
+                                              uint2 (*s_stack)[BLK], int tid, SortedSet<K>& set) {
     set.init();
     int sp = 0, replay = 0;
     uint32_t cur = 0;
@@ -316,25 +316,28 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
             const bool full = set.n >= K;
             const float top = set.top();
 
-            // leaf side (ComputeDisForLeaf, kdtree.cpp:197-212), predicated on is_leaf
-            const float dx = qx - as_f32(w.x), dy = qy - as_f32(w.z), dz = qz - as_f32(w.w);
-            const float dis2 = dx * dx + (dy * dy + dz * dz);
-            const bool ins = is_leaf && (dis2 < top);  // n<K: top is +inf; n==K: strict `<` (kdtree.cpp:207)
-            slow |= is_leaf && !ins && !full;           // inf/NaN distance while filling: the exact kernel decides
-            bool tie = false;
+            // leaf side (ComputeDisForLeaf, kdtree.cpp:197-212). A real branch: during the first descent no lane of the
+            // wave sits on a leaf and the whole block is skipped; inside it is select-only.
+            if (is_leaf) {
+                const float dx = qx - as_f32(w.x), dy = qy - as_f32(w.z), dz = qz - as_f32(w.w);
+                const float dis2 = dx * dx + (dy * dy + dz * dz);
+                const bool ins = dis2 < top;  // n<K: top is +inf; n==K: strict `<` (kdtree.cpp:207)
+                slow |= !ins && !full;        // inf/NaN distance while filling: the exact kernel decides
+                bool tie = false;
 #pragma unroll
-            for (int j = 0; j < K - 1; ++j) tie |= (dis2 == set.d[j]);
-            slow |= ins && tie;
-            set.d[K - 1] = ins ? dis2 : set.d[K - 1];
-            set.id[K - 1] = ins ? cur : set.id[K - 1];
+                for (int j = 0; j < K - 1; ++j) tie |= (dis2 == set.d[j]);
+                slow |= ins && tie;
+                set.d[K - 1] = ins ? dis2 : set.d[K - 1];
+                set.id[K - 1] = ins ? cur : set.id[K - 1];
 #pragma unroll
-            for (int j = K - 1; j > 0; --j) {  // one bubble pass; a no-op when nothing was inserted
-                const bool sw = set.d[j] < set.d[j - 1];
-                const float lo = sw ? set.d[j] : set.d[j - 1], hi = sw ? set.d[j - 1] : set.d[j];
-                const uint32_t ilo = sw ? set.id[j] : set.id[j - 1], ihi = sw ? set.id[j - 1] : set.id[j];
-                set.d[j - 1] = lo; set.d[j] = hi; set.id[j - 1] = ilo; set.id[j] = ihi;
+                for (int j = K - 1; j > 0; --j) {  // one bubble pass; a no-op when nothing was inserted
+                    const bool sw = set.d[j] < set.d[j - 1];
+                    const float lo = sw ? set.d[j] : set.d[j - 1], hi = sw ? set.d[j - 1] : set.d[j];
+                    const uint32_t ilo = sw ? set.id[j] : set.id[j - 1], ihi = sw ? set.id[j - 1] : set.id[j];
+                    set.d[j - 1] = lo; set.d[j] = hi; set.id[j - 1] = ilo; set.id[j] = ihi;
+                }
+                set.n += (ins && !full) ? 1 : 0;
             }
-            set.n += (ins && !full) ? 1 : 0;
 
             // internal side (Knn, kdtree.cpp:177-194), predicated on !is_leaf
             const float th = as_f32(w.x);
