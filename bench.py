@@ -153,7 +153,7 @@ def main():
                         nodes_per_query=round(vc["nodes"] / max(q, 1), 2), leaves_per_query=round(vc["leaves"] / max(q, 1), 2))
         line = dict(metric="scans/sec (64x1800-pt scan vs 10M-pt map) + ICP iter ms", value=round(value, 3), unit="scans/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 4),
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64 accumulate / f32 search", data="synthetic",
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", search_dtype="f32", data="synthetic",
                     config=dict(workload="BASELINE configs[2]: %d scans/GPU x 115200 pts (64x1800, cityblock-v1) vs one %d-pt map, "
                                          "P2Plane ICP, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), scans sharded by rank, no collective"
                                          % (B, args.map_points),

@@ -1,0 +1,186 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol include/locgpu.h declares, fails
+loudly without a GPU, and its host logic (packed KD-tree ingest, Gauss–Newton update) matches the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "locgpu.h")).read()
+    return sorted(set(re.findall(r"LOCGPU_API\s+[\w\s\*]+?\b(locgpu_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(api):
+    lib = api.lib()
+    declared = _header_functions()
+    assert len(declared) >= 25
+    missing = [f for f in declared if not hasattr(lib, f)]
+    assert not missing, missing
+    assert sorted(api.ABI_SYMBOLS) == declared  # the Python binding covers the whole header, nothing more
+
+
+def test_header_cites_reference_for_every_entry_point():
+    text = open(os.path.join(ROOT, "include", "locgpu.h")).read()
+    for fn in ("locgpu_icp_set_target", "locgpu_knn", "locgpu_icp_hb", "locgpu_icp_align", "locgpu_transform_cloud",
+               "locgpu_ndt_set_target", "locgpu_ndt_align"):
+        pos = text.index(fn + "(")
+        block = text[max(0, pos - 900):pos]
+        assert re.search(r"\.(cpp|h|hpp):\d+", block), fn
+
+
+def test_option_defaults_are_the_reference_defaults(api):
+    o = api.icp_opts()
+    # IcpOptions, icp_registration.hpp:29-38
+    assert (o.method, o.max_iteration, o.max_nn_distance, o.max_plane_distance, o.max_line_distance, o.min_effective_pts, o.eps) == \
+        (0, 20, 1.0, 0.1, 0.5, 10, 1e-2)
+    assert o.approximate == 1 and abs(o.ann_alpha - 0.1) < 1e-7  # kdtree.h:128-129
+    n = api.ndt_opts()
+    # NdtOptions, ndt_registration.hpp:28-41
+    assert (n.max_iteration, n.voxel_size, n.min_effective_pts, n.min_pts_in_voxel, n.eps, n.res_outlier_th, n.nearby_type) == \
+        (20, 1.0, 10, 3, 1e-2, 20.0, 1)
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback(api):
+    if api.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(api.LocGpuError) as e:
+        api.Context(0)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under loc_lib_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("loc_lib_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"\blocref\b|oracle[/\.]", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+
+
+# ---------------------------------------------------------------------------------------------- host logic: tree ingest
+def _packed_tree(api, xyz):
+    L = api.lib()
+    L.locgpu_debug_build_tree.restype = ctypes.c_size_t
+    L.locgpu_debug_build_tree.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    xyz = np.ascontiguousarray(xyz[:, :3], dtype=np.float32)
+    info = np.zeros(3, dtype=np.int64)
+    n = L.locgpu_debug_build_tree(xyz.ctypes.data, len(xyz), None, 0, info.ctypes.data)
+    slots = np.zeros(n, dtype=np.uint64)
+    L.locgpu_debug_build_tree(xyz.ctypes.data, len(xyz), slots.ctypes.data, n, info.ctypes.data)
+    return slots, info
+
+
+def _preorder(slots):
+    lo = (slots & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (slots >> np.uint64(32)).astype(np.uint32)
+    axis, th, pidx, right = [], [], [], []
+    i = 0
+    while i < len(slots):
+        tag = int(hi[i] >> 30)
+        if tag == 3:
+            axis.append(-1); th.append(0.0); pidx.append(int(hi[i] & 0x3FFFFFFF)); right.append(-1)
+            i += 2
+        else:
+            axis.append(tag); th.append(float(lo[i:i + 1].view(np.float32)[0])); pidx.append(-1); right.append(int(hi[i] & 0x3FFFFFFF))
+            i += 1
+    return np.array(axis, np.int32), np.array(th, np.float32), np.array(pidx, np.int32), right
+
+
+@pytest.mark.parametrize("case", ["uniform", "city", "duplicates", "tiny", "planar"])
+def test_packed_tree_equals_oracle_tree(api, locref, synth, case):
+    rng = np.random.RandomState(7)
+    if case == "uniform":
+        pts = (rng.rand(30000, 3) * 50).astype(np.float32)
+    elif case == "city":
+        pts = synth.make_map(150000)
+    elif case == "duplicates":
+        pts = (rng.rand(2000, 3) * 5).astype(np.float32)
+        pts[100:400] = pts[100]
+        pts[1000:1010, 0] = pts[1000, 0]
+    elif case == "tiny":
+        pts = (rng.rand(3, 3)).astype(np.float32)
+    else:
+        pts = np.c_[rng.rand(20000, 2) * 30, np.zeros(20000)].astype(np.float32)  # zero variance on z
+    slots, info = _packed_tree(api, pts)
+    tree = locref.KdTree(pts)
+    assert tuple(int(v) for v in info) == (tree.num_leaves, tree.num_nodes, tree.depth)
+    a, t, p = tree.dump()
+    a2, t2, p2, _ = _preorder(slots)
+    np.testing.assert_array_equal(a, a2)
+    np.testing.assert_array_equal(t.view(np.uint32), t2.view(np.uint32))  # thresholds bit-identical (f32 sequential sums)
+    np.testing.assert_array_equal(p, p2)
+
+
+def test_packed_tree_child_links_reproduce_knn(api, locref):
+    """Walk the packed slots (left = slot+1, right = stored index) with the reference's DFS in pure Python (small case)."""
+    rng = np.random.RandomState(8)
+    pts = (rng.rand(600, 3) * 10).astype(np.float32)
+    slots, _ = _packed_tree(api, pts)
+    lo = (slots & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (slots >> np.uint64(32)).astype(np.uint32)
+    f = lambda u: np.array([u], dtype=np.uint32).view(np.float32)[0]
+    tree = locref.KdTree(pts)
+    q = (rng.rand(40, 3) * 10).astype(np.float32)
+    ref = tree.knn(q, k=5, approximate=True, alpha=0.1)
+    import heapq
+    for qi in range(len(q)):
+        heap = []  # max-heap via negated distance; ties are irrelevant on random data
+
+        def knn(slot):
+            tag = int(hi[slot] >> 30)
+            if tag == 3:
+                p = np.array([f(lo[slot]), f(lo[slot + 1]), f(hi[slot + 1])], dtype=np.float32)
+                d = q[qi] - p
+                d2 = np.float32(d[0] * d[0]) + (np.float32(d[1] * d[1]) + np.float32(d[2] * d[2]))
+                idx = int(hi[slot] & 0x3FFFFFFF)
+                if len(heap) < 5:
+                    heapq.heappush(heap, (-d2, idx))
+                elif d2 < -heap[0][0]:
+                    heapq.heapreplace(heap, (-d2, idx))
+                return
+            th = f(lo[slot])
+            left, right = slot + 1, int(hi[slot] & 0x3FFFFFFF)
+            this, that = (left, right) if q[qi][tag] < th else (right, left)
+            knn(this)
+            dd = np.float32(q[qi][tag] - th)
+            if len(heap) < 5 or np.float32(dd * dd) < np.float32(np.float32(-heap[0][0]) * np.float32(0.1)):
+                knn(that)
+
+        knn(0)
+        got = [i for _, i in sorted(heap, key=lambda t: -t[0])]
+        assert got == list(ref[qi])
+
+
+# ---------------------------------------------------------------------------------------------- host logic: GN update
+def test_gn_update_matches_oracle(api, locref):
+    rng = np.random.RandomState(9)
+    for method in (0, 2):
+        J = rng.randn(50, 6)
+        H = J.T @ J
+        B = rng.randn(6) * 0.1
+        hb = np.concatenate([H.reshape(-1), B, [50.0, 1.0]])
+        pose = np.array([0.1, -0.2, 0.3, 0.9, 1.0, 2.0, 3.0])
+        pose[:4] /= np.linalg.norm(pose[:4])
+        new_pose, dx, applied, stop = api.gn_update(hb, method, 10, 1e-2, pose)
+        det, x = locref.lu6(H, B)
+        if method == 0:
+            x = x / 16  # icp cpp:287
+        np.testing.assert_allclose(dx, x, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(new_pose, locref.apply_update(pose, x), rtol=0, atol=1e-15)
+        assert applied and stop == (np.linalg.norm(x) < 1e-2)
+    # too few effective points, or singular H: no update (icp cpp:204-211)
+    hb = np.concatenate([np.eye(6).reshape(-1), np.ones(6), [5.0, 0.0]])
+    p2, dx, applied, stop = api.gn_update(hb, 2, 10, 1e-2, pose)
+    assert not applied and not stop and np.array_equal(p2, pose)
+    hb = np.concatenate([np.zeros(36), np.ones(6), [50.0, 0.0]])
+    p2, dx, applied, stop = api.gn_update(hb, 2, 10, 1e-2, pose)
+    assert not applied and np.array_equal(p2, pose)
