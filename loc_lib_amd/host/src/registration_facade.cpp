@@ -1,0 +1,156 @@
+// loc_lib_amd/host/src/registration_facade.cpp — the reference's matcher classes as thin hosts of liblocgpu.so.
+//
+// Behaviour kept from the reference (file:line = reference):
+//  * inputs are deep-copied by the library before a call returns (icp_registration.cpp:16,259) — callers may mutate
+//    or free their clouds right away (Lio re-filters local_map_ in place, lio.cpp:297);
+//  * ScanMatch returns true unconditionally (icp_registration.cpp:243, ndt_registration.cpp:260); on internal failure
+//    the pose is the last successful iterate; direct NDT with det(H)==0 leaves result_pose untouched (ndt cpp:435-436);
+//  * `use_ann` can only switch approximate search ON, and it is on by default (icp_registration.hpp:76-79 +
+//    kdtree.h:128): every reference ICP run uses the alpha=0.1 pruned search, so does this one;
+//  * the output cloud is `*result = *source` with x,y,z replaced by the float32 transform (icp cpp:241).
+#include <cstring>
+
+#include "../../../include/locgpu.h"
+#include "LocUtils/model/matching/3d/icp/icp_registration.hpp"
+#include "LocUtils/model/matching/3d/ndt/ndt_registration.hpp"
+#include "LocUtils/model/search_point/kdtree/kdtree.h"
+
+namespace LocUtils {
+
+namespace {
+locgpu_icp_opts to_c(const IcpOptions& o) {
+    locgpu_icp_opts c;
+    locgpu_icp_opts_default(&c);
+    c.method = o.method_ == IcpMethod::P2P ? LOCGPU_P2P : (o.method_ == IcpMethod::P2LINE ? LOCGPU_P2LINE : LOCGPU_P2PLANE);
+    c.max_iteration = o.max_iteration_;
+    c.max_nn_distance = o.max_nn_distance_;
+    c.max_plane_distance = o.max_plane_distance_;
+    c.max_line_distance = o.max_line_distance_;
+    c.min_effective_pts = o.min_effective_pts_;
+    c.eps = o.eps_;
+    c.approximate = 1;  // see header comment: the reference never disables ANN
+    c.ann_alpha = 0.1f;
+    return c;
+}
+bool write_output_cloud(locgpu_ctx* ctx, const CloudPtr& src, const SE3& pose, CloudPtr& out) {
+    if (!out) return false;  // the reference would dereference null here (loc.cpp:215 always allocates it)
+    *out = *src;             // keeps intensity and the other fields, like pcl::transformPointCloud
+    if (src->points.empty()) return true;
+    return locgpu_transform_cloud(ctx, pose.data(), src->points.data(), src->points.size(), sizeof(PointType), out->points.data(),
+                                  sizeof(PointType)) == LOCGPU_OK;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ ICP
+IcpRegistration::IcpRegistration() {}
+IcpRegistration::IcpRegistration(IcpOptions options) : options_(options) {}
+IcpRegistration::~IcpRegistration() { locgpu_destroy(ctx_); }
+void IcpRegistration::SetDevice(int device_id) { device_id_ = device_id; }
+const char* IcpRegistration::LastError() const { return locgpu_last_error(ctx_); }
+bool IcpRegistration::EnsureContext() { return ctx_ || locgpu_create(device_id_, &ctx_) == LOCGPU_OK; }
+
+bool IcpRegistration::SetInputTarget(const CloudPtr& input_target) {
+    if (options_.method_ == IcpMethod::PCLICP || !input_target || !EnsureContext()) return false;
+    has_target_ = locgpu_icp_set_target(ctx_, input_target->points.data(), input_target->points.size(), sizeof(PointType)) == LOCGPU_OK;
+    return true;  // the reference returns true whatever happened (icp_registration.cpp:28)
+}
+
+bool IcpRegistration::CaculateMatrixHAndB(const CloudPtr& input_source, const SE3& predict_pose, Mat6d& H, Vec6d& B) {
+    if (options_.method_ == IcpMethod::PCLICP) return true;  // `default: break; return true` (icp cpp:51-54)
+    if (!has_target_ || !input_source) return false;
+    const locgpu_icp_opts o = to_c(options_);
+    double h[36], b[6];
+    int ok = 0;
+    if (locgpu_icp_hb(ctx_, input_source->points.data(), input_source->points.size(), sizeof(PointType), predict_pose.data(), &o, h, b, nullptr,
+                      &ok) != LOCGPU_OK)
+        return false;
+    // the reference ACCUMULATES into the caller's H and B (icp cpp:87-88 `H +=`), LoamRegistration passes zeros
+    for (int i = 0; i < 36; ++i) H.data()[i] += h[i];  // symmetric: storage order irrelevant
+    for (int i = 0; i < 6; ++i) B.data()[i] += b[i];
+    return ok != 0;
+}
+
+bool IcpRegistration::ScanMatch(const CloudPtr& input_source, const SE3& predict_pose, CloudPtr& result_cloud_ptr, SE3& result_pose) {
+    if (!input_source) return true;
+    SE3 pose = predict_pose;
+    if (has_target_ && options_.method_ != IcpMethod::PCLICP && !input_source->points.empty()) {
+        const locgpu_icp_opts o = to_c(options_);
+        double out[7];
+        if (locgpu_icp_align(ctx_, input_source->points.data(), input_source->points.size(), sizeof(PointType), predict_pose.data(), &o, out,
+                             nullptr) == LOCGPU_OK)
+            std::memcpy(pose.data(), out, sizeof(out));
+    }
+    result_pose = pose;
+    if (ctx_) write_output_cloud(ctx_, input_source, result_pose, result_cloud_ptr);
+    return true;  // icp_registration.cpp:243
+}
+
+float IcpRegistration::GetFitnessScore() { return 0.0f; }  // icp_registration.cpp:246-250
+
+// ------------------------------------------------------------------------------------------------ NDT
+NdtRegistration::NdtRegistration() { options_.inv_voxel_size_ = 1.0 / options_.voxel_size_; }
+NdtRegistration::NdtRegistration(NdtOptions options) : options_(options) { options_.inv_voxel_size_ = 1.0 / options_.voxel_size_; }
+NdtRegistration::~NdtRegistration() { locgpu_destroy(ctx_); }
+void NdtRegistration::SetDevice(int device_id) { device_id_ = device_id; }
+const char* NdtRegistration::LastError() const { return locgpu_last_error(ctx_); }
+bool NdtRegistration::EnsureContext() { return ctx_ || locgpu_create(device_id_, &ctx_) == LOCGPU_OK; }
+
+bool NdtRegistration::SetInputTarget(const CloudPtr& input_target) {
+    if (options_.method_ != NdtMethod::DIRECT_NDT || !input_target || !EnsureContext()) return true;  // ndt cpp:67-83 always true
+    locgpu_ndt_opts o;
+    locgpu_ndt_opts_default(&o);
+    o.max_iteration = options_.max_iteration_;
+    o.voxel_size = options_.voxel_size_;
+    o.min_effective_pts = options_.min_effective_pts_;
+    o.min_pts_in_voxel = options_.min_pts_in_voxel_;
+    o.eps = options_.eps_;
+    o.res_outlier_th = options_.res_outlier_th_;
+    o.nearby_type = options_.nearby_type_ == NdtNearbyType::CENTER ? 0 : 1;
+    has_target_ = locgpu_ndt_set_target(ctx_, input_target->points.data(), input_target->points.size(), sizeof(PointType), &o) == LOCGPU_OK;
+    return true;
+}
+
+bool NdtRegistration::CaculateMatrixHAndB(const CloudPtr&, const SE3&, Mat6d&, Vec6d&) { return true; }  // empty body in the reference (ndt cpp:43-49)
+
+bool NdtRegistration::ScanMatch(const CloudPtr& input_source, const SE3& predict_pose, CloudPtr& result_cloud_ptr, SE3& result_pose) {
+    if (!input_source) return true;
+    if (has_target_ && options_.method_ == NdtMethod::DIRECT_NDT && !input_source->points.empty()) {
+        double out[7];
+        locgpu_align_stats st;
+        if (locgpu_ndt_align(ctx_, input_source->points.data(), input_source->points.size(), sizeof(PointType), predict_pose.data(), out, &st) ==
+                LOCGPU_OK && st.status == 0)
+            std::memcpy(result_pose.data(), out, sizeof(out));
+        // st.status == 1: det(H)==0 ⇒ AlignNdt returned before assigning result_pose (ndt cpp:435-436): leave it as the caller had it
+    }
+    if (ctx_) write_output_cloud(ctx_, input_source, result_pose, result_cloud_ptr);
+    return true;  // ndt_registration.cpp:260
+}
+
+float NdtRegistration::GetFitnessScore() { return 0.0f; }  // ndt_registration.cpp:466-471
+
+// ------------------------------------------------------------------------------------------------ search plug-in
+KdtreeRegistration::KdtreeRegistration(bool) {}
+KdtreeRegistration::~KdtreeRegistration() { locgpu_destroy(ctx_); }
+
+bool KdtreeRegistration::SetTargetCloud(const CloudPtr& cloud) {
+    if (!cloud || cloud->points.empty()) return false;  // kdtree.cpp:263-266
+    if (!ctx_ && locgpu_create(0, &ctx_) != LOCGPU_OK) return false;
+    return locgpu_icp_set_target(ctx_, cloud->points.data(), cloud->points.size(), sizeof(PointType)) == LOCGPU_OK;
+}
+
+bool KdtreeRegistration::FindNearstPointsBatch(const float* xyz, size_t n, int k, std::vector<int>& out) {
+    out.assign(n * (size_t)k, -1);
+    return ctx_ && locgpu_knn(ctx_, xyz, n, k, approximate_ ? 1 : 0, alpha_, LOCGPU_SEARCH_TREE_FAITHFUL, out.data(), nullptr) == LOCGPU_OK;
+}
+
+std::vector<int> KdtreeRegistration::FindNearstPoints(const Vec3f& point, int k) {
+    const float q[3] = {point[0], point[1], point[2]};
+    std::vector<int> out;
+    if (!FindNearstPointsBatch(q, 1, k, out)) out.clear();  // k > size_: empty result (kdtree.cpp:149-153)
+    return out;
+}
+
+void KdtreeRegistration::FindCloud(const CloudPtr&, std::vector<std::pair<size_t, size_t>>&) {}
+void KdtreeRegistration::SetEnableANN(bool use_ann, float alpha) { approximate_ = use_ann; alpha_ = alpha; }
+
+}  // namespace LocUtils

@@ -1,0 +1,68 @@
+// tests/cpp/facade_scanmatch.cpp — drives the C++ façade exactly the way Loc::Update does (loc.cpp:194,229):
+// SetInputTarget(map) once, then ScanMatch(scan, predict, out_cloud, out_pose) through a MatchingInterface pointer.
+// Usage: facade_scanmatch <icp|ndt> <method 0..2> <map.bin> <scan.bin> <pose7.bin> <out.bin>
+// Cloud files: raw float32 [n][3]; out.bin: 7 doubles (pose) then n*3 float32 (transformed cloud xyz).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "LocUtils/model/matching/3d/icp/icp_registration.hpp"
+#include "LocUtils/model/matching/3d/ndt/ndt_registration.hpp"
+
+using namespace LocUtils;
+
+static CloudPtr load(const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { std::perror(path); std::exit(2); }
+    std::fseek(f, 0, SEEK_END);
+    const long bytes = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<float> raw(bytes / 4);
+    if (std::fread(raw.data(), 4, raw.size(), f) != raw.size()) std::exit(2);
+    std::fclose(f);
+    CloudPtr c(new PointCloudType);
+    c->points.resize(raw.size() / 3);
+    for (size_t i = 0; i < c->points.size(); ++i) {
+        c->points[i].x = raw[3 * i]; c->points[i].y = raw[3 * i + 1]; c->points[i].z = raw[3 * i + 2];
+        c->points[i].intensity = (float)i;
+    }
+    return c;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 7) { std::fprintf(stderr, "usage\n"); return 2; }
+    const std::string kind = argv[1];
+    const int method = std::atoi(argv[2]);
+    CloudPtr map = load(argv[3]), scan = load(argv[4]);
+    SE3 predict, result;
+    {
+        FILE* f = std::fopen(argv[5], "rb");
+        if (!f || std::fread(predict.data(), 8, 7, f) != 7) return 2;
+        std::fclose(f);
+    }
+    std::shared_ptr<MatchingInterface> match_ptr;  // what Loc / Lio hold (loc.hpp:85)
+    if (kind == "icp") {
+        IcpOptions o(method == 0 ? IcpMethod::P2P : (method == 1 ? IcpMethod::P2LINE : IcpMethod::P2PLANE));
+        match_ptr = std::make_shared<IcpRegistration>(o);
+    } else {
+        NdtOptions o;
+        match_ptr = std::make_shared<NdtRegistration>(o);
+    }
+    match_ptr->SetInputTarget(map);
+    map->points.clear();  // the matcher deep-copied it: callers may drop their cloud (lio.cpp:297 mutates it in place)
+    CloudPtr out(new PointCloudType);
+    const bool ok = match_ptr->ScanMatch(scan, predict, out, result);
+    if (!ok || out->points.size() != scan->points.size()) return 3;
+    for (size_t i = 0; i < out->points.size(); ++i)
+        if (out->points[i].intensity != (float)i) return 4;  // other fields survive the transform
+    FILE* f = std::fopen(argv[6], "wb");
+    std::fwrite(result.data(), 8, 7, f);
+    for (const auto& p : out->points) std::fwrite(&p.x, 4, 3, f);
+    std::fclose(f);
+    std::printf("pose %.12f %.12f %.12f %.12f %.9f %.9f %.9f\n", result.data()[0], result.data()[1], result.data()[2], result.data()[3],
+                result.data()[4], result.data()[5], result.data()[6]);
+    return 0;
+}

@@ -250,6 +250,37 @@ def test_ndt_negative_coordinates_truncate_toward_zero(gpu_ctx, locref):
     assert len(kg) == len(ko) == 1 and tuple(kg[0]) == (0, 0, 0)
 
 
+# ----------------------------------------------------------------------------------------------- C++ façade
+@pytest.mark.parametrize("kind,method", [("icp", 2), ("icp", 0), ("icp", 1), ("ndt", 0)])
+def test_cpp_facade_scanmatch(locref, small_world, tmp_path, kind, method):
+    """LocUtils::IcpRegistration / NdtRegistration (loc_lib_amd/host) driven through MatchingInterface like Loc::Update."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "cpp", "facade_scanmatch")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    m, s, init = small_world["map"], small_world["scan10k"], small_world["init_pose"]
+    np.ascontiguousarray(m[:, :3], dtype=np.float32).tofile(tmp_path / "map.bin")
+    np.ascontiguousarray(s[:, :3], dtype=np.float32).tofile(tmp_path / "scan.bin")
+    np.asarray(init, dtype=np.float64).tofile(tmp_path / "pose.bin")
+    r = subprocess.run([exe, kind, str(method), str(tmp_path / "map.bin"), str(tmp_path / "scan.bin"), str(tmp_path / "pose.bin"),
+                        str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(tmp_path / "out.bin", dtype=np.uint8)
+    pose = raw[:56].view(np.float64)
+    cloud = raw[56:].view(np.float32).reshape(-1, 3)
+    if kind == "icp":
+        ref = locref.Icp(method=method)
+        ref.set_target(m)
+        want = ref.align(s, init)["pose"]
+    else:
+        ref = locref.Ndt()
+        ref.set_target(m)
+        want = ref.align(s, init)["pose"]
+    dt, dr = pose_delta(pose, want)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+    np.testing.assert_array_equal(cloud.view(np.uint32), locref.transform_cloud_f32(pose, s[:, :3]).view(np.uint32))
+
+
 # ----------------------------------------------------------------------------------------------- golden fixtures
 def test_golden_fixture_gpu(gpu_ctx, api):
     """Committed golden vectors (tests/golden/make_golden.py, generated with the oracle in the build container)."""
