@@ -56,7 +56,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scans-per-gpu", type=int, default=32)
+    ap.add_argument("--scans-per-gpu", type=int, default=256)
+    ap.add_argument("--method", choices=["p2plane", "p2line", "p2p", "ndt"], default="p2plane",
+                    help="matcher to time; the headline metric is p2plane (others are reported for DESIGN.md tables)")
     ap.add_argument("--map-points", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -89,11 +91,19 @@ def main():
     t_ingest = time.time() - t0
     tinfo = ctx.icp_target_info()
     scan_ids = [(rank * B + i) % 256 for i in range(B)]
-    scans = [synth.make_scan(sid) for sid in scan_ids]
+    uniq = sorted(set(scan_ids))
+    scan_of = {sid: synth.make_scan(sid) for sid in uniq}
+    scans = [scan_of[sid] for sid in scan_ids]
     inits = np.stack([synth.make_pose(sid)[1] for sid in scan_ids])
     truth = np.stack([synth.make_pose(sid)[0] for sid in scan_ids])
     batch = ctx.batch(scans)
-    opts = api.icp_opts(method=api.P2PLANE)  # every other field = reference default
+    method = dict(p2plane=api.P2PLANE, p2line=api.P2LINE, p2p=api.P2P, ndt=-1)[args.method]
+    opts = api.icp_opts(method=max(method, 0))  # every other field = reference default
+    if method < 0:
+        t0 = time.time()
+        ctx.ndt_set_target(map_xyz)           # NdtOptions defaults: voxel 1.0, NEARBY6, DIRECT_NDT
+        t_ingest = time.time() - t0
+    align = (lambda: ctx.ndt_align_batch(batch, inits)) if method < 0 else (lambda: ctx.icp_align_batch(batch, inits, opts))
 
     def barrier():
         if dist is not None:
@@ -102,12 +112,12 @@ def main():
 
     # ---- visit counts of exactly this workload (separate instrumented pass, untimed) → algorithmic bytes
     ctx.visit_count_enable(True)
-    out_poses, stats = ctx.icp_align_batch(batch, inits, opts)
+    out_poses, stats = align()
     vc = ctx.visit_count_read(reset=True)
     ctx.visit_count_enable(False)
 
     for _ in range(args.warmup):
-        ctx.icp_align_batch(batch, inits, opts)
+        align()
 
     # ---- timed region: exactly `steps` steps; HIP events on the library's stream time each kernel launch
     ctx.profile_read(reset=True)
@@ -115,7 +125,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out_poses, stats = ctx.icp_align_batch(batch, inits, opts)
+        out_poses, stats = align()
     barrier()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
@@ -133,17 +143,20 @@ def main():
 
     if rank == 0:
         # roofline of the dominant kernel over the timed region (all launches, partially idle ones included)
-        k = 5
-        q = vc["queries"]
+        k = 1 if args.method == "p2p" else 5
+        q = vc["queries"] if method >= 0 else sum(s["iterations"] for s in stats) * 115200
         search_bytes = q * 16 + vc["nodes"] * 16 + q * 4 * k            # src float4 + one 16-B slot pair per node visit + index lists
         accum_bytes = q * (16 + 4 * k + 16 * k) + gn_iters * 29 * 8      # src + indices + 5 gathered leaves; partial sums negligible
+        if method < 0:
+            nv = ctx.ndt_target_info()["num_voxels"]
+            accum_bytes = q * (16 + 7 * 12) + (prof["accum_n"] or 1) * nv * 96  # src + 7 hash probes per point; voxel μ/info once per launch
         t_search = prof["search_ms"] * prof["search_n"] / args.steps      # ms per step
         t_accum = prof["accum_ms"] * prof["accum_n"] / args.steps
         t_solve = prof["solve_ms"] * prof["solve_n"] / args.steps
         if t_search >= t_accum:
             kname, kbytes, kt, kn, kavg = "icp_search_fast_kernel(+redo)", search_bytes, t_search, prof["search_n"], prof["search_ms"]
         else:
-            kname, kbytes, kt, kn, kavg = "icp_plane_accum_kernel", accum_bytes, t_accum, prof["accum_n"], prof["accum_ms"]
+            kname, kbytes, kt, kn, kavg = ("ndt_accum_kernel" if method < 0 else "icp_%s_accum_kernel" % args.method), accum_bytes, t_accum, prof["accum_n"], prof["accum_ms"]
         launches_per_step = kn / args.steps
         achieved = (kbytes / 1e9) / (kt / 1e3) if kt > 0 else 0.0
         roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -155,8 +168,8 @@ def main():
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 4),
                     higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", search_dtype="f32", data="synthetic",
                     config=dict(workload="BASELINE configs[2]: %d scans/GPU x 115200 pts (64x1800, cityblock-v1) vs one %d-pt map, "
-                                         "P2Plane ICP, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), scans sharded by rank, no collective"
-                                         % (B, args.map_points),
+                                         "%s, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), scans sharded by rank, no collective"
+                                         % (B, args.map_points, "direct NDT (voxel 1.0, NEARBY6)" if method < 0 else args.method.upper() + " ICP"),
                                 scans_per_gpu=B, map_points=args.map_points, search_mode="tree_faithful", tree_depth=tinfo["depth"],
                                 tree_bytes=tinfo["bytes"]),
                     icp_iter_ms=round((t_search + t_accum + t_solve) / max(prof["search_n"] / args.steps, 1), 5),
@@ -166,7 +179,7 @@ def main():
                     median_translation_error_to_truth_m=round(err_t, 4),
                     setup_s=dict(map_gen=round(t_map, 2), tree_ingest=round(t_ingest, 2)),
                     roofline=roofline)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.method == "p2plane":
             cb, cpu_poses = cpu_baseline(map_xyz, scans, inits, args.cpu_seconds)
             n = len(cpu_poses)
             d = np.linalg.norm(np.stack(cpu_poses)[:, 4:] - out_poses[:n, 4:], axis=1)

@@ -56,10 +56,13 @@ __device__ __host__ inline void quat_to_R(const double* q, double* R) {
 }
 
 // One-sided (Hestenes) Jacobi SVD, M×N, columns in a[N][M], right vectors accumulated in v[N][N].
-// Fully unrolled over (p,q) so both arrays live in VGPRs; the sweep loop exits per lane when a sweep
-// made no rotation (same rule as the oracle, so the iterates match bit for bit).
+// Fully unrolled over (p,q) so both arrays live in VGPRs; the sweep loop exits per lane when a sweep made no rotation.
+// This is FP64-issue bound, so FMA contraction is allowed HERE (results differ from the un-fused CPU oracle by
+// rounding only, ~1e-16 relative; the float32 search arithmetic stays un-fused). The rotation uses
+// t = sign(ζ)/(|ζ|+√(1+ζ²)), c = 1/√(1+t²), s = c·t with ζ = (β−α)/(2γ).
 template <int M, int N>
 __device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&v)[N][N]) {
+#pragma clang fp contract(fast)
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -77,7 +80,8 @@ __device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&
                     beta += a[q][i] * a[q][i];
                     gamma += a[p][i] * a[q][i];
                 }
-                if (!(gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
+                // converged pair: |γ| ≤ 1e-15·√(αβ)  ⇔  γ² ≤ 1e-30·αβ (no square root on the common path)
+                if (!(gamma == 0.0 || gamma * gamma <= 1e-30 * (alpha * beta))) {
                     rotated = true;
                     const double zeta = (beta - alpha) / (2.0 * gamma);
                     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

@@ -153,6 +153,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double* __
 // acc layout: [0..20] upper triangle of H row by row (00 01 .. 05 11 12 .. 55), [21..26] B, [27] effective_num.
 template <int ROWS>
 __device__ __forceinline__ void add_rows(double (&acc)[28], const double (&J)[ROWS][6], const double (&e)[ROWS]) {
+#pragma clang fp contract(fast)
     int o = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
