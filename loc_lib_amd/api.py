@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "locgpu_transform_cloud", "locgpu_batch_create", "locgpu_batch_destroy", "locgpu_icp_align_batch", "locgpu_ndt_align_batch",
     "locgpu_icp_hb_batch", "locgpu_gn_update", "locgpu_ndt_set_target", "locgpu_ndt_target_info", "locgpu_ndt_dump",
     "locgpu_ndt_align", "locgpu_profile_enable", "locgpu_profile_read", "locgpu_visit_count_enable", "locgpu_visit_count_read",
-    "locgpu_search_stats_read",
+    "locgpu_search_stats_read", "locgpu_graph_enable",
 ]
 
 
@@ -91,7 +91,7 @@ def lib():
             "locgpu_ndt_dump": (i32, [vp, vp, vp, vp, sz, vp]), "locgpu_ndt_align": (i32, [vp, vp, sz, sz, vp, vp, vp]),
             "locgpu_profile_enable": (i32, [vp, i32]), "locgpu_profile_read": (i32, [vp, vp, i32]),
             "locgpu_visit_count_enable": (i32, [vp, i32]), "locgpu_visit_count_read": (i32, [vp, vp, i32]),
-            "locgpu_search_stats_read": (i32, [vp, vp, i32]),
+            "locgpu_search_stats_read": (i32, [vp, vp, i32]), "locgpu_graph_enable": (i32, [vp, i32]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -261,6 +261,10 @@ class Context:
         self._check(lib().locgpu_ndt_align(self._h, s.ctypes.data, s.shape[0], s.strides[0], _pose(init_pose).ctypes.data, out.ctypes.data,
                                            ctypes.byref(st)))
         return out, _stats_dict(st)
+
+    def graph_enable(self, on=True):
+        """Replay a captured hipGraph of all Gauss–Newton iterations per align call (BASELINE config 5)."""
+        self._check(lib().locgpu_graph_enable(self._h, int(on)))
 
     # ---- measurement hooks
     def profile_enable(self, on=True):

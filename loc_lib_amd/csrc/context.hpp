@@ -34,6 +34,7 @@ struct locgpu_ctx {
     std::vector<hipEvent_t> events;
     double prof_ms[3] = {0, 0, 0};
     long long prof_n[3] = {0, 0, 0};
+    bool use_graph = false;  // replay a captured hipGraph of all GN iterations instead of eager chunks
     bool count_visits = false;
     unsigned long long* d_visits = nullptr;
     unsigned long long* d_search_stats = nullptr;  // [2]: queries searched / queries redone by the exact kernel
@@ -51,6 +52,13 @@ struct locgpu_batch {
     double* d_hb = nullptr;        // [n_scans][44]
     uint32_t* d_redo_list = nullptr;      // [pitch]
     unsigned int* d_redo_count = nullptr;
+    // hipGraph of {H2D state, max_iteration × (search, fit+accumulate, solve), D2H state}, keyed by the launch parameters
+    hipGraphExec_t graph_exec = nullptr;
+    locgpu::GnParams graph_prm{};
+    int graph_k = -1;
+    float graph_alpha = 0.f;
+    bool graph_ndt = false;
+    const void* graph_target = nullptr;  // tree / NDT table the capture was made against
     locgpu::PoseState* h_state = nullptr;  // pinned
     double* h_hb = nullptr;                // pinned
     std::vector<int> counts;

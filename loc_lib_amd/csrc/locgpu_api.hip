@@ -44,6 +44,7 @@ static void free_batch(locgpu_batch* b) {
     if (b->d_hb) (void)hipFree(b->d_hb);
     if (b->d_redo_list) (void)hipFree(b->d_redo_list);
     if (b->d_redo_count) (void)hipFree(b->d_redo_count);
+    if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
     if (b->h_state) (void)hipHostFree(b->h_state);
     if (b->h_hb) (void)hipHostFree(b->h_hb);
     delete b;
@@ -273,6 +274,7 @@ struct IterLauncher {
 
     // One GN iteration = search + accumulate + solve. Returns false on a launch error.
     bool ndt = false;
+    bool capturing = false;  // inside hipStreamBeginCapture: no event records
     bool launch(int do_update);
     void collect_profile();
 };
@@ -285,7 +287,7 @@ namespace locgpu {
 
 bool IterLauncher::launch(int do_update) {
     hipStream_t s = ctx->stream;
-    const bool prof = ctx->profile;
+    const bool prof = ctx->profile && !capturing;
     auto mark = [&]() {
         if (!prof) return;
         hipEvent_t ev = get_event(ctx, ev_used);
@@ -327,9 +329,45 @@ void IterLauncher::collect_profile() {
     ev_used = 0;
 }
 
+static void write_results(locgpu_batch* b, const double* init_poses, double* out_poses, locgpu_align_stats* stats);
+
+// hipGraph path (BASELINE config 5): every GN iteration of the batch is captured once — the kernels early-out per scan on
+// the device-side `done` flag, so a fixed node sequence gives the same result as the data-dependent eager loop — and
+// replayed per call with a single host synchronisation at the end.
+static int run_align_graph(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt,
+                           double* out_poses, locgpu_align_stats* stats) {
+    hipStream_t s = ctx->stream;
+    init_states(b, init_poses);
+    const void* target = ndt ? (const void*)ctx->ndt->d_keys : (const void*)ctx->d_tree;
+    const bool same = b->graph_exec && b->graph_k == k && b->graph_alpha == alpha_eff && b->graph_ndt == ndt && b->graph_target == target &&
+                      std::memcmp(&b->graph_prm, &prm, sizeof(GnParams)) == 0;
+    if (!same) {
+        if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        LOCGPU_HIP(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        bool ok = hip_ok(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_scans * sizeof(PoseState), hipMemcpyHostToDevice, s), "capture H2D");
+        IterLauncher it{ctx, b, prm, k, alpha_eff};
+        it.ndt = ndt;
+        it.capturing = true;
+        for (int i = 0; ok && i < prm.max_iteration; ++i) ok = it.launch(1);
+        ok = ok && hip_ok(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_scans * sizeof(PoseState), hipMemcpyDeviceToHost, s), "capture D2H");
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (!ok || !hip_ok(ctx, e, "hipStreamEndCapture")) { if (graph) (void)hipGraphDestroy(graph); return LOCGPU_ERR_NO_DEVICE; }
+        const bool inst = hip_ok(ctx, hipGraphInstantiate(&b->graph_exec, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+        (void)hipGraphDestroy(graph);
+        if (!inst) { b->graph_exec = nullptr; return LOCGPU_ERR_NO_DEVICE; }
+        b->graph_prm = prm; b->graph_k = k; b->graph_alpha = alpha_eff; b->graph_ndt = ndt; b->graph_target = target;
+    }
+    LOCGPU_HIP(ctx, hipGraphLaunch(b->graph_exec, s));
+    LOCGPU_HIP(ctx, hipStreamSynchronize(s));
+    write_results(b, init_poses, out_poses, stats);
+    return LOCGPU_OK;
+}
+
 static int run_align(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt,
                      double* out_poses, locgpu_align_stats* stats) {
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->use_graph && !ctx->count_visits && prm.max_iteration > 0) return run_align_graph(ctx, b, init_poses, prm, k, alpha_eff, ndt, out_poses, stats);
     init_states(b, init_poses);
     hipStream_t s = ctx->stream;
     LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_scans * sizeof(PoseState), hipMemcpyHostToDevice, s));
@@ -350,6 +388,11 @@ static int run_align(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses,
             if (!b->h_state[i].done) { all_done = false; break; }
         if (launched >= prm.max_iteration) all_done = true;
     }
+    write_results(b, init_poses, out_poses, stats);
+    return LOCGPU_OK;
+}
+
+static void write_results(locgpu_batch* b, const double* init_poses, double* out_poses, locgpu_align_stats* stats) {
     for (int i = 0; i < b->n_scans; ++i) {
         const PoseState& ps = b->h_state[i];
         if (ps.status == 1) {  // direct NDT aborted: reference leaves result_pose unassigned; hand back init_pose
@@ -367,7 +410,6 @@ static int run_align(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses,
             stats[i].last_dx_norm = ps.last_dx_norm;
         }
     }
-    return LOCGPU_OK;
 }
 
 static int check_icp(locgpu_ctx* ctx, const locgpu_icp_opts* o, GnParams& prm, int& k, float& alpha_eff) {
@@ -533,6 +575,12 @@ int locgpu_transform_cloud(locgpu_ctx* ctx, const double pose[7], const void* sr
 }
 
 // --------------------------------------------------------------------------------------------- measurement
+int locgpu_graph_enable(locgpu_ctx* ctx, int on) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    ctx->use_graph = on != 0;
+    return LOCGPU_OK;
+}
+
 int locgpu_profile_enable(locgpu_ctx* ctx, int on) {
     if (!ctx) return LOCGPU_ERR_INVALID;
     ctx->profile = on != 0;

@@ -250,6 +250,44 @@ def test_ndt_negative_coordinates_truncate_toward_zero(gpu_ctx, locref):
     assert len(kg) == len(ko) == 1 and tuple(kg[0]) == (0, 0, 0)
 
 
+# ----------------------------------------------------------------------------------------------- hipGraph mode
+def test_graph_mode_equals_eager(gpu_ctx, api, synth, small_world):
+    """Captured hipGraph of all GN iterations (device-side early-outs) == the eager data-dependent loop, bit for bit;
+    the instantiated graph is replayed with new initial poses, other options re-capture."""
+    m = small_world["map"]
+    scans = [small_world["scan10k"], small_world["scan2k"], small_world["scan10k"][::3]]
+    init = small_world["init_pose"]
+    inits = np.stack([init, init, init])
+    inits[1, 4:] += [0.04, -0.03, 0.01]
+    gpu_ctx.icp_set_target(m)
+    gpu_ctx.ndt_set_target(m)
+    b = gpu_ctx.batch(scans)
+    try:
+        for method in (2, 0):
+            opts = api.icp_opts(method=method)
+            gpu_ctx.graph_enable(False)
+            want, wst = gpu_ctx.icp_align_batch(b, inits, opts)
+            gpu_ctx.graph_enable(True)
+            got, gst = gpu_ctx.icp_align_batch(b, inits, opts)      # capture + launch
+            np.testing.assert_array_equal(got, want)
+            assert [s["iterations"] for s in gst] == [s["iterations"] for s in wst]
+            inits2 = inits.copy()
+            inits2[:, 4:] += 0.02
+            got2, _ = gpu_ctx.icp_align_batch(b, inits2, opts)     # replay with other poses
+            gpu_ctx.graph_enable(False)
+            want2, _ = gpu_ctx.icp_align_batch(b, inits2, opts)
+            np.testing.assert_array_equal(got2, want2)
+        gpu_ctx.graph_enable(False)
+        want, _ = gpu_ctx.ndt_align_batch(b, inits)
+        gpu_ctx.graph_enable(True)
+        got, _ = gpu_ctx.ndt_align_batch(b, inits)
+        # NDT sums are FP64 atomics-free per scan (fixed order) ⇒ also bitwise equal
+        np.testing.assert_array_equal(got, want)
+    finally:
+        gpu_ctx.graph_enable(False)
+        b.close()
+
+
 # ----------------------------------------------------------------------------------------------- C++ façade
 @pytest.mark.parametrize("kind,method", [("icp", 2), ("icp", 0), ("icp", 1), ("ndt", 0)])
 def test_cpp_facade_scanmatch(locref, small_world, tmp_path, kind, method):
