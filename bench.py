@@ -51,6 +51,25 @@ def cpu_baseline(map_xyz, scans, inits, seconds_budget=20.0):
                        "%.1f ms per GN iteration" % (done, ingest, 1e3 * t_align / max(iters, 1))), poses
 
 
+def load_traffic(kernel_name, scans_per_gpu, map_points, method):
+    """HBM bytes per launch of `kernel_name` from the newest committed PMC collection (tools/collect_traffic.py) made on the
+    same workload, or None. bench.py cannot run rocprofv3 on itself; the collection is a separate --pmc run of this script."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        c = d.get("config", {})
+        if (c.get("scans_per_gpu"), c.get("map_points"), c.get("method")) != (scans_per_gpu, map_points, method):
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if k.split("<")[0] in kernel_name:
+                best = v.get("traffic_bytes_per_launch")
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,9 +177,10 @@ def main():
         else:
             kname, kbytes, kt, kn, kavg = ("ndt_accum_kernel" if method < 0 else "icp_%s_accum_kernel" % args.method), accum_bytes, t_accum, prof["accum_n"], prof["accum_ms"]
         launches_per_step = kn / args.steps
+        traffic = load_traffic(kname, B, args.map_points, args.method)
         achieved = (kbytes / 1e9) / (kt / 1e3) if kt > 0 else 0.0
         roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         algorithmic_bytes_per_launch=int(kbytes / max(launches_per_step, 1)), avg_launch_ms=round(kavg, 5),
                         launches_per_step=launches_per_step,
                         nodes_per_query=round(vc["nodes"] / max(q, 1), 2), leaves_per_query=round(vc["leaves"] / max(q, 1), 2))
