@@ -58,8 +58,7 @@ __device__ __host__ inline void quat_to_R(const double* q, double* R) {
 // One-sided (Hestenes) Jacobi SVD, M×N, columns in a[N][M], right vectors accumulated in v[N][N].
 // Fully unrolled over (p,q) so both arrays live in VGPRs; the sweep loop exits per lane when a sweep made no rotation.
 // This is FP64-issue bound, so FMA contraction is allowed HERE (results differ from the un-fused CPU oracle by
-// rounding only, ~1e-16 relative; the float32 search arithmetic stays un-fused). The rotation uses
-// t = sign(ζ)/(|ζ|+√(1+ζ²)), c = 1/√(1+t²), s = c·t with ζ = (β−α)/(2γ).
+// rounding only, ~1e-16 relative; the float32 search arithmetic stays un-fused).
 template <int M, int N>
 __device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&v)[N][N]) {
 #pragma clang fp contract(fast)
@@ -83,9 +82,16 @@ __device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&
                 // converged pair: |γ| ≤ 1e-15·√(αβ)  ⇔  γ² ≤ 1e-30·αβ (no square root on the common path)
                 if (!(gamma == 0.0 || gamma * gamma <= 1e-30 * (alpha * beta))) {
                     rotated = true;
-                    const double zeta = (beta - alpha) / (2.0 * gamma);
-                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / sqrt(1.0 + t * t);
+                    // Jacobi rotation that zeroes γ: t = tan θ = sign(ζ)/(|ζ|+√(1+ζ²)), ζ = (β−α)/(2γ), written as
+                    // t = 2γ / (d + sign(d)·√(d²+4γ²)) with d = β−α: one sqrt and one divide; c = 1/√(1+t²) from
+                    // v_rsq_f64 refined by two Newton steps (|c²+s²−1| ≲ 2e-16, as good as the divide-based form).
+                    const double d = beta - alpha, g2 = 2.0 * gamma;
+                    const double r = sqrt(d * d + g2 * g2);
+                    const double t = g2 / (d + (d >= 0.0 ? r : -r));
+                    const double x = 1.0 + t * t, hx = 0.5 * x;
+                    double c = __builtin_amdgcn_rsq(x);
+                    c = c * (1.5 - hx * c * c);
+                    c = c * (1.5 - hx * c * c);
                     const double s = c * t;
 #pragma unroll
                     for (int i = 0; i < M; ++i) {

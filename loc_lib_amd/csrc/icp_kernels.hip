@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kBlock) void icp_search_kernel(const uint2* __restr
 
 // K1 fast path (see tree_knn_fast): exact for every query it completes; the others go to redo_list.
 // search_stats[0] += queries handled here, search_stats[1] += queries handed to the exact redo kernel.
-template <int K, int DF, int BLK>
+template <int K, int DF, int BLK, bool STAMP = false>
 __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, float alpha_eff, int T,
@@ -72,7 +72,19 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
     const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
     SortedSet<K> set;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
-    const bool slow = tree_knn_fast<K, DF, BLK>(rsrc, (float)qs.x, (float)qs.y, (float)qs.z, alpha_eff, T, s_stack, tid, set);
+    unsigned long long diag[5] = {0, 0, 0, 0, 0};
+    const bool slow = tree_knn_fast<K, DF, BLK, STAMP>(rsrc, (float)qs.x, (float)qs.y, (float)qs.z, alpha_eff, T, s_stack, tid, set, diag);
+    if (STAMP && search_stats) {
+        // per-wave maxima (what the wave pays) and per-lane sums (useful work); search_stats[2..] are diagnostic slots
+        unsigned long long wmax[5];
+        for (int j = 0; j < 5; ++j) {
+            unsigned long long v = diag[j];
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+            wmax[j] = v;
+        }
+        for (int j = 0; j < 5; ++j) atomicAdd(&search_stats[2 + j], diag[j]);                 // lane sums
+        if ((tid & 63) == 0) { for (int j = 0; j < 5; ++j) atomicAdd(&search_stats[7 + j], wmax[j]); atomicAdd(&search_stats[12], 1ull); }  // wave maxima, waves
+    }
     if (slow) {
         redo_list[atomicAdd(redo_count, 1u)] = (uint32_t)gi;
     } else {
@@ -510,6 +522,16 @@ static int fast_stack_depth() {
 template <int K, int D, int DF>
 static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
     const int T = a.depth > DF ? a.depth - DF : 0;  // leading stack positions the fast kernel does not store
+    (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);
+    static const bool stamp = [] { const char* e = getenv("LOCGPU_STAMP"); return e && atoi(e) != 0; }();
+    if (stamp) {  // diagnostic build of the default shape; results unchanged, timing meaningless
+        dim3 g2((a.max_n + 63) / 64, a.n_scans);
+        hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 64, true>), g2, dim3(64), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+                           a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
+        hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(512), dim3(kBlock), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
+                           a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
+        return;
+    }
     static const int blk = [] { const char* e = getenv("LOCGPU_FAST_BLOCK"); const int v = e ? atoi(e) : 64; return (v == 256 || v == 128) ? v : 64; }();
     (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);
     if (blk != 256) {

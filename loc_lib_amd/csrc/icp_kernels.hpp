@@ -299,15 +299,49 @@ struct SortedSet {  // ascending: d[0] ≤ … ≤ d[K-1]; empty slots hold +inf
 // buffer_load_dwordx4 (32-bit offset) returns a node together with the slot behind it (a whole leaf).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int K, int DF, int BLK>
+// STAMP = diagnostic build only (LOCGPU_STAMP=1): diag[0..4] receive this lane's first-descent cycles, total cycles,
+// main-loop trips, VISIT trips and POP rounds. Never instantiated in the timed path.
+template <int K, int DF, int BLK, bool STAMP = false>
 __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, float qx, float qy, float qz, float alpha_eff, int T,
-                                              uint2 (*s_stack)[BLK], int tid, SortedSet<K>& set) {
+                                              uint2 (*s_stack)[BLK], int tid, SortedSet<K>& set, unsigned long long* diag = nullptr) {
+    unsigned long long t_begin = 0, t_mid = 0;
+    unsigned int n_trips = 0, n_visit = 0, n_pop = 0;
+    if (STAMP) t_begin = __builtin_amdgcn_s_memtime();
     set.init();
     int sp = 0, replay = 0;
     uint32_t cur = 0;
     float min_drop = __builtin_inff();
     bool slow = false, live = true, need_pop = false;
+
+    // ---- first descent: the result set is empty, so every internal node pushes its far side (NeedExpand is true while
+    // size < k) and no lane meets a leaf or pops. A minimal loop for these ≈depth trips; lanes leave it at their first leaf.
+    for (;;) {
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(tree_rsrc, (int)(cur << 3), 0, 0);
+        const uint32_t meta = w.y;
+        const uint32_t tag = meta >> 30;
+        if (tag == 3u) break;
+        const float th = as_f32(w.x);
+        const float qa = tag == 0u ? qx : (tag == 1u ? qy : qz);
+        const float dd = qa - th;
+        const float d2 = dd * dd;
+        const uint32_t right = meta & 0x3FFFFFFFu;
+        const bool go_left = qa < th;
+        if (sp < T) {
+            min_drop = d2 < min_drop ? d2 : min_drop;
+            slow |= !(d2 == d2);  // NaN coordinate
+        } else if (sp - T < DF) {
+            s_stack[sp - T][tid] = make_uint2(go_left ? right : cur + 1u, __float_as_uint(d2));
+        } else {
+            slow = true;
+        }
+        sp++;
+        cur = go_left ? cur + 1u : right;
+    }
+    live = !slow;
+    if (STAMP) t_mid = __builtin_amdgcn_s_memtime();
+
     while (live) {
+        if (STAMP) { n_trips++; n_visit += need_pop ? 0 : 1; n_pop += need_pop ? 1 : 0; }
         if (!need_pop) {  // ------------------------------------------------ VISIT one node
             const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(tree_rsrc, (int)(cur << 3), 0, 0);
             const uint32_t meta = w.y;
@@ -389,6 +423,10 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
             }
         }
         live = live && !slow;
+    }
+    if (STAMP) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        diag[0] = t_mid - t_begin; diag[1] = t_end - t_begin; diag[2] = n_trips; diag[3] = n_visit; diag[4] = n_pop;
     }
     return slow;
 }

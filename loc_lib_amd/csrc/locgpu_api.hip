@@ -6,6 +6,7 @@
 // reads back the small per-scan state every `kChunk` iterations.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -602,13 +603,19 @@ int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[2], int reset) {
     if (!ctx || !out) return LOCGPU_ERR_INVALID;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_search_stats) {
-        LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_search_stats, 2 * sizeof(unsigned long long)));
-        LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, 2 * sizeof(unsigned long long)));
+        LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_search_stats, 16 * sizeof(unsigned long long)));
+        LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, 16 * sizeof(unsigned long long)));
     }
     LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long h[2];
+    unsigned long long h[16];
     LOCGPU_HIP(ctx, hipMemcpy(h, ctx->d_search_stats, sizeof(h), hipMemcpyDeviceToHost));
     out[0] = h[0]; out[1] = h[1];
+    if (getenv("LOCGPU_STAMP") && h[12]) {  // diagnostic build only
+        const double q = (double)h[0], w = (double)h[12];
+        fprintf(stderr, "[locgpu stamp] per lane: descent %.0f cyc, total %.0f cyc, trips %.1f (visit %.1f, pop-only %.1f) | per wave (max over lanes): "
+                        "descent %.0f cyc, total %.0f cyc, trips %.1f (visit %.1f, pop %.1f)\n",
+                h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / w, h[8] / w, h[9] / w, h[10] / w, h[11] / w);
+    }
     if (reset) LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, sizeof(h)));
     return LOCGPU_OK;
 }
