@@ -77,13 +77,16 @@ typedef struct locgpu_ndt_opts {
     double eps;                /* 1e-2 */
     double res_outlier_th;     /* 20.0 */
     int32_t nearby_type;       /* 0 CENTER, 1 NEARBY6 (hpp:16-20) */
+    int32_t method;            /* 1 DIRECT_NDT (default), 2 INCREMENTAL_NDT (NdtMethod, hpp:21-26; 0 PCL_NDT is a no-op in the reference) */
+    int64_t capacity;          /* 100000: LRU voxel capacity of the incremental variant (capacity_, hpp:37) */
 } locgpu_ndt_opts;
 
 /* Per-scan result counters (the reference only logs these through glog). */
 typedef struct locgpu_align_stats {
     int32_t iterations;        /* Gauss–Newton iterations executed (H,B evaluations) */
     int32_t converged;         /* 1 if the loop left through |dx| < eps */
-    int32_t status;            /* 0 ok; 1 direct-NDT det(H)==0 ⇒ reference returns before writing result_pose (ndt cpp:435-436) */
+    int32_t status;            /* 0 ok; 1 direct-NDT det(H)==0 ⇒ reference returns before writing result_pose (ndt cpp:435-436);
+                                  2 incremental NDT: too few effective residuals ⇒ returns false with the current pose (ndt cpp:349-353) */
     int32_t reserved;
     int64_t last_effective_num;
     double last_dx_norm;
@@ -143,7 +146,10 @@ LOCGPU_API int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const doubl
 LOCGPU_API int locgpu_gn_update(const double hb[44], int method, int min_effective_pts, double eps, double pose[7], double dx[6],
                                 int* applied, int* stop);
 
-/* ---- NDT target: NdtRegistration::SetInputTarget → SetDirectNdtTargetCloud (ndt_registration.cpp:65-85, 87-148). */
+/* ---- NDT target: NdtRegistration::SetInputTarget → SetDirectNdtTargetCloud (ndt_registration.cpp:65-85, 87-148), or with
+ * opts->method == 2 → SetIncNdtTargetCloud (:150-183): the voxel set then PERSISTS across calls (LRU of opts->capacity voxels,
+ * statistics of a voxel recomputed from the points the latest call put into it); switching method, voxel_size or capacity,
+ * or a direct call, starts from an empty set. */
 LOCGPU_API int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, const locgpu_ndt_opts* opts);
 /* out[0]=voxels kept, out[1]=hash-table capacity, out[2]=bytes in HBM */
 LOCGPU_API int locgpu_ndt_target_info(const locgpu_ctx* ctx, int64_t out[3]);

@@ -19,6 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 P2P, P2LINE, P2PLANE = 0, 1, 2
 SEARCH_TREE_FAITHFUL, SEARCH_GRID_EXACT = 0, 1
 CENTER, NEARBY6 = 0, 1
+DIRECT_NDT, INCREMENTAL_NDT = 1, 2
 
 # every symbol include/locgpu.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -46,7 +47,7 @@ class IcpOpts(ctypes.Structure):
 class NdtOpts(ctypes.Structure):
     _fields_ = [("max_iteration", ctypes.c_int32), ("voxel_size", ctypes.c_double), ("min_effective_pts", ctypes.c_int32),
                 ("min_pts_in_voxel", ctypes.c_int32), ("eps", ctypes.c_double), ("res_outlier_th", ctypes.c_double),
-                ("nearby_type", ctypes.c_int32)]
+                ("nearby_type", ctypes.c_int32), ("method", ctypes.c_int32), ("capacity", ctypes.c_int64)]
 
 
 class AlignStats(ctypes.Structure):

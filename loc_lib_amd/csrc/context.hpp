@@ -10,6 +10,7 @@
 #include "icp_kernels.hpp"
 
 struct NdtTable;  // ndt_kernels.hpp
+namespace locgpu { struct IncNdtState; }  // ndt_inc.hpp
 
 struct locgpu_ctx {
     int device = 0;
@@ -23,6 +24,7 @@ struct locgpu_ctx {
 
     // NDT target
     NdtTable* ndt = nullptr;
+    locgpu::IncNdtState* inc = nullptr;  // incremental NDT voxel set (persists across set_target calls)
     locgpu_ndt_opts ndt_opts;
 
     // reusable one-scan batch for the single-scan entry points

@@ -426,6 +426,14 @@ __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restri
             return;
         }
         ok = eff >= prm.min_effective_pts;
+    } else if (prm.method == 4) {
+        // incremental NDT: too few accepted residuals ⇒ `result_pose = pose; return false` (ndt cpp:349-353); no det(H) test
+        ok = eff >= prm.min_effective_pts;
+        if (!ok) {
+            ps.status = 2; ps.done = 1; ps.iterations += 1; ps.last_eff = eff;
+            if (hb_out) { for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i]; for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i]; hb_out[44 * scan + 42] = (double)eff; hb_out[44 * scan + 43] = 0.0; }
+            return;
+        }
     } else {
         ok = (eff >= prm.min_effective_pts) && !(det == 0.0);
     }

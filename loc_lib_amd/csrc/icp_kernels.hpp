@@ -25,7 +25,7 @@ constexpr int kAccW = 32;          // doubles per block partial: 21 H (upper) + 
 constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
 
 struct GnParams {
-    int method;              // locgpu_icp_method, or 3 = direct NDT
+    int method;              // locgpu_icp_method, 3 = direct NDT, 4 = incremental NDT
     int max_iteration;
     int min_effective_pts;
     double eps;

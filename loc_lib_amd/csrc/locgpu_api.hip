@@ -76,6 +76,8 @@ void locgpu_ndt_opts_default(locgpu_ndt_opts* o) {
     o->eps = 1e-2;
     o->res_outlier_th = 20.0;
     o->nearby_type = 1;
+    o->method = 1;
+    o->capacity = 100000;
 }
 
 int locgpu_device_count(void) {
@@ -282,6 +284,7 @@ struct IterLauncher {
 
 }  // namespace locgpu
 
+#include "ndt_inc.hpp"
 #include "ndt_kernels.hpp"
 
 namespace locgpu {
@@ -306,7 +309,11 @@ bool IterLauncher::launch(int do_update) {
         launch_icp_accum(prm.method, aa, s);
     } else {
         mark();  // NDT has no separate search kernel: search slot stays empty
-        launch_ndt_accum(ctx->ndt, b->d_src, b->d_counts, b->d_state, b->max_n, b->n_scans, b->d_partials, s);
+        if (prm.method == 4)
+            launch_inc_accum(ctx->inc, ctx->ndt_opts.res_outlier_th, ctx->ndt_opts.nearby_type == 0 ? 1 : 7, b->d_src, b->d_counts, b->d_state,
+                             b->max_n, b->n_scans, b->d_partials, s);
+        else
+            launch_ndt_accum(ctx->ndt, b->d_src, b->d_counts, b->d_state, b->max_n, b->n_scans, b->d_partials, s);
     }
     mark();
     launch_gn_solve(b->d_partials, b->blocks_per_scan, b->d_state, b->n_scans, prm, do_update, b->d_hb, s);
@@ -339,7 +346,7 @@ static int run_align_graph(locgpu_ctx* ctx, locgpu_batch* b, const double* init_
                            double* out_poses, locgpu_align_stats* stats) {
     hipStream_t s = ctx->stream;
     init_states(b, init_poses);
-    const void* target = ndt ? (const void*)ctx->ndt->d_keys : (const void*)ctx->d_tree;
+    const void* target = !ndt ? (const void*)ctx->d_tree : (prm.method == 4 ? inc_ndt_table_ptr(ctx->inc) : (const void*)ctx->ndt->d_keys);
     const bool same = b->graph_exec && b->graph_k == k && b->graph_alpha == alpha_eff && b->graph_ndt == ndt && b->graph_target == target &&
                       std::memcmp(&b->graph_prm, &prm, sizeof(GnParams)) == 0;
     if (!same) {
@@ -650,11 +657,13 @@ int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset) {
 namespace locgpu {
 void ndt_free(locgpu_ctx* ctx) {
     if (ctx->ndt) { ndt_table_free(*ctx->ndt); delete ctx->ndt; ctx->ndt = nullptr; }
+    if (ctx->inc) { inc_ndt_destroy(ctx->inc); ctx->inc = nullptr; }
 }
 static int check_ndt(locgpu_ctx* ctx, GnParams& prm) {
     if (!ctx) return LOCGPU_ERR_INVALID;
-    if (!ctx->ndt) return fail(ctx, LOCGPU_ERR_NO_TARGET, "ndt: SetInputTarget has not been called");
-    prm.method = 3;
+    const bool inc = ctx->ndt_opts.method == 2;
+    if ((inc && !ctx->inc) || (!inc && !ctx->ndt)) return fail(ctx, LOCGPU_ERR_NO_TARGET, "ndt: SetInputTarget has not been called");
+    prm.method = inc ? 4 : 3;
     prm.max_iteration = ctx->ndt_opts.max_iteration;
     prm.min_effective_pts = ctx->ndt_opts.min_effective_pts;
     prm.eps = ctx->ndt_opts.eps;
@@ -670,7 +679,8 @@ int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
     if (!pts || n == 0 || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: empty cloud or stride < 12");
     locgpu_ndt_opts o;
     if (opts) o = *opts; else locgpu_ndt_opts_default(&o);
-    if (!(o.voxel_size > 0.0) || (o.nearby_type != 0 && o.nearby_type != 1)) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: bad options");
+    if (!(o.voxel_size > 0.0) || (o.nearby_type != 0 && o.nearby_type != 1) || (o.method != 1 && o.method != 2) || (o.method == 2 && o.capacity < 2))
+        return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: bad options");
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<float4> host(n);
     const char* base = (const char*)pts;
@@ -678,6 +688,22 @@ int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
     float4* d_pts = nullptr;
     LOCGPU_HIP(ctx, hipMalloc((void**)&d_pts, n * sizeof(float4)));
     if (!hip_ok(ctx, hipMemcpy(d_pts, host.data(), n * sizeof(float4), hipMemcpyHostToDevice), "H2D map")) { (void)hipFree(d_pts); return LOCGPU_ERR_NO_DEVICE; }
+    if (o.method == 2) {
+        // incremental: keep the voxel set unless the grid itself changed
+        if (ctx->inc && (ctx->ndt_opts.method != 2 || ctx->ndt_opts.voxel_size != o.voxel_size || ctx->ndt_opts.capacity != o.capacity)) {
+            inc_ndt_destroy(ctx->inc);
+            ctx->inc = nullptr;
+        }
+        if (!ctx->inc) ctx->inc = inc_ndt_create((size_t)o.capacity, o.voxel_size);
+        bool bad = false;
+        const hipError_t e = inc_ndt_ingest(*ctx->inc, host.data(), d_pts, n, ctx->stream, &bad);
+        (void)hipFree(d_pts);
+        if (e != hipSuccess) { hip_ok(ctx, e, "inc_ndt_ingest"); return LOCGPU_ERR_NO_DEVICE; }
+        ctx->ndt_opts = o;
+        if (bad) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: a point lies outside the +-2^20-voxel key range (it was skipped)");
+        return LOCGPU_OK;
+    }
+    if (ctx->inc) { inc_ndt_destroy(ctx->inc); ctx->inc = nullptr; }
     if (!ctx->ndt) ctx->ndt = new NdtTable();
     bool bad_key = false;
     const hipError_t e = ndt_build(*ctx->ndt, d_pts, n, o.voxel_size, o.min_pts_in_voxel, ctx->stream, &bad_key);
@@ -692,6 +718,7 @@ int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
 
 int locgpu_ndt_target_info(const locgpu_ctx* ctx, int64_t out[3]) {
     if (!ctx || !out) return LOCGPU_ERR_INVALID;
+    if (ctx->ndt_opts.method == 2 && ctx->inc) { out[0] = (int64_t)inc_ndt_num_voxels(ctx->inc); out[1] = ctx->ndt_opts.capacity; out[2] = 0; return LOCGPU_OK; }
     if (!ctx->ndt) { out[0] = out[1] = out[2] = 0; return LOCGPU_ERR_NO_TARGET; }
     out[0] = (int64_t)ctx->ndt->n_vox;
     out[1] = (int64_t)ctx->ndt->cap;
@@ -701,6 +728,12 @@ int locgpu_ndt_target_info(const locgpu_ctx* ctx, int64_t out[3]) {
 
 int locgpu_ndt_dump(locgpu_ctx* ctx, int32_t* keys, double* mu, double* info, size_t cap, size_t* n_out) {
     if (!ctx || !n_out) return LOCGPU_ERR_INVALID;
+    if (ctx->ndt_opts.method == 2 && ctx->inc) {
+        LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+        LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *n_out = inc_ndt_dump(ctx->inc, keys, mu, info, cap);
+        return LOCGPU_OK;
+    }
     if (!ctx->ndt) return fail(ctx, LOCGPU_ERR_NO_TARGET, "ndt_dump: no target");
     *n_out = ctx->ndt->n_vox;
     const size_t n = std::min(cap, ctx->ndt->n_vox);

@@ -1,6 +1,6 @@
 // Drop-in for LocUtils/include/LocUtils/model/matching/3d/ndt/ndt_registration.hpp: same enums, NdtOptions
-// (field for field) and virtuals. DIRECT_NDT runs in liblocgpu.so. PCL_NDT is a no-op in the reference too
-// (ndt_registration.cpp:69-70,246-247); INCREMENTAL_NDT is the next row of the scope table.
+// (field for field) and virtuals. DIRECT_NDT and INCREMENTAL_NDT run in liblocgpu.so. PCL_NDT is a no-op in the
+// reference too (ndt_registration.cpp:69-70,246-247).
 #pragma once
 #include <cstddef>
 #include <memory>

@@ -96,7 +96,7 @@ const char* NdtRegistration::LastError() const { return locgpu_last_error(ctx_);
 bool NdtRegistration::EnsureContext() { return ctx_ || locgpu_create(device_id_, &ctx_) == LOCGPU_OK; }
 
 bool NdtRegistration::SetInputTarget(const CloudPtr& input_target) {
-    if (options_.method_ != NdtMethod::DIRECT_NDT || !input_target || !EnsureContext()) return true;  // ndt cpp:67-83 always true
+    if (options_.method_ == NdtMethod::PCL_NDT || !input_target || !EnsureContext()) return true;  // ndt cpp:67-83 always true
     locgpu_ndt_opts o;
     locgpu_ndt_opts_default(&o);
     o.max_iteration = options_.max_iteration_;
@@ -106,6 +106,8 @@ bool NdtRegistration::SetInputTarget(const CloudPtr& input_target) {
     o.eps = options_.eps_;
     o.res_outlier_th = options_.res_outlier_th_;
     o.nearby_type = options_.nearby_type_ == NdtNearbyType::CENTER ? 0 : 1;
+    o.method = options_.method_ == NdtMethod::INCREMENTAL_NDT ? 2 : 1;
+    o.capacity = (int64_t)options_.capacity_;
     has_target_ = locgpu_ndt_set_target(ctx_, input_target->points.data(), input_target->points.size(), sizeof(PointType), &o) == LOCGPU_OK;
     return true;
 }
@@ -114,11 +116,11 @@ bool NdtRegistration::CaculateMatrixHAndB(const CloudPtr&, const SE3&, Mat6d&, V
 
 bool NdtRegistration::ScanMatch(const CloudPtr& input_source, const SE3& predict_pose, CloudPtr& result_cloud_ptr, SE3& result_pose) {
     if (!input_source) return true;
-    if (has_target_ && options_.method_ == NdtMethod::DIRECT_NDT && !input_source->points.empty()) {
+    if (has_target_ && options_.method_ != NdtMethod::PCL_NDT && !input_source->points.empty()) {
         double out[7];
         locgpu_align_stats st;
         if (locgpu_ndt_align(ctx_, input_source->points.data(), input_source->points.size(), sizeof(PointType), predict_pose.data(), out, &st) ==
-                LOCGPU_OK && st.status == 0)
+                LOCGPU_OK && st.status != 1)  // status 2 (incremental, too few residuals): result_pose = current pose (ndt cpp:351)
             std::memcpy(result_pose.data(), out, sizeof(out));
         // st.status == 1: det(H)==0 ⇒ AlignNdt returned before assigning result_pose (ndt cpp:435-436): leave it as the caller had it
     }

@@ -250,6 +250,59 @@ def test_ndt_negative_coordinates_truncate_toward_zero(gpu_ctx, locref):
     assert len(kg) == len(ko) == 1 and tuple(kg[0]) == (0, 0, 0)
 
 
+# ----------------------------------------------------------------------------------------------- incremental NDT
+def _world_scan(locref, synth, sid, n):
+    """Scan `sid` expressed in the world frame with its true pose (what Lio feeds the matcher after a keyframe)."""
+    s = synth.make_scan(sid, subsample=n, crop_half=36.0)
+    true_pose, _ = synth.make_pose(sid)
+    return locref.transform_cloud_f32(true_pose, s)
+
+
+@pytest.mark.parametrize("capacity", [100000, 700])
+def test_incremental_ndt_matches_oracle(gpu_ctx, api, locref, synth, small_world, capacity):
+    """SetIncNdtTargetCloud called three times (voxel set persists, LRU eviction when capacity is small), then AlignIncNdt."""
+    clouds = [small_world["map"][::4], _world_scan(locref, synth, 3, 6000), _world_scan(locref, synth, 4, 5000)]
+    opts = api.ndt_opts(method=api.INCREMENTAL_NDT, capacity=capacity)
+    ndt = locref.Ndt(method=locref.INCREMENTAL_NDT, capacity=capacity)
+    gpu_ctx.ndt_set_target(clouds[0][:10], api.ndt_opts())  # a direct call in between resets the incremental set
+    for c in clouds:
+        gpu_ctx.ndt_set_target(c, opts)
+        ndt.set_target(c)
+        assert gpu_ctx.ndt_target_info()["num_voxels"] == ndt.num_voxels()
+    if capacity == 700:
+        assert ndt.num_voxels() < 700  # evictions happened
+    kg, mug, ig = gpu_ctx.ndt_dump()
+    ko, muo, io = ndt.dump()
+    og, oo = np.lexsort(kg.T[::-1]), np.lexsort(ko.T[::-1])
+    np.testing.assert_array_equal(kg[og], ko[oo])
+    np.testing.assert_allclose(mug[og], muo[oo], rtol=0, atol=1e-9)
+    scale = np.abs(io[oo]).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(ig[og] - io[oo]) / scale).max() < 1e-7
+    s, init = small_world["scan10k"], small_world["init_pose"]
+    ro = ndt.align(s, init)
+    pg, st = gpu_ctx.ndt_align(s, init)
+    assert st["status"] == ro["status"] and st["iterations"] == ro["iters"]
+    dt, dr = pose_delta(pg, ro["pose"])
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+
+
+def test_incremental_ndt_too_few_residuals(gpu_ctx, api, locref):
+    """effective_num < min_effective_pts ⇒ AlignIncNdt returns false with result = current pose (ndt cpp:349-353)."""
+    rng = np.random.RandomState(3)
+    m = (rng.rand(50, 3) * 2).astype(np.float32)
+    far = (rng.rand(30, 3) * 2 + 500).astype(np.float32)
+    opts = api.ndt_opts(method=api.INCREMENTAL_NDT)
+    gpu_ctx.ndt_set_target(m[:5], api.ndt_opts())
+    gpu_ctx.ndt_set_target(m, opts)
+    ndt = locref.Ndt(method=locref.INCREMENTAL_NDT)
+    ndt.set_target(m)
+    init = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    ro = ndt.align(far, init)
+    pg, st = gpu_ctx.ndt_align(far, init)
+    assert ro["status"] == 2 and st["status"] == 2 and st["iterations"] == ro["iters"] == 1
+    np.testing.assert_array_equal(pg, init)
+
+
 # ----------------------------------------------------------------------------------------------- hipGraph mode
 def test_graph_mode_equals_eager(gpu_ctx, api, synth, small_world):
     """Captured hipGraph of all GN iterations (device-side early-outs) == the eager data-dependent loop, bit for bit;
