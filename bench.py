@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--method", choices=["p2plane", "p2line", "p2p", "ndt"], default="p2plane",
                     help="matcher to time; the headline metric is p2plane (others are reported for DESIGN.md tables)")
     ap.add_argument("--map-points", type=int, default=10_000_000)
+    ap.add_argument("--search", choices=["tree", "tree_exact", "grid"], default="tree",
+                    help="tree = the reference's default alpha=0.1 approximate KD-tree search (headline); tree_exact / grid = "
+                         "SetEnableANN(false) semantics through the tree or through the exact cell grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -118,6 +121,10 @@ def main():
     batch = ctx.batch(scans)
     method = dict(p2plane=api.P2PLANE, p2line=api.P2LINE, p2p=api.P2P, ndt=-1)[args.method]
     opts = api.icp_opts(method=max(method, 0))  # every other field = reference default
+    if args.search == "grid":
+        opts.search_mode = api.SEARCH_GRID_EXACT
+    elif args.search == "tree_exact":
+        opts.approximate = 0
     if method < 0:
         t0 = time.time()
         ctx.ndt_set_target(map_xyz)           # NdtOptions defaults: voxel 1.0, NEARBY6, DIRECT_NDT
@@ -165,6 +172,10 @@ def main():
         k = 1 if args.method == "p2p" else 5
         q = vc["queries"] if method >= 0 else sum(s["iterations"] for s in stats) * 115200
         search_bytes = q * 16 + vc["nodes"] * 16 + q * 4 * k            # src float4 + one 16-B slot pair per node visit + index lists
+        if args.search == "grid":
+            # SURVEY §8(d) exact/grid formula: 16·N_cand + N_q·(12 + 4k); N_cand (distinct leaves in the cells any query's final
+            # search block touches) is bounded below by the leaves the queries actually return: use k·q/4 as a conservative stand-in
+            search_bytes = q * (16 + 4 * k) + 16 * (k * q // 4)
         accum_bytes = q * (16 + 4 * k + 16 * k) + gn_iters * 29 * 8      # src + indices + 5 gathered leaves; partial sums negligible
         if method < 0:
             nv = ctx.ndt_target_info()["num_voxels"]
@@ -173,7 +184,7 @@ def main():
         t_accum = prof["accum_ms"] * prof["accum_n"] / args.steps
         t_solve = prof["solve_ms"] * prof["solve_n"] / args.steps
         if t_search >= t_accum:
-            kname, kbytes, kt, kn, kavg = "icp_search_fast_kernel(+redo)", search_bytes, t_search, prof["search_n"], prof["search_ms"]
+            kname, kbytes, kt, kn, kavg = ("icp_search_grid_kernel(+pass2+redo)" if args.search == "grid" else "icp_search_fast_kernel(+redo)"), search_bytes, t_search, prof["search_n"], prof["search_ms"]
         else:
             kname, kbytes, kt, kn, kavg = ("ndt_accum_kernel" if method < 0 else "icp_%s_accum_kernel" % args.method), accum_bytes, t_accum, prof["accum_n"], prof["accum_ms"]
         launches_per_step = kn / args.steps
@@ -190,7 +201,7 @@ def main():
                     config=dict(workload="BASELINE configs[2]: %d scans/GPU x 115200 pts (64x1800, cityblock-v1) vs one %d-pt map, "
                                          "%s, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), scans sharded by rank, no collective"
                                          % (B, args.map_points, "direct NDT (voxel 1.0, NEARBY6)" if method < 0 else args.method.upper() + " ICP"),
-                                scans_per_gpu=B, map_points=args.map_points, search_mode="tree_faithful", tree_depth=tinfo["depth"],
+                                scans_per_gpu=B, map_points=args.map_points, search_mode=dict(tree="tree_faithful_ann", tree_exact="tree_faithful_exact", grid="grid_exact")[args.search], tree_depth=tinfo["depth"],
                                 tree_bytes=tinfo["bytes"]),
                     icp_iter_ms=round((t_search + t_accum + t_solve) / max(prof["search_n"] / args.steps, 1), 5),
                     icp_iter_ms_per_scan=round((t_search + t_accum + t_solve) * args.steps / max(gn_iters, 1), 6),
@@ -199,7 +210,7 @@ def main():
                     median_translation_error_to_truth_m=round(err_t, 4),
                     setup_s=dict(map_gen=round(t_map, 2), tree_ingest=round(t_ingest, 2)),
                     roofline=roofline)
-        if world == 1 and not args.no_cpu_baseline and args.method == "p2plane":
+        if world == 1 and not args.no_cpu_baseline and args.method == "p2plane" and args.search == "tree":
             cb, cpu_poses = cpu_baseline(map_xyz, scans, inits, args.cpu_seconds)
             n = len(cpu_poses)
             d = np.linalg.norm(np.stack(cpu_poses)[:, 4:] - out_poses[:n, 4:], axis=1)

@@ -7,6 +7,7 @@
 
 #include "../../include/locgpu.h"
 #include "device_math.hpp"
+#include "grid_kernels.hpp"
 #include "icp_kernels.hpp"
 
 struct NdtTable;  // ndt_kernels.hpp
@@ -21,6 +22,12 @@ struct locgpu_ctx {
     uint2* d_tree = nullptr;
     size_t tree_slots = 0, num_leaves = 0, num_nodes = 0, num_points = 0;
     int depth = 0;
+    unsigned long long target_epoch = 0;  // bumped by every set_target: captured graphs of older targets are never replayed
+
+    // exact-search grid over the tree's leaves (built on first use of LOCGPU_SEARCH_GRID_EXACT)
+    locgpu::GridView grid;
+    uint32_t* d_cell_start = nullptr;
+    float4* d_grid_pts = nullptr;
 
     // NDT target
     NdtTable* ndt = nullptr;
@@ -53,7 +60,8 @@ struct locgpu_batch {
     double* d_partials = nullptr;  // [n_scans][blocks_per_scan][kAccW]
     double* d_hb = nullptr;        // [n_scans][44]
     uint32_t* d_redo_list = nullptr;      // [pitch]
-    unsigned int* d_redo_count = nullptr;
+    unsigned int* d_redo_count = nullptr;  // [2]: the two lists' counters
+    uint32_t* d_redo_list2 = nullptr;      // [pitch], allocated on first use of the grid search
     // hipGraph of {H2D state, max_iteration × (search, fit+accumulate, solve), D2H state}, keyed by the launch parameters
     hipGraphExec_t graph_exec = nullptr;
     locgpu::GnParams graph_prm{};
@@ -61,6 +69,7 @@ struct locgpu_batch {
     float graph_alpha = 0.f;
     bool graph_ndt = false;
     const void* graph_target = nullptr;  // tree / NDT table the capture was made against
+    unsigned long long graph_epoch = 0;
     locgpu::PoseState* h_state = nullptr;  // pinned
     double* h_hb = nullptr;                // pinned
     std::vector<int> counts;

@@ -577,6 +577,23 @@ static bool launch_fast_k(const SearchArgs& a, hipStream_t s) {
     return true;
 }
 
+template <int K>
+static bool launch_redo_k(const SearchArgs& a, hipStream_t s) {
+#define LOCGPU_REDO(D) hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(512), dim3(kBlock), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k, \
+                                          a.alpha_eff, a.redo_list, a.redo_count, a.search_stats)
+    if (a.depth <= 32) LOCGPU_REDO(32);
+    else if (a.depth <= 40) LOCGPU_REDO(40);
+    else if (a.depth <= 64) LOCGPU_REDO(64);
+    else return false;
+#undef LOCGPU_REDO
+    return true;
+}
+bool launch_icp_search_redo(const SearchArgs& a, hipStream_t s) {
+    if (a.k == 1) return launch_redo_k<1>(a, s);
+    if (a.k == 5) return launch_redo_k<5>(a, s);
+    return false;
+}
+
 bool launch_icp_search(const SearchArgs& a, hipStream_t s) {
     // Instrumented (visit-counting) runs and LOCGPU_SEARCH_VARIANT experiments use the exact one-pass kernel.
     const bool exact_only = a.visit_totals != nullptr || search_variant() != 0 || !a.redo_list;

@@ -24,6 +24,8 @@ struct SearchArgs {
     unsigned long long* visit_totals;  // null unless visit counting is on
     uint32_t* redo_list;               // [n_scans*max_n] queries the fast kernel hands to the exact kernel
     unsigned int* redo_count;
+    uint32_t* redo_list2;              // grid mode: first pass → second pass
+    unsigned int* redo_count2;
     unsigned long long* search_stats;  // [2] cumulative: queries searched, queries redone exactly (may be null)
 };
 
@@ -40,6 +42,8 @@ struct AccumArgs {
 };
 
 bool launch_icp_search(const SearchArgs& a, hipStream_t s);
+// exact tree traversal over a.redo_list only (the list is filled by a preceding fast / grid kernel)
+bool launch_icp_search_redo(const SearchArgs& a, hipStream_t s);
 bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, int k, float alpha_eff, int32_t* out, uint32_t* visits,
                       hipStream_t s);
 void launch_icp_accum(int method, const AccumArgs& a, hipStream_t s);

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "context.hpp"
+#include "grid_build.hpp"
 #include "kdtree_build.hpp"
 #include "launch.hpp"
 
@@ -35,6 +36,43 @@ bool hip_ok(locgpu_ctx* ctx, hipError_t e, const char* what) {
 }
 }  // namespace locgpu
 
+static void free_grid(locgpu_ctx* ctx) {
+    if (ctx->d_cell_start) (void)hipFree(ctx->d_cell_start);
+    if (ctx->d_grid_pts) (void)hipFree(ctx->d_grid_pts);
+    ctx->d_cell_start = nullptr;
+    ctx->d_grid_pts = nullptr;
+    ctx->grid = locgpu::GridView();
+}
+
+// Build the exact-search grid from the packed tree already in HBM (first use of LOCGPU_SEARCH_GRID_EXACT after a set_target).
+static int ensure_grid(locgpu_ctx* ctx) {
+    if (ctx->grid.pts) return LOCGPU_OK;
+    std::vector<uint64_t> slots(ctx->tree_slots);
+    LOCGPU_HIP(ctx, hipMemcpy(slots.data(), ctx->d_tree, slots.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    locgpu::SearchGrid g;
+    std::string err;
+    if (!locgpu::build_search_grid(slots.data(), slots.size(), g, err)) return locgpu::fail(ctx, LOCGPU_ERR_INVALID, "grid search: " + err);
+    LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_cell_start, g.cell_start.size() * sizeof(uint32_t)));
+    LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_grid_pts, g.num_points * sizeof(float4)));
+    LOCGPU_HIP(ctx, hipMemcpy(ctx->d_cell_start, g.cell_start.data(), g.cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    LOCGPU_HIP(ctx, hipMemcpy(ctx->d_grid_pts, g.points.data(), g.num_points * sizeof(float4), hipMemcpyHostToDevice));
+    locgpu::GridView& v = ctx->grid;
+    v.cell_start = ctx->d_cell_start;
+    v.pts = ctx->d_grid_pts;
+    float max_abs = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        v.dims[a] = g.dims[a];
+        v.origin[a] = g.origin[a];
+        max_abs = std::max(max_abs, std::max(std::fabs(g.origin[a]), std::fabs(g.origin[a] + g.dims[a] * g.cell)));
+    }
+    v.cell = g.cell;
+    v.inv_cell = g.inv_cell;
+    v.slack = 1e-3f * g.cell + 16.f * 1.2e-7f * max_abs;  // float32 rounding of the point→cell assignment and of the face positions
+    v.num_points = g.num_points;
+    v.bytes = g.cell_start.size() * sizeof(uint32_t) + g.num_points * sizeof(float4);
+    return LOCGPU_OK;
+}
+
 static void free_batch(locgpu_batch* b) {
     if (!b) return;
     if (b->d_src) (void)hipFree(b->d_src);
@@ -45,6 +83,7 @@ static void free_batch(locgpu_batch* b) {
     if (b->d_hb) (void)hipFree(b->d_hb);
     if (b->d_redo_list) (void)hipFree(b->d_redo_list);
     if (b->d_redo_count) (void)hipFree(b->d_redo_count);
+    if (b->d_redo_list2) (void)hipFree(b->d_redo_list2);
     if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
     if (b->h_state) (void)hipHostFree(b->h_state);
     if (b->h_hb) (void)hipHostFree(b->h_hb);
@@ -112,6 +151,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_batch(ctx->single);
     if (ctx->d_tree) (void)hipFree(ctx->d_tree);
+    free_grid(ctx);
     if (ctx->d_visits) (void)hipFree(ctx->d_visits);
     if (ctx->d_search_stats) (void)hipFree(ctx->d_search_stats);
     ndt_free(ctx);
@@ -136,6 +176,7 @@ int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
     if (!build_packed_kdtree(xyz.data(), n, t, err)) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: " + err);
     if (t.depth > 64) return fail(ctx, LOCGPU_ERR_DEPTH, "icp_set_target: KD-tree depth " + std::to_string(t.depth) + " exceeds the 64-entry traversal stack");
     if (ctx->d_tree) { LOCGPU_HIP(ctx, hipFree(ctx->d_tree)); ctx->d_tree = nullptr; }
+    free_grid(ctx);
     LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_tree, t.slots.size() * sizeof(uint64_t)));
     LOCGPU_HIP(ctx, hipMemcpy(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     ctx->tree_slots = t.slots.size();
@@ -143,6 +184,7 @@ int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
     ctx->num_nodes = t.num_nodes;
     ctx->num_points = t.num_points;
     ctx->depth = t.depth;
+    ctx->target_epoch++;
     return LOCGPU_OK;
 }
 
@@ -161,27 +203,59 @@ int locgpu_knn(locgpu_ctx* ctx, const float* queries, size_t nq, int k, int appr
     if (!ctx) return LOCGPU_ERR_INVALID;
     if (!ctx->d_tree) return fail(ctx, LOCGPU_ERR_NO_TARGET, "knn: no target set");
     if (!queries || !out_idx || k < 1 || k > 8) return fail(ctx, LOCGPU_ERR_INVALID, "knn: bad arguments (1 <= k <= 8)");
-    if (search_mode != LOCGPU_SEARCH_TREE_FAITHFUL) return fail(ctx, LOCGPU_ERR_INVALID, "knn: search mode not available");
+    if (search_mode != LOCGPU_SEARCH_TREE_FAITHFUL && search_mode != LOCGPU_SEARCH_GRID_EXACT) return fail(ctx, LOCGPU_ERR_INVALID, "knn: unknown search mode");
     if ((size_t)k > ctx->num_leaves) return fail(ctx, LOCGPU_ERR_K_TOO_LARGE, "knn: k larger than the number of tree leaves");
     if (nq == 0) return LOCGPU_OK;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    const bool grid = search_mode == LOCGPU_SEARCH_GRID_EXACT;
+    if (grid) {
+        if (k != 1 && k != 5) return fail(ctx, LOCGPU_ERR_INVALID, "knn: grid search supports k = 1 or 5");
+        const int grc = ensure_grid(ctx);
+        if (grc != LOCGPU_OK) return grc;
+    }
     float* d_q = nullptr;
     int32_t* d_out = nullptr;
     uint32_t* d_vis = nullptr;
+    unsigned int* d_flag = nullptr;
     int rc = LOCGPU_OK;
-    auto cleanup = [&]() { if (d_q) (void)hipFree(d_q); if (d_out) (void)hipFree(d_out); if (d_vis) (void)hipFree(d_vis); };
+    auto cleanup = [&]() { if (d_q) (void)hipFree(d_q); if (d_out) (void)hipFree(d_out); if (d_vis) (void)hipFree(d_vis); if (d_flag) (void)hipFree(d_flag); };
     if (!hip_ok(ctx, hipMalloc((void**)&d_q, nq * 12), "hipMalloc") || !hip_ok(ctx, hipMalloc((void**)&d_out, nq * k * 4), "hipMalloc") ||
-        (visits && !hip_ok(ctx, hipMalloc((void**)&d_vis, nq * 8), "hipMalloc"))) {
+        !hip_ok(ctx, hipMalloc((void**)&d_flag, 4), "hipMalloc") || (visits && !hip_ok(ctx, hipMalloc((void**)&d_vis, nq * 8), "hipMalloc"))) {
         cleanup();
         return LOCGPU_ERR_OOM;
     }
-    if (!hip_ok(ctx, hipMemcpyAsync(d_q, queries, nq * 12, hipMemcpyHostToDevice, ctx->stream), "H2D")) rc = LOCGPU_ERR_NO_DEVICE;
-    if (rc == LOCGPU_OK && !launch_knn_query(ctx->d_tree, ctx->depth, d_q, nq, k, approximate ? alpha : 1.0f, d_out, d_vis, ctx->stream))
+    hipStream_t s = ctx->stream;
+    if (!hip_ok(ctx, hipMemcpyAsync(d_q, queries, nq * 12, hipMemcpyHostToDevice, s), "H2D")) rc = LOCGPU_ERR_NO_DEVICE;
+    if (rc == LOCGPU_OK && grid) {
+        // grid kernel first; the queries it cannot settle (out_idx[i*k] == -2) are answered by the exact tree traversal
+        unsigned int flagged = 0;
+        (void)hipMemsetAsync(d_flag, 0, 4, s);
+        if (!launch_knn_grid_query(ctx->grid, ctx->d_tree, d_q, nq, k, d_out, d_flag, s)) rc = fail(ctx, LOCGPU_ERR_INVALID, "knn: unsupported k");
+        if (rc == LOCGPU_OK && (!hip_ok(ctx, hipMemcpyAsync(out_idx, d_out, nq * k * 4, hipMemcpyDeviceToHost, s), "D2H") ||
+                                !hip_ok(ctx, hipMemcpyAsync(&flagged, d_flag, 4, hipMemcpyDeviceToHost, s), "D2H") ||
+                                !hip_ok(ctx, hipStreamSynchronize(s), "sync")))
+            rc = LOCGPU_ERR_NO_DEVICE;
+        if (rc == LOCGPU_OK && visits) std::memset(visits, 0, nq * 8);
+        if (rc == LOCGPU_OK && flagged) {
+            std::vector<int32_t> tmp(nq * k);
+            if (!launch_knn_query(ctx->d_tree, ctx->depth, d_q, nq, k, 1.0f, d_out, nullptr, s)) rc = fail(ctx, LOCGPU_ERR_DEPTH, "knn: unsupported k/depth");
+            if (rc == LOCGPU_OK && (!hip_ok(ctx, hipMemcpyAsync(tmp.data(), d_out, nq * k * 4, hipMemcpyDeviceToHost, s), "D2H") ||
+                                    !hip_ok(ctx, hipStreamSynchronize(s), "sync")))
+                rc = LOCGPU_ERR_NO_DEVICE;
+            if (rc == LOCGPU_OK)
+                for (size_t i = 0; i < nq; ++i)
+                    if (out_idx[i * k] == -2)
+                        for (int j = 0; j < k; ++j) out_idx[i * k + j] = tmp[i * k + j];
+        }
+        cleanup();
+        return rc;
+    }
+    if (rc == LOCGPU_OK && !launch_knn_query(ctx->d_tree, ctx->depth, d_q, nq, k, approximate ? alpha : 1.0f, d_out, d_vis, s))
         rc = fail(ctx, LOCGPU_ERR_DEPTH, "knn: unsupported k/depth");
     if (rc == LOCGPU_OK && !hip_ok(ctx, hipGetLastError(), "knn launch")) rc = LOCGPU_ERR_NO_DEVICE;
-    if (rc == LOCGPU_OK && !hip_ok(ctx, hipMemcpyAsync(out_idx, d_out, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream), "D2H")) rc = LOCGPU_ERR_NO_DEVICE;
-    if (rc == LOCGPU_OK && visits && !hip_ok(ctx, hipMemcpyAsync(visits, d_vis, nq * 8, hipMemcpyDeviceToHost, ctx->stream), "D2H")) rc = LOCGPU_ERR_NO_DEVICE;
-    if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync") && rc == LOCGPU_OK) rc = LOCGPU_ERR_NO_DEVICE;
+    if (rc == LOCGPU_OK && !hip_ok(ctx, hipMemcpyAsync(out_idx, d_out, nq * k * 4, hipMemcpyDeviceToHost, s), "D2H")) rc = LOCGPU_ERR_NO_DEVICE;
+    if (rc == LOCGPU_OK && visits && !hip_ok(ctx, hipMemcpyAsync(visits, d_vis, nq * 8, hipMemcpyDeviceToHost, s), "D2H")) rc = LOCGPU_ERR_NO_DEVICE;
+    if (!hip_ok(ctx, hipStreamSynchronize(s), "sync") && rc == LOCGPU_OK) rc = LOCGPU_ERR_NO_DEVICE;
     cleanup();
     return rc;
 }
@@ -212,7 +286,7 @@ static int make_batch(locgpu_ctx* ctx, const void* const* srcs, const size_t* co
               hip_ok(ctx, hipMalloc((void**)&b->d_partials, (size_t)n_scans * b->blocks_per_scan * kAccW * sizeof(double)), "hipMalloc partials") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_hb, (size_t)n_scans * 44 * sizeof(double)), "hipMalloc hb") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_list, b->pitch * sizeof(uint32_t)), "hipMalloc redo") &&
-              hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, sizeof(unsigned int)), "hipMalloc redo") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, 2 * sizeof(unsigned int)), "hipMalloc redo") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_scans * sizeof(PoseState)), "hipHostMalloc state") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_scans * 44 * sizeof(double)), "hipHostMalloc hb");
     if (!ok) { free_batch(b); return LOCGPU_ERR_OOM; }
@@ -301,8 +375,13 @@ bool IterLauncher::launch(int do_update) {
     if (!ndt) {
         SearchArgs sa{ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ctx->depth, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, k, alpha_eff,
                       prm.method == LOCGPU_P2P ? 1 : 0, ctx->count_visits ? ctx->d_visits : nullptr, b->d_redo_list, b->d_redo_count,
-                      ctx->d_search_stats};
-        if (!launch_icp_search(sa, s)) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
+                      b->d_redo_list2, b->d_redo_count + 1, ctx->d_search_stats};
+        const bool grid_mode = alpha_eff < 0.f;
+        if (grid_mode && !b->d_redo_list2 && !hip_ok(ctx, hipMalloc((void**)&b->d_redo_list2, b->pitch * sizeof(uint32_t)), "hipMalloc redo2")) return false;
+        sa.redo_list2 = b->d_redo_list2;
+        if (grid_mode) sa.alpha_eff = 1.0f;  // the tree kernel that settles the grid's leftovers runs the exact pruning rule
+        const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, s) : launch_icp_search(sa, s);
+        if (!ok_search) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
         mark();
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
         AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
@@ -348,6 +427,7 @@ static int run_align_graph(locgpu_ctx* ctx, locgpu_batch* b, const double* init_
     init_states(b, init_poses);
     const void* target = !ndt ? (const void*)ctx->d_tree : (prm.method == 4 ? inc_ndt_table_ptr(ctx->inc) : (const void*)ctx->ndt->d_keys);
     const bool same = b->graph_exec && b->graph_k == k && b->graph_alpha == alpha_eff && b->graph_ndt == ndt && b->graph_target == target &&
+                      b->graph_epoch == ctx->target_epoch &&
                       std::memcmp(&b->graph_prm, &prm, sizeof(GnParams)) == 0;
     if (!same) {
         if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
@@ -365,6 +445,7 @@ static int run_align_graph(locgpu_ctx* ctx, locgpu_batch* b, const double* init_
         (void)hipGraphDestroy(graph);
         if (!inst) { b->graph_exec = nullptr; return LOCGPU_ERR_NO_DEVICE; }
         b->graph_prm = prm; b->graph_k = k; b->graph_alpha = alpha_eff; b->graph_ndt = ndt; b->graph_target = target;
+        b->graph_epoch = ctx->target_epoch;
     }
     LOCGPU_HIP(ctx, hipGraphLaunch(b->graph_exec, s));
     LOCGPU_HIP(ctx, hipStreamSynchronize(s));
@@ -425,7 +506,12 @@ static int check_icp(locgpu_ctx* ctx, const locgpu_icp_opts* o, GnParams& prm, i
     if (!o) return fail(ctx, LOCGPU_ERR_INVALID, "icp: opts is NULL");
     if (!ctx->d_tree) return fail(ctx, LOCGPU_ERR_NO_TARGET, "icp: SetInputTarget has not been called");
     if (o->method < LOCGPU_P2P || o->method > LOCGPU_P2PLANE) return fail(ctx, LOCGPU_ERR_INVALID, "icp: unknown method");
-    if (o->search_mode != LOCGPU_SEARCH_TREE_FAITHFUL) return fail(ctx, LOCGPU_ERR_INVALID, "icp: search mode not available in this build");
+    if (o->search_mode != LOCGPU_SEARCH_TREE_FAITHFUL && o->search_mode != LOCGPU_SEARCH_GRID_EXACT)
+        return fail(ctx, LOCGPU_ERR_INVALID, "icp: unknown search mode");
+    if (o->search_mode == LOCGPU_SEARCH_GRID_EXACT) {
+        const int rc = ensure_grid(ctx);
+        if (rc != LOCGPU_OK) return rc;
+    }
     prm.method = o->method;
     prm.max_iteration = o->max_iteration;
     prm.min_effective_pts = o->min_effective_pts;
@@ -435,6 +521,7 @@ static int check_icp(locgpu_ctx* ctx, const locgpu_icp_opts* o, GnParams& prm, i
     prm.max_line_distance = o->max_line_distance;
     k = o->method == LOCGPU_P2P ? 1 : 5;
     alpha_eff = o->approximate ? o->ann_alpha : 1.0f;
+    if (o->search_mode == LOCGPU_SEARCH_GRID_EXACT) alpha_eff = -1.0f;  // marker: grid search (exact by construction; `approximate` is ignored)
     // k > size_: GetClosestPoint logs an error and returns nothing (kdtree.cpp:149-153) ⇒ no correspondences at all.
     // The search kernel reproduces that by never filling the k-th slot; nothing to reject here.
     return LOCGPU_OK;
@@ -700,6 +787,7 @@ int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
         (void)hipFree(d_pts);
         if (e != hipSuccess) { hip_ok(ctx, e, "inc_ndt_ingest"); return LOCGPU_ERR_NO_DEVICE; }
         ctx->ndt_opts = o;
+        ctx->target_epoch++;
         if (bad) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: a point lies outside the +-2^20-voxel key range (it was skipped)");
         return LOCGPU_OK;
     }
@@ -713,6 +801,7 @@ int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
     ctx->ndt->res_outlier_th = o.res_outlier_th;
     ctx->ndt->n_nearby = o.nearby_type == 0 ? 1 : 7;
     ctx->ndt_opts = o;
+    ctx->target_epoch++;
     return LOCGPU_OK;
 }
 

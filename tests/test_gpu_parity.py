@@ -250,6 +250,73 @@ def test_ndt_negative_coordinates_truncate_toward_zero(gpu_ctx, locref):
     assert len(kg) == len(ko) == 1 and tuple(kg[0]) == (0, 0, 0)
 
 
+# ----------------------------------------------------------------------------------------------- exact grid search
+def _knn_equal_up_to_ties(got, ref, q, pts):
+    """Same index lists, except where float32 distances tie exactly (then the distances must still agree position by position)."""
+    same = np.all(got == ref, axis=1)
+    if same.all():
+        return 0
+    bad = np.where(~same)[0]
+
+    def d2(idx):
+        d = q[bad, None, :] - pts[idx[bad]]
+        d = d.astype(np.float32)
+        return d[..., 0] * d[..., 0] + (d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2])
+    np.testing.assert_array_equal(d2(got), d2(ref))
+    return len(bad)
+
+
+@pytest.mark.parametrize("k", [1, 5])
+def test_grid_knn_equals_exact_tree(gpu_ctx, api, locref, small_world, k):
+    m = small_world["map"]
+    rng = np.random.RandomState(200 + k)
+    near = (m[rng.choice(len(m), 6000, replace=False), :3] + rng.randn(6000, 3).astype(np.float32) * 0.08).astype(np.float32)
+    sparse = (m[rng.choice(len(m), 500, replace=False), :3] + rng.randn(500, 3).astype(np.float32) * 3.0).astype(np.float32)  # several rings
+    far = (rng.rand(100, 3).astype(np.float32) - 0.5) * 2000                                                                    # tree fallback
+    q = np.vstack([near, sparse, far]).astype(np.float32)
+    gpu_ctx.icp_set_target(m)
+    tree = locref.KdTree(m)
+    got = gpu_ctx.knn(q, k=k, search_mode=api.SEARCH_GRID_EXACT)
+    ref = tree.knn(q, k=k, approximate=False)
+    n_tied = _knn_equal_up_to_ties(got, ref, q, m[:, :3])
+    assert n_tied <= 2
+
+
+def test_grid_knn_duplicates_and_tiny(gpu_ctx, api, locref):
+    pts = np.random.RandomState(5).rand(400, 3).astype(np.float32)
+    pts[10:60] = pts[10]  # dropped by the tree's degenerate-leaf rule ⇒ absent from the grid too
+    gpu_ctx.icp_set_target(pts)
+    tree = locref.KdTree(pts)
+    q = np.random.RandomState(6).rand(300, 3).astype(np.float32)
+    got = gpu_ctx.knn(q, k=5, search_mode=api.SEARCH_GRID_EXACT)
+    assert _knn_equal_up_to_ties(got, tree.knn(q, k=5, approximate=False), q, pts) == 0
+    gpu_ctx.icp_set_target(pts[:7])
+    tree = locref.KdTree(pts[:7])
+    np.testing.assert_array_equal(gpu_ctx.knn(q, k=5, search_mode=api.SEARCH_GRID_EXACT), tree.knn(q, k=5, approximate=False))
+
+
+@pytest.mark.parametrize("method", [2, 0, 1])
+def test_icp_grid_mode_matches_exact_oracle(gpu_ctx, api, locref, small_world, method):
+    """search_mode = GRID_EXACT ≡ the reference with SetEnableANN(false) (kdtree.cpp:285-288)."""
+    m, s, init = small_world["map"], small_world["scan10k"], small_world["init_pose"]
+    gpu_ctx.icp_set_target(m)
+    icp = locref.Icp(method=method, use_ann=False)
+    icp.set_target(m)
+    opts = api.icp_opts(method=method, search_mode=api.SEARCH_GRID_EXACT)
+    ok_o, Ho, Bo, eff_o = icp.hb(s, init)
+    ok_g, Hg, Bg, eff_g = gpu_ctx.icp_hb(s, init, opts)
+    assert ok_g == ok_o and eff_g == eff_o
+    _hb_close(Hg, Bg, Ho, Bo)
+    ro = icp.align(s, init)
+    pg, st = gpu_ctx.icp_align(s, init, opts)
+    dt, dr = pose_delta(pg, ro["pose"])
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and st["iterations"] == ro["iters"], (dt, dr)
+    # and the exact tree kernel (approximate=0) gives the same alignment as the grid
+    pt, st2 = gpu_ctx.icp_align(s, init, api.icp_opts(method=method, approximate=0))
+    dt, dr = pose_delta(pg, pt)
+    assert dt <= 1e-9 and dr <= 1e-9
+
+
 # ----------------------------------------------------------------------------------------------- incremental NDT
 def _world_scan(locref, synth, sid, n):
     """Scan `sid` expressed in the world frame with its true pose (what Lio feeds the matcher after a keyframe)."""

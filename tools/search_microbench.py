@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--map-points", type=int, default=10_000_000)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--method", type=int, default=2)
+    ap.add_argument("--search", choices=["tree", "tree_exact", "grid"], default="tree")
     args = ap.parse_args()
     ctx = api.Context(0)
     m = synth.make_map(args.map_points)
@@ -30,6 +31,10 @@ def main():
     inits = np.stack([synth.make_pose(i % 256)[1] for i in range(args.scans)])
     b = ctx.batch(scans)
     opts = api.icp_opts(method=args.method)
+    if args.search == "grid":
+        opts.search_mode = api.SEARCH_GRID_EXACT
+    elif args.search == "tree_exact":
+        opts.approximate = 0
     ctx.visit_count_enable(True)
     hb_ref = ctx.icp_hb_batch(b, inits, opts)
     vc = ctx.visit_count_read(reset=True)
@@ -47,7 +52,7 @@ def main():
     q = vc["queries"]
     k = 1 if args.method == 0 else 5
     sbytes = q * 16 + vc["nodes"] * 16 + q * 4 * k
-    print(json.dumps(dict(variant=os.environ.get("LOCGPU_SEARCH_VARIANT", "0"), scans=args.scans, queries=q, hb_identical_to_default=same, redo_frac=round(ss["redone"] / max(ss["searched"], 1), 5),
+    print(json.dumps(dict(variant=os.environ.get("LOCGPU_SEARCH_VARIANT", "0"), search=args.search, scans=args.scans, queries=q, hb_identical_to_default=same, redo_frac=round(ss["redone"] / max(ss["searched"], 1), 5),
                           search_ms=round(p["search_ms"], 4), accum_ms=round(p["accum_ms"], 4), solve_ms=round(p["solve_ms"], 4),
                           search_us_per_scan=round(1e3 * p["search_ms"] / args.scans, 2),
                           search_alg_GBs=round(sbytes / 1e9 / (p["search_ms"] / 1e3), 1),
