@@ -94,7 +94,7 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ):  # launched by torch.distributed.run (even with one rank)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
