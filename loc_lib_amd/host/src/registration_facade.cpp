@@ -12,6 +12,7 @@
 
 #include "../../../include/locgpu.h"
 #include "LocUtils/model/matching/3d/icp/icp_registration.hpp"
+#include "LocUtils/model/matching/3d/loam/loam_registration.hpp"
 #include "LocUtils/model/matching/3d/ndt/ndt_registration.hpp"
 #include "LocUtils/model/search_point/kdtree/kdtree.h"
 
@@ -129,6 +130,67 @@ bool NdtRegistration::ScanMatch(const CloudPtr& input_source, const SE3& predict
 }
 
 float NdtRegistration::GetFitnessScore() { return 0.0f; }  // ndt_registration.cpp:466-471
+
+// ------------------------------------------------------------------------------------------------ LOAM
+LoamRegistration::LoamRegistration() {}
+LoamRegistration::LoamRegistration(LoamOption option) : options_(option) {}
+LoamRegistration::~LoamRegistration() { locgpu_destroy(edge_ctx_); locgpu_destroy(surf_ctx_); }
+void LoamRegistration::SetDevice(int device_id) { device_id_ = device_id; }
+float LoamRegistration::GetFitnessScore() { return 0.0f; }  // loam_registration.cpp:101-104
+
+bool LoamRegistration::SetInputTarget(const CloudPtr& edge_input, const CloudPtr& surf_input) {
+    if (options_.use_edge_points_ && edge_input && (edge_ctx_ || locgpu_create(device_id_, &edge_ctx_) == LOCGPU_OK))
+        has_edge_ = locgpu_icp_set_target(edge_ctx_, edge_input->points.data(), edge_input->points.size(), sizeof(PointType)) == LOCGPU_OK;
+    if (options_.use_surf_points_ && surf_input && (surf_ctx_ || locgpu_create(device_id_, &surf_ctx_) == LOCGPU_OK))
+        has_surf_ = locgpu_icp_set_target(surf_ctx_, surf_input->points.data(), surf_input->points.size(), sizeof(PointType)) == LOCGPU_OK;
+    return true;  // loam_registration.cpp:35
+}
+
+bool LoamRegistration::ScanMatch(const CloudPtr& edge_input, const CloudPtr& surf_input, const SE3& predict_pose, CloudPtr& result_cloud_ptr,
+                                 SE3& result_pose) {
+    // Sources stay resident for the whole loop; each iteration = one H/B evaluation per feature class (loam_registration.cpp:53-71),
+    // the sum H = H_edge + H_surf, B = B_edge + B_surf (:76-77), dx = H⁻¹·B with NO effective-count or determinant test (:79),
+    // update, stop at |dx| < eps_ (:85). A failed sub-evaluation aborts with `return false` before result_pose is written (:56-70).
+    struct Side { locgpu_ctx* ctx; locgpu_batch* batch; locgpu_icp_opts opts; bool use; };
+    Side sides[2] = {{surf_ctx_, nullptr, to_c(options_.surf_icp_option_), options_.use_surf_points_},
+                     {edge_ctx_, nullptr, to_c(options_.edge_icp_option_), options_.use_edge_points_}};
+    const CloudPtr* inputs[2] = {&surf_input, &edge_input};
+    const bool have[2] = {has_surf_, has_edge_};
+    bool ok = true;
+    for (int i = 0; i < 2 && ok; ++i) {
+        if (!sides[i].use) continue;
+        if (!have[i] || !*inputs[i] || (*inputs[i])->points.empty()) { ok = false; break; }
+        const void* src[1] = {(*inputs[i])->points.data()};
+        const size_t cnt[1] = {(*inputs[i])->points.size()};
+        ok = locgpu_batch_create(sides[i].ctx, src, cnt, sizeof(PointType), 1, &sides[i].batch) == LOCGPU_OK;
+    }
+    SE3 pose = predict_pose;
+    for (int iter = 0; ok && iter < options_.max_iteration_; ++iter) {
+        double sum[44] = {0};
+        for (int i = 0; i < 2 && ok; ++i) {
+            if (!sides[i].use) continue;
+            double hb[44];
+            ok = locgpu_icp_hb_batch(sides[i].ctx, sides[i].batch, pose.data(), &sides[i].opts, hb) == LOCGPU_OK && hb[43] != 0.0;
+            for (int k = 0; k < 42; ++k) sum[k] += hb[k];
+        }
+        if (!ok) break;
+        sum[42] = 1e18;  // no effective-count gate in the LOAM loop
+        double dx[6];
+        int applied = 0, stop = 0;
+        locgpu_gn_update(sum, LOCGPU_P2PLANE, 0, options_.eps_, pose.data(), dx, &applied, &stop);
+        if (stop) break;
+    }
+    for (auto& sd : sides) locgpu_batch_destroy(sd.batch);
+    if (!ok) return false;
+    result_pose = pose;
+    // *cloud += *edge; *cloud += *surf; transformPointCloud (loam_registration.cpp:93-96)
+    CloudPtr cloud(new PointCloudType);
+    if (edge_input) cloud->points.insert(cloud->points.end(), edge_input->points.begin(), edge_input->points.end());
+    if (surf_input) cloud->points.insert(cloud->points.end(), surf_input->points.begin(), surf_input->points.end());
+    locgpu_ctx* any = surf_ctx_ ? surf_ctx_ : edge_ctx_;
+    if (any) write_output_cloud(any, cloud, result_pose, result_cloud_ptr);
+    return true;
+}
 
 // ------------------------------------------------------------------------------------------------ search plug-in
 KdtreeRegistration::KdtreeRegistration(bool) {}

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "LocUtils/model/matching/3d/icp/icp_registration.hpp"
+#include "LocUtils/model/matching/3d/loam/loam_registration.hpp"
 #include "LocUtils/model/matching/3d/ndt/ndt_registration.hpp"
 
 using namespace LocUtils;
@@ -32,7 +33,27 @@ static CloudPtr load(const char* path) {
     return c;
 }
 
+// loam mode: facade_scanmatch loam <edge_map.bin> <surf_map.bin> <edge_scan.bin> <surf_scan.bin> <pose7.bin> <out.bin>
+static int run_loam(char** argv) {
+    CloudPtr edge_map = load(argv[2]), surf_map = load(argv[3]), edge = load(argv[4]), surf = load(argv[5]);
+    SE3 predict, result;
+    FILE* f = std::fopen(argv[6], "rb");
+    if (!f || std::fread(predict.data(), 8, 7, f) != 7) return 2;
+    std::fclose(f);
+    std::shared_ptr<MatchingInterface> match_ptr = std::make_shared<LoamRegistration>(LoamOption());  // lio.cpp:51 / loc.cpp:71
+    match_ptr->SetInputTarget(edge_map, surf_map);
+    CloudPtr out(new PointCloudType);
+    if (!match_ptr->ScanMatch(edge, surf, predict, out, result)) return 3;
+    if (out->points.size() != edge->points.size() + surf->points.size()) return 4;
+    f = std::fopen(argv[7], "wb");
+    std::fwrite(result.data(), 8, 7, f);
+    for (const auto& p : out->points) std::fwrite(&p.x, 4, 3, f);
+    std::fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc == 8 && std::string(argv[1]) == "loam") return run_loam(argv);
     if (argc != 7) { std::fprintf(stderr, "usage\n"); return 2; }
     const std::string kind = argv[1];
     const int method = std::atoi(argv[2]);

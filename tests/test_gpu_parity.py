@@ -439,6 +439,42 @@ def test_cpp_facade_scanmatch(locref, small_world, tmp_path, kind, method):
     np.testing.assert_array_equal(cloud.view(np.uint32), locref.transform_cloud_f32(pose, s[:, :3]).view(np.uint32))
 
 
+def test_cpp_facade_loam(locref, small_world, tmp_path):
+    """LoamRegistration (loam_registration.cpp:38-99): edge P2Line + surf P2Plane normal equations summed, own GN loop (eps 1e-3)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "cpp", "facade_scanmatch")
+    m, s, init = small_world["map"], small_world["scan10k"], small_world["init_pose"]
+    edge_map, surf_map = m[::5], m
+    edge, surf = s[::7], s[np.arange(len(s)) % 7 != 0]
+    for name, arr in (("em", edge_map), ("sm", surf_map), ("e", edge), ("s", surf)):
+        np.ascontiguousarray(arr[:, :3], dtype=np.float32).tofile(tmp_path / (name + ".bin"))
+    np.asarray(init, dtype=np.float64).tofile(tmp_path / "pose.bin")
+    r = subprocess.run([exe, "loam"] + [str(tmp_path / n) for n in ("em.bin", "sm.bin", "e.bin", "s.bin", "pose.bin", "out.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(tmp_path / "out.bin", dtype=np.uint8)
+    pose = raw[:56].view(np.float64)
+    cloud = raw[56:].view(np.float32).reshape(-1, 3)
+    # oracle composition
+    ie, isf = locref.Icp(method=locref.P2LINE), locref.Icp(method=locref.P2PLANE)
+    ie.set_target(edge_map)
+    isf.set_target(surf_map)
+    p = np.array(init, dtype=np.float64)
+    for _ in range(20):
+        ok1, H1, B1, _ = isf.hb(surf, p)
+        ok2, H2, B2, _ = ie.hb(edge, p)
+        assert ok1 and ok2
+        det, dx = locref.lu6(H1 + H2, B1 + B2)
+        p = locref.apply_update(p, dx)
+        if np.linalg.norm(dx) < 1e-3:
+            break
+    dt, dr = pose_delta(pose, p)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (dt, dr)
+    both = np.vstack([edge[:, :3], surf[:, :3]])
+    np.testing.assert_array_equal(cloud.view(np.uint32), locref.transform_cloud_f32(pose, both).view(np.uint32))
+
+
 # ----------------------------------------------------------------------------------------------- golden fixtures
 def test_golden_fixture_gpu(gpu_ctx, api):
     """Committed golden vectors (tests/golden/make_golden.py, generated with the oracle in the build container)."""
