@@ -195,17 +195,21 @@ __device__ __forceinline__ void R_hat(const double* R, const D3& q, double (&Rh)
     }
 }
 
+
 // K2, P2Plane: IcpRegistration::CaculateMatrixHAndBP2Plane (icp_registration.cpp:161-213) + math::FitPlane (math_utils.h:112-136).
 __global__ __launch_bounds__(kBlock) void icp_plane_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
-                                                                 double max_plane_distance, double* __restrict__ partials) {
+                                                                 double max_plane_distance, double* __restrict__ partials, int kPlanePts) {
     const int scan = blockIdx.y;
     if (st[scan].done) return;  // uniform per block
-    const int i = blockIdx.x * kBlock + threadIdx.x;
     double acc[28];
 #pragma unroll
     for (int v = 0; v < 28; ++v) acc[v] = 0.0;
+    // kPlanePts points per thread before the (≈500-instruction) 28-value wave reduction
+#pragma unroll 1
+    for (int pp = 0; pp < kPlanePts; ++pp) {
+    const int i = (blockIdx.x * kPlanePts + pp) * kBlock + threadIdx.x;
     if (i < counts[scan]) {
         const size_t gi = (size_t)scan * max_n + i;
         const uint32_t s4 = nn[4 * nn_pitch + gi];
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void icp_plane_accum_kernel(const uint2* __
                 if (err * err > 1e-2) fit = false;
             }
             if (fit) {
-                acc[27] = 1.0;  // effective_num++ before the residual gate (icp cpp:184)
+                acc[27] += 1.0;  // effective_num++ before the residual gate (icp cpp:184)
                 const double dis = dot3(n3, qs) + n4[3];
                 if (!(fabs(dis) > max_plane_distance)) {
                     const double* R = st[scan].R;
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(kBlock) void icp_plane_accum_kernel(const uint2* __
                 }
             }
         }
+    }
     }
     block_reduce_store<28>(acc, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
 }
@@ -625,17 +630,27 @@ bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, i
     return false;
 }
 
-void launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
-    dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
-    if (method == 2)
-        hipLaunchKernelGGL(icp_plane_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate,
-                           a.partials);
-    else if (method == 1)
+int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
+    const int blocks = (a.max_n + kBlock - 1) / kBlock;
+    if (method == 2) {
+        // points per thread: amortise the wave reduction when the batch already fills the chip; 1 for small launches (latency)
+        static const int forced = [] { const char* e = getenv("LOCGPU_PLANE_PTS"); return e ? atoi(e) : 0; }();
+        const long total_blocks = (long)blocks * a.n_scans;
+        int pts = forced > 0 ? forced : (total_blocks >= 8192 ? 8 : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1)));
+        if (pts > 8) pts = 8;
+        const int gx = (blocks + pts - 1) / pts;
+        hipLaunchKernelGGL(icp_plane_accum_kernel, dim3(gx, a.n_scans), dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate,
+                           a.partials, pts);
+        return gx;
+    }
+    dim3 grid(blocks, a.n_scans);
+    if (method == 1)
         hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate,
                            a.partials);
     else
         hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate,
                            a.partials);
+    return blocks;
 }
 
 void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,

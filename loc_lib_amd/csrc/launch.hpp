@@ -46,7 +46,8 @@ bool launch_icp_search(const SearchArgs& a, hipStream_t s);
 bool launch_icp_search_redo(const SearchArgs& a, hipStream_t s);
 bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, int k, float alpha_eff, int32_t* out, uint32_t* visits,
                       hipStream_t s);
-void launch_icp_accum(int method, const AccumArgs& a, hipStream_t s);
+// returns the number of partial blocks per scan the kernel wrote (what gn_solve must sum)
+int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s);
 void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
                      hipStream_t s);
 void launch_transform_cloud(const float4* src, size_t n, const float* m12, float4* dst, hipStream_t s);

@@ -372,6 +372,7 @@ bool IterLauncher::launch(int do_update) {
         if (ev) { (void)hipEventRecord(ev, s); ev_used++; }
     };
     mark();
+    int n_partial_blocks = b->blocks_per_scan;
     if (!ndt) {
         SearchArgs sa{ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ctx->depth, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, k, alpha_eff,
                       prm.method == LOCGPU_P2P ? 1 : 0, ctx->count_visits ? ctx->d_visits : nullptr, b->d_redo_list, b->d_redo_count,
@@ -385,7 +386,7 @@ bool IterLauncher::launch(int do_update) {
         mark();
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
         AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
-        launch_icp_accum(prm.method, aa, s);
+        n_partial_blocks = launch_icp_accum(prm.method, aa, s);
     } else {
         mark();  // NDT has no separate search kernel: search slot stays empty
         if (prm.method == 4)
@@ -395,7 +396,7 @@ bool IterLauncher::launch(int do_update) {
             launch_ndt_accum(ctx->ndt, b->d_src, b->d_counts, b->d_state, b->max_n, b->n_scans, b->d_partials, s);
     }
     mark();
-    launch_gn_solve(b->d_partials, b->blocks_per_scan, b->d_state, b->n_scans, prm, do_update, b->d_hb, s);
+    launch_gn_solve(b->d_partials, n_partial_blocks, b->d_state, b->n_scans, prm, do_update, b->d_hb, s);
     mark();
     return hip_ok(ctx, hipGetLastError(), "kernel launch");
 }
