@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--search", choices=["tree", "tree_exact", "grid"], default="tree",
                     help="tree = the reference's default alpha=0.1 approximate KD-tree search (headline); tree_exact / grid = "
                          "SetEnableANN(false) semantics through the tree or through the exact cell grid")
+    ap.add_argument("--include-upload", action="store_true",
+                    help="time host-buffer hand-over too: every step re-creates the batch from host clouds (pack + H2D over PCIe). "
+                         "Reported for DESIGN.md only; never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -129,7 +132,16 @@ def main():
         t0 = time.time()
         ctx.ndt_set_target(map_xyz)           # NdtOptions defaults: voxel 1.0, NEARBY6, DIRECT_NDT
         t_ingest = time.time() - t0
-    align = (lambda: ctx.ndt_align_batch(batch, inits)) if method < 0 else (lambda: ctx.icp_align_batch(batch, inits, opts))
+    align_resident = (lambda: ctx.ndt_align_batch(batch, inits)) if method < 0 else (lambda: ctx.icp_align_batch(batch, inits, opts))
+
+    def align_with_upload():
+        b2 = ctx.batch(scans)  # host clouds → pinned pack → H2D, like a ScanMatch call that is handed host buffers
+        try:
+            return ctx.ndt_align_batch(b2, inits) if method < 0 else ctx.icp_align_batch(b2, inits, opts)
+        finally:
+            b2.close()
+
+    align = align_with_upload if args.include_upload else align_resident
 
     def barrier():
         if dist is not None:

@@ -70,6 +70,7 @@ struct locgpu_batch {
     bool graph_ndt = false;
     const void* graph_target = nullptr;  // tree / NDT table the capture was made against
     unsigned long long graph_epoch = 0;
+    float4* h_src = nullptr;               // pinned staging of the packed source (single-scan path only; reused across calls)
     locgpu::PoseState* h_state = nullptr;  // pinned
     double* h_hb = nullptr;                // pinned
     std::vector<int> counts;

@@ -34,5 +34,19 @@ for name in ("p2plane", "ndt"):
             b.close()
         out["%s_%s" % (name, "graph" if graph else "eager")] = dict(ms_per_scan=round(1e3 * float(np.mean(ts)), 4),
                                                                      scans_per_s=round(1.0 / float(np.mean(ts)), 1), mean_iters=float(np.mean(its)))
+# host-pointer path, what the façade's ScanMatch calls per scan: pack + H2D + align + D2H of the pose
+for graph in (False, True):
+    ctx.graph_enable(graph)
+    opts = api.icp_opts(method=api.P2PLANE)
+    ts = []
+    for sid in range(12):
+        scan = synth.make_scan(sid)
+        _, init = synth.make_pose(sid)
+        ctx.icp_align(scan, init, opts)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.icp_align(scan, init, opts)
+        ts.append((time.perf_counter() - t0) / 5)
+    out["p2plane_hostptr_%s" % ("graph" if graph else "eager")] = dict(ms_per_scan=round(1e3 * float(np.mean(ts)), 4), scans_per_s=round(1.0 / float(np.mean(ts)), 1))
 ctx.graph_enable(False)
 print(json.dumps(out))
