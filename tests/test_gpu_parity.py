@@ -496,6 +496,64 @@ def test_golden_fixture_gpu(gpu_ctx, api):
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and st["iterations"] == int(g["iters_ndt"])
 
 
+# ----------------------------------------------------------------------------------------------- error paths
+def test_error_codes_and_empty_inputs(api, small_world):
+    ctx = api.Context(0)
+    try:
+        opts = api.icp_opts(method=2)
+        s, init = small_world["scan2k"], small_world["init_pose"]
+        with pytest.raises(api.LocGpuError) as e:   # ScanMatch before SetInputTarget
+            ctx.icp_align(s, init, opts)
+        assert e.value.code == -3
+        with pytest.raises(api.LocGpuError) as e:
+            ctx.ndt_align(s, init)
+        assert e.value.code == -3
+        with pytest.raises(api.LocGpuError) as e:   # empty target (kdtree.cpp:12-15 returns false)
+            ctx.icp_set_target(np.zeros((0, 3), dtype=np.float32))
+        assert e.value.code == -1
+        ctx.icp_set_target(small_world["map"])
+        with pytest.raises(api.LocGpuError) as e:   # empty source
+            ctx.icp_align(np.zeros((0, 3), dtype=np.float32), init, opts)
+        assert e.value.code == -1
+        with pytest.raises(api.LocGpuError) as e:
+            ctx.knn(s, k=9)
+        assert e.value.code == -1
+        bad = api.icp_opts(method=2)
+        bad.method = 7
+        with pytest.raises(api.LocGpuError):
+            ctx.icp_align(s, init, bad)
+        # the context is still usable after errors
+        pose, st = ctx.icp_align(s, init, opts)
+        assert st["iterations"] >= 1 and np.all(np.isfinite(pose))
+        # max_iteration = 0: the loop body never runs, pose = predict (icp cpp:358)
+        pose0, st0 = ctx.icp_align(s, init, api.icp_opts(method=2, max_iteration=0))
+        np.testing.assert_array_equal(pose0, init)
+        assert st0["iterations"] == 0
+    finally:
+        ctx.close()
+
+
+# ----------------------------------------------------------------------------------------------- bench configuration
+def test_bench_config_parity_10m(gpu_ctx, api, locref, synth):
+    """BASELINE configs[2] at full size: 115 200-pt scans vs the 10 M-pt map, reference-default P2Plane — GPU vs the oracle."""
+    m = synth.make_map(10_000_000)
+    gpu_ctx.icp_set_target(m)
+    icp = locref.Icp(method=2)
+    icp.set_target(m)
+    info = gpu_ctx.icp_target_info()
+    assert (info["num_leaves"], info["num_nodes"], info["depth"]) == tuple(icp.tree_info()[k] for k in ("num_leaves", "num_nodes", "depth"))
+    scans = [synth.make_scan(sid) for sid in (11, 200)]
+    inits = np.stack([synth.make_pose(sid)[1] for sid in (11, 200)])
+    b = gpu_ctx.batch(scans)
+    out, stats = gpu_ctx.icp_align_batch(b, inits, api.icp_opts(method=2))
+    for i, s in enumerate(scans):
+        ro = icp.align(s, inits[i])
+        dt, dr = pose_delta(out[i], ro["pose"])
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and dt < 1e-9, (i, dt, dr)
+        assert stats[i]["iterations"] == ro["iters"]
+    b.close()
+
+
 # ----------------------------------------------------------------------------------------------- properties at full size
 def test_full_size_properties(gpu_ctx, api, synth):
     """BASELINE config 2 size (115 200-pt scan vs 1 M-pt map): size-independent properties, no oracle needed.
