@@ -186,6 +186,29 @@ def test_point_sharded_hb_sum_equals_full(gpu_ctx, api, small_world):
     assert summed[42] == full[42]
 
 
+def test_point_sharded_align_equals_monolithic(gpu_ctx, api, small_world):
+    """multi_gpu.point_sharded_align (per-iteration H,B over point shards → sum → host update, the loop that carries the RCCL
+    all-reduce when ranks own the shards) reproduces the on-device Gauss–Newton loop: same iterations, same pose."""
+    from loc_lib_amd import multi_gpu
+    m, s, init = small_world["map"], small_world["scan10k"], small_world["init_pose"]
+    gpu_ctx.icp_set_target(m)
+    for method in (2, 0):
+        opts = api.icp_opts(method=method)
+        want, st = gpu_ctx.icp_align(s, init, opts)
+        shards = gpu_ctx.batch([s[:3500], s[3500:7000], s[7000:]])  # three "ranks" worth of points
+
+        def hb_fn(pose):
+            hb = gpu_ctx.icp_hb_batch(shards, np.stack([pose] * 3), opts)
+            out = hb[:, :43].sum(0)
+            return np.concatenate([out, [0.0]])
+
+        got, iters = multi_gpu.point_sharded_align(hb_fn, api.gn_update, init, method=method)
+        shards.close()
+        assert iters == st["iterations"]
+        dt, dr = pose_delta(got, want)
+        assert dt < 1e-9 and dr < 1e-9, (method, dt, dr)
+
+
 # ----------------------------------------------------------------------------------------------- output cloud
 def test_transform_cloud_bit_exact(gpu_ctx, locref, small_world):
     s = np.zeros((2000, 8), dtype=np.float32)  # pcl::PointXYZI stride (32 bytes)
