@@ -182,6 +182,80 @@ LOCGPU_API int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int res
  * kernel's launches, out[1] = queries it handed to the exact redo kernel (distance ties / near-misses on the top tree levels). */
 LOCGPU_API int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[2], int reset);
 
+/* =====================================================================================================================
+ * Clouds resident in HBM and the filters either side of the matcher.
+ *
+ * In the reference every scan passes RemoveNanPoint → VoxelFilter::Filter → ScanMatch (loc.cpp:217-224, lio.cpp:236,257),
+ * the global map passes BoxFilter::Filter → SetInputTarget (loc.cpp:187-194) and every keyframe passes
+ * pcl::transformPointCloud → operator+= → VoxelFilter::Filter → SetInputTarget (lio.cpp:268-306). All of these are thin
+ * wrappers over PCL 1.8 (pcl::removeNaNFromPointCloud, pcl::VoxelGrid, pcl::CropBox, pcl::transformPointCloud). The entry
+ * points below run the same steps on the GPU; a locgpu_cloud keeps a cloud in HBM between them so that a scan crosses PCIe
+ * once. A cloud is {x, y, z, intensity} per point plus PCL's `is_dense` flag, which the PCL filters trust (a cloud flagged
+ * dense is never tested for NaN) and which therefore travels with the data.
+ *
+ * Results equal PCL's: the same points in the same order (VoxelGrid: centroids in ascending voxel index; CropBox and
+ * removeNaN: survivors in input order). VoxelGrid's float32 centroid sums run in input order (PCL's order inside a voxel is
+ * whatever its unstable std::sort leaves, so the last bits of a centroid are not defined by PCL itself).
+ * `intensity_offset` = byte offset of the float32 intensity inside a point (pcl::PointXYZI: 16), or LOCGPU_NO_INTENSITY.
+ * ===================================================================================================================== */
+typedef struct locgpu_cloud locgpu_cloud;
+typedef struct locgpu_submap locgpu_submap;
+#define LOCGPU_NO_INTENSITY ((size_t)-1)
+
+LOCGPU_API int locgpu_cloud_create(locgpu_ctx* ctx, locgpu_cloud** out);
+LOCGPU_API void locgpu_cloud_destroy(locgpu_cloud* c);
+/* Host → HBM (deep copy, like every reference call that takes a CloudPtr). */
+LOCGPU_API int locgpu_cloud_upload(locgpu_cloud* c, const void* pts, size_t n, size_t stride_bytes, size_t intensity_offset, int is_dense);
+LOCGPU_API int locgpu_cloud_info(const locgpu_cloud* c, size_t* n, int* is_dense);
+/* HBM → host: writes x, y, z (and intensity unless LOCGPU_NO_INTENSITY) of each point, leaves the other bytes of the
+ * caller's points alone. Fails with LOCGPU_ERR_INVALID when capacity < the cloud's size. */
+LOCGPU_API int locgpu_cloud_download(const locgpu_cloud* c, void* out, size_t capacity, size_t stride_bytes, size_t intensity_offset);
+LOCGPU_API int locgpu_cloud_copy(const locgpu_cloud* in, locgpu_cloud* out);
+
+/* RemoveNanPoint, LocUtils/include/LocUtils/common/point_cloud_utils.h:13-20 (pcl::removeNaNFromPointCloud). out may be in. */
+LOCGPU_API int locgpu_cloud_remove_nan(const locgpu_cloud* in, locgpu_cloud* out);
+/* VoxelFilter::Filter, LocUtils/src/model/cloud_filter/voxel_filter.cpp:19-25 (pcl::VoxelGrid, leaf = (v, v, v), defaults).
+ * *passthrough (optional) = 1 when PCL's "leaf size is too small for the input dataset" rule copied the input unchanged.
+ * out may be in (the reference filters local_map_ in place, lio.cpp:300). */
+LOCGPU_API int locgpu_cloud_voxel_filter(const locgpu_cloud* in, float leaf, locgpu_cloud* out, int* passthrough);
+/* BoxFilter::Filter, LocUtils/src/model/cloud_filter/box_filter.cpp:25-32 (pcl::CropBox, inclusive bounds). The caller
+ * computes the edges as BoxFilter::CalculateEdge does (:59-66): min = origin − size, max = origin + size in float32. */
+LOCGPU_API int locgpu_cloud_crop_box(const locgpu_cloud* in, const float min_xyz[3], const float max_xyz[3], locgpu_cloud* out);
+/* pcl::transformPointCloud(in, out, pose.matrix()) with the double-precision matrix of lio.cpp:244,279. out may be in. */
+LOCGPU_API int locgpu_cloud_transform(const locgpu_cloud* in, const double pose[7], locgpu_cloud* out);
+/* pcl::PointCloud::operator+= (lio.cpp:245,291,297). */
+LOCGPU_API int locgpu_cloud_append(locgpu_cloud* dst, const locgpu_cloud* src);
+
+/* The matcher entry points on resident clouds (same semantics as their host-pointer versions above). */
+LOCGPU_API int locgpu_icp_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* target);
+LOCGPU_API int locgpu_ndt_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* target, const locgpu_ndt_opts* opts);
+LOCGPU_API int locgpu_icp_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const double init_pose[7], const locgpu_icp_opts* opts,
+                                      double out_pose[7], locgpu_align_stats* stats);
+LOCGPU_API int locgpu_ndt_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const double init_pose[7], double out_pose[7],
+                                      locgpu_align_stats* stats);
+
+/* Host-pointer one-shots (upload → filter → download), what VoxelFilter::Filter / BoxFilter::Filter / RemoveNanPoint bind to.
+ * `out` needs room for n points; *out_n receives the count, *out_is_dense (optional) the flag of the result. out may be pts. */
+LOCGPU_API int locgpu_voxel_filter(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, size_t intensity_offset, int is_dense, float leaf,
+                                   void* out, size_t* out_n, int* out_is_dense);
+LOCGPU_API int locgpu_crop_box(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, size_t intensity_offset, int is_dense,
+                               const float min_xyz[3], const float max_xyz[3], void* out, size_t* out_n, int* out_is_dense);
+LOCGPU_API int locgpu_remove_nan(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, size_t intensity_offset, int is_dense, void* out,
+                                 size_t* out_n, int* out_is_dense);
+
+/* The local map of Lio::AddCloud's keyframe branch (lio.cpp:268-306), kept in HBM: a queue of at most num_kfs world-frame
+ * keyframe clouds (scans_in_local_map_) and the voxel-filtered local map (local_map_) that is the next matching target.
+ * add_keyframe(scan, pose): key_frame_scan = transform(scan, pose) (pose NULL: scan is already in the world frame); push;
+ * when the queue exceeds num_kfs drop the oldest and rebuild the map from the retained keyframes, otherwise append the new
+ * one to the (already filtered) map; then voxel-filter the map in place. The caller then hands locgpu_submap_cloud() to
+ * locgpu_icp_set_target_cloud / locgpu_ndt_set_target_cloud (or the new keyframe alone for INCREMENTAL_NDT, lio.cpp:301-304). */
+LOCGPU_API int locgpu_submap_create(locgpu_ctx* ctx, int num_kfs, float leaf, locgpu_submap** out);
+LOCGPU_API void locgpu_submap_destroy(locgpu_submap* m);
+LOCGPU_API int locgpu_submap_add_keyframe(locgpu_submap* m, const locgpu_cloud* scan, const double pose[7]);
+LOCGPU_API int locgpu_submap_cloud(locgpu_submap* m, locgpu_cloud** map);          /* borrowed: owned by the submap */
+LOCGPU_API int locgpu_submap_last_keyframe(locgpu_submap* m, locgpu_cloud** kf);   /* borrowed: the newest world-frame keyframe */
+LOCGPU_API int locgpu_submap_info(const locgpu_submap* m, int* n_keyframes, size_t* map_points);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,14 @@ ABI_SYMBOLS = [
     "locgpu_icp_hb_batch", "locgpu_gn_update", "locgpu_ndt_set_target", "locgpu_ndt_target_info", "locgpu_ndt_dump",
     "locgpu_ndt_align", "locgpu_profile_enable", "locgpu_profile_read", "locgpu_visit_count_enable", "locgpu_visit_count_read",
     "locgpu_search_stats_read", "locgpu_graph_enable",
+    "locgpu_cloud_create", "locgpu_cloud_destroy", "locgpu_cloud_upload", "locgpu_cloud_info", "locgpu_cloud_download", "locgpu_cloud_copy",
+    "locgpu_cloud_remove_nan", "locgpu_cloud_voxel_filter", "locgpu_cloud_crop_box", "locgpu_cloud_transform", "locgpu_cloud_append",
+    "locgpu_icp_set_target_cloud", "locgpu_ndt_set_target_cloud", "locgpu_icp_align_cloud", "locgpu_ndt_align_cloud",
+    "locgpu_voxel_filter", "locgpu_crop_box", "locgpu_remove_nan",
+    "locgpu_submap_create", "locgpu_submap_destroy", "locgpu_submap_add_keyframe", "locgpu_submap_cloud", "locgpu_submap_last_keyframe",
+    "locgpu_submap_info",
 ]
+NO_INTENSITY = ctypes.c_size_t(-1).value
 
 
 class LocGpuError(RuntimeError):
@@ -93,6 +100,20 @@ def lib():
             "locgpu_profile_enable": (i32, [vp, i32]), "locgpu_profile_read": (i32, [vp, vp, i32]),
             "locgpu_visit_count_enable": (i32, [vp, i32]), "locgpu_visit_count_read": (i32, [vp, vp, i32]),
             "locgpu_search_stats_read": (i32, [vp, vp, i32]), "locgpu_graph_enable": (i32, [vp, i32]),
+            "locgpu_cloud_create": (i32, [vp, vp]), "locgpu_cloud_destroy": (None, [vp]),
+            "locgpu_cloud_upload": (i32, [vp, vp, sz, sz, sz, i32]), "locgpu_cloud_info": (i32, [vp, vp, vp]),
+            "locgpu_cloud_download": (i32, [vp, vp, sz, sz, sz]), "locgpu_cloud_copy": (i32, [vp, vp]),
+            "locgpu_cloud_remove_nan": (i32, [vp, vp]), "locgpu_cloud_voxel_filter": (i32, [vp, f32, vp, vp]),
+            "locgpu_cloud_crop_box": (i32, [vp, vp, vp, vp]), "locgpu_cloud_transform": (i32, [vp, vp, vp]),
+            "locgpu_cloud_append": (i32, [vp, vp]),
+            "locgpu_icp_set_target_cloud": (i32, [vp, vp]), "locgpu_ndt_set_target_cloud": (i32, [vp, vp, vp]),
+            "locgpu_icp_align_cloud": (i32, [vp, vp, vp, vp, vp, vp]), "locgpu_ndt_align_cloud": (i32, [vp, vp, vp, vp, vp]),
+            "locgpu_voxel_filter": (i32, [vp, vp, sz, sz, sz, i32, f32, vp, vp, vp]),
+            "locgpu_crop_box": (i32, [vp, vp, sz, sz, sz, i32, vp, vp, vp, vp, vp]),
+            "locgpu_remove_nan": (i32, [vp, vp, sz, sz, sz, i32, vp, vp, vp]),
+            "locgpu_submap_create": (i32, [vp, i32, f32, vp]), "locgpu_submap_destroy": (None, [vp]),
+            "locgpu_submap_add_keyframe": (i32, [vp, vp, vp]), "locgpu_submap_cloud": (i32, [vp, vp]),
+            "locgpu_submap_last_keyframe": (i32, [vp, vp]), "locgpu_submap_info": (i32, [vp, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -212,6 +233,43 @@ class Context:
                                                  out.strides[0]))
         return out
 
+    # ---- filters either side of the matcher, host-pointer one-shots ([n, 4] float32 x, y, z, intensity)
+    def _one_shot(self, fn, cloud, is_dense, *extra):
+        a = _xyzi(cloud)
+        out = np.zeros_like(a)
+        n, d = ctypes.c_size_t(0), ctypes.c_int(0)
+        self._check(fn(self._h, a.ctypes.data, a.shape[0], 16, 12, int(is_dense), *extra, out.ctypes.data, ctypes.byref(n), ctypes.byref(d)))
+        return out[:n.value].copy(), bool(d.value)
+
+    def voxel_filter(self, cloud, leaf, is_dense=True):
+        return self._one_shot(lib().locgpu_voxel_filter, cloud, is_dense, float(leaf))
+
+    def crop_box(self, cloud, mn, mx, is_dense=True):
+        mn, mx = np.ascontiguousarray(mn, np.float32), np.ascontiguousarray(mx, np.float32)
+        return self._one_shot(lib().locgpu_crop_box, cloud, is_dense, mn.ctypes.data, mx.ctypes.data)
+
+    def remove_nan(self, cloud, is_dense):
+        return self._one_shot(lib().locgpu_remove_nan, cloud, is_dense)
+
+    # ---- matcher entry points on resident clouds
+    def icp_set_target_cloud(self, cloud):
+        self._check(lib().locgpu_icp_set_target_cloud(self._h, cloud._h))
+
+    def ndt_set_target_cloud(self, cloud, opts=None):
+        self._check(lib().locgpu_ndt_set_target_cloud(self._h, cloud._h, ctypes.byref(opts) if opts is not None else None))
+
+    def icp_align_cloud(self, cloud, init_pose, opts):
+        out = np.zeros(7)
+        st = AlignStats()
+        self._check(lib().locgpu_icp_align_cloud(self._h, cloud._h, _pose(init_pose).ctypes.data, ctypes.byref(opts), out.ctypes.data, ctypes.byref(st)))
+        return out, _stats_dict(st)
+
+    def ndt_align_cloud(self, cloud, init_pose):
+        out = np.array(_pose(init_pose), copy=True)
+        st = AlignStats()
+        self._check(lib().locgpu_ndt_align_cloud(self._h, cloud._h, _pose(init_pose).ctypes.data, out.ctypes.data, ctypes.byref(st)))
+        return out, _stats_dict(st)
+
     # ---- batches
     def batch(self, scans):
         return Batch(self, scans)
@@ -289,6 +347,130 @@ class Context:
         out = np.zeros(2, dtype=np.uint64)
         self._check(lib().locgpu_search_stats_read(self._h, out.ctypes.data, int(reset)))
         return dict(searched=int(out[0]), redone=int(out[1]))
+
+
+def _xyzi(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 4:
+        raise ValueError("cloud must be [n, 4] float32 (x, y, z, intensity)")
+    return a
+
+
+class Cloud:
+    """A cloud resident in HBM (locgpu_cloud): float32 x, y, z, intensity per point + PCL's is_dense flag."""
+
+    def __init__(self, ctx, points=None, is_dense=True, _borrowed=None):
+        self.ctx = ctx
+        self._owned = _borrowed is None
+        if _borrowed is not None:
+            self._h = _borrowed
+        else:
+            self._h = ctypes.c_void_p()
+            ctx._check(lib().locgpu_cloud_create(ctx._h, ctypes.byref(self._h)))
+            if points is not None:
+                self.upload(points, is_dense)
+
+    def upload(self, points, is_dense=True):
+        a = _xyzi(points)
+        self.ctx._check(lib().locgpu_cloud_upload(self._h, a.ctypes.data, a.shape[0], 16, 12, int(is_dense)))
+        return self
+
+    @property
+    def info(self):
+        n, d = ctypes.c_size_t(0), ctypes.c_int(0)
+        self.ctx._check(lib().locgpu_cloud_info(self._h, ctypes.byref(n), ctypes.byref(d)))
+        return int(n.value), bool(d.value)
+
+    def __len__(self):
+        return self.info[0]
+
+    @property
+    def is_dense(self):
+        return self.info[1]
+
+    def download(self):
+        n = len(self)
+        out = np.zeros((n, 4), np.float32)
+        self.ctx._check(lib().locgpu_cloud_download(self._h, out.ctypes.data, n, 16, 12))
+        return out
+
+    def _out(self, out):
+        return out if out is not None else Cloud(self.ctx)
+
+    def copy(self, out=None):
+        out = self._out(out)
+        self.ctx._check(lib().locgpu_cloud_copy(self._h, out._h))
+        return out
+
+    def remove_nan(self, out=None):
+        out = self._out(out)
+        self.ctx._check(lib().locgpu_cloud_remove_nan(self._h, out._h))
+        return out
+
+    def voxel_filter(self, leaf, out=None, with_passthrough=False):
+        out = self._out(out)
+        pt = ctypes.c_int(0)
+        self.ctx._check(lib().locgpu_cloud_voxel_filter(self._h, float(leaf), out._h, ctypes.byref(pt)))
+        return (out, bool(pt.value)) if with_passthrough else out
+
+    def crop_box(self, mn, mx, out=None):
+        out = self._out(out)
+        mn, mx = np.ascontiguousarray(mn, np.float32), np.ascontiguousarray(mx, np.float32)
+        self.ctx._check(lib().locgpu_cloud_crop_box(self._h, mn.ctypes.data, mx.ctypes.data, out._h))
+        return out
+
+    def transform(self, pose, out=None):
+        out = self._out(out)
+        self.ctx._check(lib().locgpu_cloud_transform(self._h, _pose(pose).ctypes.data, out._h))
+        return out
+
+    def append(self, other):
+        self.ctx._check(lib().locgpu_cloud_append(self._h, other._h))
+        return self
+
+    def close(self):
+        if self._owned and getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib().locgpu_cloud_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Submap:
+    """Lio::AddCloud's keyframe local map in HBM (locgpu_submap)."""
+
+    def __init__(self, ctx, num_kfs, leaf):
+        self.ctx = ctx
+        self._h = ctypes.c_void_p()
+        ctx._check(lib().locgpu_submap_create(ctx._h, int(num_kfs), float(leaf), ctypes.byref(self._h)))
+
+    def add_keyframe(self, scan, pose=None):
+        self.ctx._check(lib().locgpu_submap_add_keyframe(self._h, scan._h, _pose(pose).ctypes.data if pose is not None else None))
+
+    def cloud(self):
+        h = ctypes.c_void_p()
+        self.ctx._check(lib().locgpu_submap_cloud(self._h, ctypes.byref(h)))
+        return Cloud(self.ctx, _borrowed=h)
+
+    def last_keyframe(self):
+        h = ctypes.c_void_p()
+        self.ctx._check(lib().locgpu_submap_last_keyframe(self._h, ctypes.byref(h)))
+        return Cloud(self.ctx, _borrowed=h)
+
+    @property
+    def info(self):
+        k, n = ctypes.c_int(0), ctypes.c_size_t(0)
+        self.ctx._check(lib().locgpu_submap_info(self._h, ctypes.byref(k), ctypes.byref(n)))
+        return int(k.value), int(n.value)
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib().locgpu_submap_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 class Batch:

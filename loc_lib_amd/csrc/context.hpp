@@ -11,7 +11,7 @@
 #include "icp_kernels.hpp"
 
 struct NdtTable;  // ndt_kernels.hpp
-namespace locgpu { struct IncNdtState; }  // ndt_inc.hpp
+namespace locgpu { struct IncNdtState; struct FilterScratch; }  // ndt_inc.hpp, cloud_filters.hpp
 
 struct locgpu_ctx {
     int device = 0;
@@ -33,6 +33,8 @@ struct locgpu_ctx {
     NdtTable* ndt = nullptr;
     locgpu::IncNdtState* inc = nullptr;  // incremental NDT voxel set (persists across set_target calls)
     locgpu_ndt_opts ndt_opts;
+
+    locgpu::FilterScratch* filt = nullptr;  // workspaces of the cloud filters (cloud_filters.hip)
 
     // reusable one-scan batch for the single-scan entry points
     locgpu_batch* single = nullptr;

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "context.hpp"
+#include "cloud_filters.hpp"
 #include "grid_build.hpp"
 #include "kdtree_build.hpp"
 #include "launch.hpp"
@@ -158,6 +159,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     if (ctx->d_visits) (void)hipFree(ctx->d_visits);
     if (ctx->d_search_stats) (void)hipFree(ctx->d_search_stats);
     ndt_free(ctx);
+    filters_free(ctx);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -543,11 +545,9 @@ static int check_icp(locgpu_ctx* ctx, const locgpu_icp_opts* o, GnParams& prm, i
     return LOCGPU_OK;
 }
 
-static int single_batch(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, locgpu_batch** out) {
-    // The reference deep-copies the source on every call (SetSource, icp_registration.cpp:252-265); so do we — but into buffers
-    // that are kept between calls: a per-scan caller (Loc::Update at 10-20 Hz) must not pay a dozen hipMalloc/hipFree per scan.
+// The reusable one-scan batch (device buffers + pinned staging) with room for n points.
+static int single_reserve(locgpu_ctx* ctx, size_t n, locgpu_batch** out) {
     if (n == 0) return fail(ctx, LOCGPU_ERR_INVALID, "source cloud is empty");
-    if (!src || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "source cloud: NULL pointer or stride < 12");
     locgpu_batch* b = ctx->single;
     if (!b || (size_t)b->max_n < n || !b->h_src) {
         if (b) { free_batch(b); ctx->single = nullptr; }
@@ -561,10 +561,34 @@ static int single_batch(locgpu_ctx* ctx, const void* src, size_t n, size_t strid
         b = ctx->single;
         if (!hip_ok(ctx, hipHostMalloc((void**)&b->h_src, cap * sizeof(float4)), "hipHostMalloc src")) { free_batch(b); ctx->single = nullptr; return LOCGPU_ERR_OOM; }
     }
+    *out = b;
+    return LOCGPU_OK;
+}
+
+static int single_batch(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, locgpu_batch** out) {
+    // The reference deep-copies the source on every call (SetSource, icp_registration.cpp:252-265); so do we — but into buffers
+    // that are kept between calls: a per-scan caller (Loc::Update at 10-20 Hz) must not pay a dozen hipMalloc/hipFree per scan.
+    if (n == 0) return fail(ctx, LOCGPU_ERR_INVALID, "source cloud is empty");
+    if (!src || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "source cloud: NULL pointer or stride < 12");
+    locgpu_batch* b = nullptr;
+    const int rc = single_reserve(ctx, n, &b);
+    if (rc != LOCGPU_OK) return rc;
     const char* base = (const char*)src;
     for (size_t i = 0; i < n; ++i) { b->h_src[i] = float4{0.f, 0.f, 0.f, 0.f}; std::memcpy(&b->h_src[i], base + i * stride_bytes, 12); }
     b->counts[0] = (int)n;
     LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_src, b->h_src, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_counts, b->counts.data(), sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    *out = b;
+    return LOCGPU_OK;
+}
+
+// Same, from a cloud that is already in HBM (the w lane carries the intensity; no kernel of the matcher reads it).
+static int single_batch_dev(locgpu_ctx* ctx, const float4* d_src, size_t n, locgpu_batch** out) {
+    locgpu_batch* b = nullptr;
+    const int rc = single_reserve(ctx, n, &b);
+    if (rc != LOCGPU_OK) return rc;
+    b->counts[0] = (int)n;
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_src, d_src, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_counts, b->counts.data(), sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     *out = b;
     return LOCGPU_OK;
@@ -793,21 +817,21 @@ static int check_ndt(locgpu_ctx* ctx, GnParams& prm) {
 
 extern "C" {
 
-int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, const locgpu_ndt_opts* opts) {
-    if (!ctx) return LOCGPU_ERR_INVALID;
-    if (!pts || n == 0 || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: empty cloud or stride < 12");
+// Target ingest from a cloud already in HBM. `host` (optional) = the same points on the host; the incremental method's
+// LRU bookkeeping walks them there and they are fetched when absent.
+static int ndt_set_target_dev(locgpu_ctx* ctx, const float4* d_pts, const float4* host, size_t n, const locgpu_ndt_opts* opts) {
     locgpu_ndt_opts o;
     if (opts) o = *opts; else locgpu_ndt_opts_default(&o);
     if (!(o.voxel_size > 0.0) || (o.nearby_type != 0 && o.nearby_type != 1) || (o.method != 1 && o.method != 2) || (o.method == 2 && o.capacity < 2))
         return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: bad options");
-    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
-    std::vector<float4> host(n);
-    const char* base = (const char*)pts;
-    for (size_t i = 0; i < n; ++i) { host[i] = float4{0.f, 0.f, 0.f, 0.f}; std::memcpy(&host[i], base + i * stride_bytes, 12); }
-    float4* d_pts = nullptr;
-    LOCGPU_HIP(ctx, hipMalloc((void**)&d_pts, n * sizeof(float4)));
-    if (!hip_ok(ctx, hipMemcpy(d_pts, host.data(), n * sizeof(float4), hipMemcpyHostToDevice), "H2D map")) { (void)hipFree(d_pts); return LOCGPU_ERR_NO_DEVICE; }
     if (o.method == 2) {
+        std::vector<float4> fetched;
+        if (!host) {
+            fetched.resize(n);
+            LOCGPU_HIP(ctx, hipMemcpyAsync(fetched.data(), d_pts, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+            LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            host = fetched.data();
+        }
         // incremental: keep the voxel set unless the grid itself changed
         if (ctx->inc && (ctx->ndt_opts.method != 2 || ctx->ndt_opts.voxel_size != o.voxel_size || ctx->ndt_opts.capacity != o.capacity)) {
             inc_ndt_destroy(ctx->inc);
@@ -815,8 +839,7 @@ int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
         }
         if (!ctx->inc) ctx->inc = inc_ndt_create((size_t)o.capacity, o.voxel_size);
         bool bad = false;
-        const hipError_t e = inc_ndt_ingest(*ctx->inc, host.data(), d_pts, n, ctx->stream, &bad);
-        (void)hipFree(d_pts);
+        const hipError_t e = inc_ndt_ingest(*ctx->inc, host, d_pts, n, ctx->stream, &bad);
         if (e != hipSuccess) { hip_ok(ctx, e, "inc_ndt_ingest"); return LOCGPU_ERR_NO_DEVICE; }
         ctx->ndt_opts = o;
         ctx->target_epoch++;
@@ -827,7 +850,6 @@ int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
     if (!ctx->ndt) ctx->ndt = new NdtTable();
     bool bad_key = false;
     const hipError_t e = ndt_build(*ctx->ndt, d_pts, n, o.voxel_size, o.min_pts_in_voxel, ctx->stream, &bad_key);
-    (void)hipFree(d_pts);
     if (e != hipSuccess) { ndt_free(ctx); hip_ok(ctx, e, "ndt_build"); return LOCGPU_ERR_NO_DEVICE; }
     if (bad_key) { ndt_free(ctx); return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: a point lies outside the +-2^20-voxel key range"); }
     ctx->ndt->res_outlier_th = o.res_outlier_th;
@@ -835,6 +857,22 @@ int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
     ctx->ndt_opts = o;
     ctx->target_epoch++;
     return LOCGPU_OK;
+}
+
+int locgpu_ndt_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, const locgpu_ndt_opts* opts) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!pts || n == 0 || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: empty cloud or stride < 12");
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<float4> host(n);
+    const char* base = (const char*)pts;
+    for (size_t i = 0; i < n; ++i) { host[i] = float4{0.f, 0.f, 0.f, 0.f}; std::memcpy(&host[i], base + i * stride_bytes, 12); }
+    float4* d_pts = nullptr;
+    LOCGPU_HIP(ctx, hipMalloc((void**)&d_pts, n * sizeof(float4)));
+    if (!hip_ok(ctx, hipMemcpy(d_pts, host.data(), n * sizeof(float4), hipMemcpyHostToDevice), "H2D map")) { (void)hipFree(d_pts); return LOCGPU_ERR_NO_DEVICE; }
+    const int rc = ndt_set_target_dev(ctx, d_pts, host.data(), n, opts);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_pts);
+    return rc;
 }
 
 int locgpu_ndt_target_info(const locgpu_ctx* ctx, int64_t out[3]) {
@@ -886,4 +924,55 @@ int locgpu_ndt_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_b
     return run_align(ctx, b, init_pose, prm, 0, 1.0f, true, out_pose, stats);
 }
 
+// ---- matcher entry points on clouds resident in HBM (cloud_filters.hpp) ----
+int locgpu_icp_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* target) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!target || target->ctx != ctx) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target_cloud: bad cloud");
+    if (target->n == 0) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: empty cloud or stride < 12");
+    // The mean-split tree is built on the host (its float32 sums are sequential by definition, kdtree.cpp:94-123), so the
+    // cloud crosses PCIe once in each direction: 16 B/point down, the packed tree (≈24 B/point) up.
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    float4* stage = nullptr;
+    if (!hip_ok(ctx, cloud_stage(ctx, target->n, &stage), "pinned staging")) return LOCGPU_ERR_OOM;
+    LOCGPU_HIP(ctx, hipMemcpyAsync(stage, target->d, target->n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return locgpu_icp_set_target(ctx, stage, target->n, sizeof(float4));
+}
+
+int locgpu_ndt_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* target, const locgpu_ndt_opts* opts) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!target || target->ctx != ctx) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target_cloud: bad cloud");
+    if (target->n == 0) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: empty cloud or stride < 12");
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    const int rc = ndt_set_target_dev(ctx, target->d, nullptr, target->n, opts);
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
+int locgpu_icp_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const double init_pose[7], const locgpu_icp_opts* opts, double out_pose[7],
+                           locgpu_align_stats* stats) {
+    GnParams prm;
+    int k;
+    float alpha_eff;
+    int rc = check_icp(ctx, opts, prm, k, alpha_eff);
+    if (rc != LOCGPU_OK) return rc;
+    if (!src || src->ctx != ctx || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "icp_align_cloud: bad arguments");
+    locgpu_batch* b = nullptr;
+    rc = single_batch_dev(ctx, src->d, src->n, &b);
+    if (rc != LOCGPU_OK) return rc;
+    return run_align(ctx, b, init_pose, prm, k, alpha_eff, false, out_pose, stats);
+}
+
+int locgpu_ndt_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const double init_pose[7], double out_pose[7], locgpu_align_stats* stats) {
+    GnParams prm;
+    int rc = check_ndt(ctx, prm);
+    if (rc != LOCGPU_OK) return rc;
+    if (!src || src->ctx != ctx || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_cloud: bad arguments");
+    locgpu_batch* b = nullptr;
+    rc = single_batch_dev(ctx, src->d, src->n, &b);
+    if (rc != LOCGPU_OK) return rc;
+    return run_align(ctx, b, init_pose, prm, 0, 1.0f, true, out_pose, stats);
+}
+
 }  // extern "C"
+

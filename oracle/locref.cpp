@@ -27,6 +27,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "locref_filters.hpp"
 #include "locref_kdtree.hpp"
 #include "locref_math.hpp"
 
@@ -782,4 +783,44 @@ void locref_transform_cloud_f32(const double pose[7], const float* in, size_t n,
     }
 }
 
+// ---- cloud filters either side of the matcher (locref_filters.hpp); points are float32 [n][4] = x, y, z, intensity ----
+size_t locref_remove_nan(const float* in, size_t n, int is_dense, float* out) {
+    return RemoveNaN((const PointXYZI*)in, n, is_dense != 0, (PointXYZI*)out);
+}
+size_t locref_crop_box(const float* in, size_t n, int is_dense, const float mn[3], const float mx[3], float* out) {
+    return CropBox((const PointXYZI*)in, n, is_dense != 0, mn, mx, (PointXYZI*)out);
+}
+void locref_box_edges(const float step[3], const float origin[3], float mn[3], float mx[3]) { BoxEdges(step, origin, mn, mx); }
+// info[0] = status, info[1..3] = min_b, info[4..6] = div_b
+size_t locref_voxel_grid(const float* in, size_t n, int is_dense, float leaf, int order, float* out, int info[7]) {
+    VoxelGridInfo I;
+    const size_t m = VoxelGrid((const PointXYZI*)in, n, is_dense != 0, leaf, order, (PointXYZI*)out, &I);
+    if (info) {
+        info[0] = I.status;
+        for (int a = 0; a < 3; ++a) { info[1 + a] = I.min_b[a]; info[4 + a] = I.div_b[a]; }
+    }
+    return m;
+}
+void locref_transform_cloud_f64(const double pose[7], const float* in, size_t n, int is_dense, float* out) {
+    const SE3 T = se3_from_array(pose);
+    const M3 R = rotation_matrix(T);
+    double m[12];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) m[4 * r + c] = R(r, c);
+    }
+    m[3] = T.t.x; m[7] = T.t.y; m[11] = T.t.z;
+    TransformCloudF64((const PointXYZI*)in, n, is_dense != 0, m, (PointXYZI*)out);
+}
+void* locref_localmap_create(size_t num_kfs, float leaf, int order) {
+    LocalMap* m = new LocalMap();
+    m->num_kfs = num_kfs; m->leaf = leaf; m->order = order;
+    return m;
+}
+void locref_localmap_destroy(void* h) { delete (LocalMap*)h; }
+void locref_localmap_add_keyframe(void* h, const float* pts, size_t n, int is_dense) { ((LocalMap*)h)->AddKeyframe((const PointXYZI*)pts, n, is_dense != 0); }
+size_t locref_localmap_size(void* h) { return ((LocalMap*)h)->map.size(); }
+int locref_localmap_dense(void* h) { return ((LocalMap*)h)->map_dense ? 1 : 0; }
+void locref_localmap_copy(void* h, float* out) { LocalMap* m = (LocalMap*)h; std::memcpy(out, m->map.data(), m->map.size() * sizeof(PointXYZI)); }
+
 }  // extern "C"
+

@@ -19,7 +19,7 @@ TRACE_W = 50  # H36 B6 dx6 eff ok
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("locref.cpp", "locref_math.hpp", "locref_kdtree.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("locref.cpp", "locref_math.hpp", "locref_kdtree.hpp", "locref_filters.hpp")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liblocref.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -59,6 +59,17 @@ def lib():
             "locref_ndt_dump": (_sz, [_vp, _vp, _vp, _vp, _sz]),
             "locref_ndt_align": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _i, _vp]),
             "locref_transform_cloud_f32": (None, [_vp, _vp, _sz, _sz, _vp, _sz]),
+            "locref_remove_nan": (_sz, [_vp, _sz, _i, _vp]),
+            "locref_crop_box": (_sz, [_vp, _sz, _i, _vp, _vp, _vp]),
+            "locref_box_edges": (None, [_vp, _vp, _vp, _vp]),
+            "locref_voxel_grid": (_sz, [_vp, _sz, _i, _f, _i, _vp, _vp]),
+            "locref_transform_cloud_f64": (None, [_vp, _vp, _sz, _i, _vp]),
+            "locref_localmap_create": (_vp, [_sz, _f, _i]),
+            "locref_localmap_destroy": (None, [_vp]),
+            "locref_localmap_add_keyframe": (None, [_vp, _vp, _sz, _i]),
+            "locref_localmap_size": (_sz, [_vp]),
+            "locref_localmap_dense": (_i, [_vp]),
+            "locref_localmap_copy": (None, [_vp, _vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -252,3 +263,84 @@ class Ndt:
         if st != 1:
             out = written
         return dict(pose=out, status=st, iters=iters.value, trace=trace[:min(iters.value, trace_cap)])
+
+
+# ---------------------------------------------------------------------------------------------
+# Cloud filters either side of the matcher (locref_filters.hpp). Clouds are float32 [n, 4] = x, y, z, intensity.
+SORT_STD, SORT_STABLE = 0, 1
+
+
+def _xyzi(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] == 4
+    return a
+
+
+def remove_nan(cloud, is_dense):
+    """pcl::removeNaNFromPointCloud as RemoveNanPoint calls it (point_cloud_utils.h:13-20)."""
+    cloud = _xyzi(cloud)
+    out = np.empty_like(cloud)
+    m = lib().locref_remove_nan(cloud.ctypes.data, len(cloud), int(is_dense), out.ctypes.data)
+    return out[:m].copy()
+
+
+def box_edges(step, origin):
+    """BoxFilter::CalculateEdge (box_filter.cpp:59-66): float32 (min, max) corners."""
+    step, origin = np.asarray(step, np.float32), np.asarray(origin, np.float32)
+    mn, mx = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    lib().locref_box_edges(step.ctypes.data, origin.ctypes.data, mn.ctypes.data, mx.ctypes.data)
+    return mn, mx
+
+
+def crop_box(cloud, is_dense, mn, mx):
+    """BoxFilter::Filter → pcl::CropBox (box_filter.cpp:25-32)."""
+    cloud = _xyzi(cloud)
+    mn, mx = np.ascontiguousarray(mn, np.float32), np.ascontiguousarray(mx, np.float32)
+    out = np.empty_like(cloud)
+    m = lib().locref_crop_box(cloud.ctypes.data, len(cloud), int(is_dense), mn.ctypes.data, mx.ctypes.data, out.ctypes.data)
+    return out[:m].copy()
+
+
+def voxel_grid(cloud, is_dense, leaf, order=SORT_STD, with_info=False):
+    """VoxelFilter::Filter → pcl::VoxelGrid (voxel_filter.cpp:19-25). Returns centroids in voxel-index order."""
+    cloud = _xyzi(cloud)
+    out = np.empty_like(cloud)
+    info = np.zeros(7, np.int32)
+    m = lib().locref_voxel_grid(cloud.ctypes.data, len(cloud), int(is_dense), float(leaf), int(order), out.ctypes.data, info.ctypes.data)
+    res = out[:m].copy()
+    if with_info:
+        return res, dict(status=int(info[0]), min_b=info[1:4].copy(), div_b=info[4:7].copy())
+    return res
+
+
+def transform_cloud_f64(pose, cloud, is_dense=True):
+    """pcl::transformPointCloud with a double 4x4 (lio.cpp:244,279): double arithmetic, float32 result."""
+    cloud = _xyzi(cloud)
+    out = np.empty_like(cloud)
+    lib().locref_transform_cloud_f64(_pose(pose).ctypes.data, cloud.ctypes.data, len(cloud), int(is_dense), out.ctypes.data)
+    return out
+
+
+class LocalMap:
+    """Keyframe branch of Lio::AddCloud (lio.cpp:268-306): the matching target after each keyframe."""
+
+    def __init__(self, num_kfs, leaf, order=SORT_STD):
+        self._h = lib().locref_localmap_create(int(num_kfs), float(leaf), int(order))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().locref_localmap_destroy(self._h)
+            self._h = None
+
+    def add_keyframe(self, cloud, is_dense=True):
+        cloud = _xyzi(cloud)
+        lib().locref_localmap_add_keyframe(self._h, cloud.ctypes.data, len(cloud), int(is_dense))
+
+    @property
+    def is_dense(self):
+        return bool(lib().locref_localmap_dense(self._h))
+
+    def cloud(self):
+        out = np.empty((lib().locref_localmap_size(self._h), 4), np.float32)
+        lib().locref_localmap_copy(self._h, out.ctypes.data)
+        return out

@@ -1,0 +1,223 @@
+"""GPU parity of the cloud filters either side of the matcher against oracle/locref_filters.hpp,
+through the C ABI (include/locgpu.h: locgpu_cloud_*, locgpu_voxel_filter / crop_box / remove_nan, locgpu_submap_*).
+
+Bars: point sets, counts and ORDER are exact. VoxelGrid centroids are bit-identical to the oracle summing in input order
+(SORT_STABLE — the order a stable sort gives, which is what the GPU's radix sort is); against the oracle's std::sort order
+(what PCL itself does, unpinned inside a voxel) they agree within float32 summation rounding."""
+import numpy as np
+import pytest
+
+from conftest import pose_delta
+
+pytestmark = pytest.mark.gpu
+
+EPS = float(np.finfo(np.float32).eps)
+
+
+def _rand_cloud(n, seed, scale=10.0):
+    rng = np.random.default_rng(seed)
+    c = (rng.normal(size=(n, 4)) * scale).astype(np.float32)
+    c[:, 3] = rng.uniform(0, 255, n).astype(np.float32)
+    return c
+
+
+def _scan_xyzi(synth, scan_id, **kw):
+    s = synth.make_scan(scan_id, **kw)
+    out = np.zeros((len(s), 4), np.float32)
+    out[:, :3] = s[:, :3]
+    out[:, 3] = (np.arange(len(s)) % 251).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("leaf", [0.3, 1.0, 2.5])
+def test_voxel_filter_bit_exact_vs_stable_oracle(gpu_ctx, locref, leaf):
+    c = _rand_cloud(200000, 1)
+    got, dense = gpu_ctx.voxel_filter(c, leaf)
+    ref = locref.voxel_grid(c, True, leaf, order=locref.SORT_STABLE)
+    assert dense and got.shape == ref.shape
+    assert np.array_equal(got, ref)
+    pcl_like = locref.voxel_grid(c, True, leaf, order=locref.SORT_STD)
+    assert np.abs(got - pcl_like).max() <= 256 * EPS * np.abs(c).max()
+
+
+def test_voxel_filter_on_scan_and_map(gpu_ctx, locref, synth):
+    scan = _scan_xyzi(synth, 5)  # full 115 200-pt scan, sensor frame
+    for leaf in (0.5, 0.1):
+        got, _ = gpu_ctx.voxel_filter(scan, leaf)
+        assert np.array_equal(got, locref.voxel_grid(scan, True, leaf, order=locref.SORT_STABLE))
+    m = synth.make_map(2_000_000)
+    mm = np.zeros((len(m), 4), np.float32)
+    mm[:, :3] = m[:, :3]
+    got, _ = gpu_ctx.voxel_filter(mm, 0.5)
+    ref = locref.voxel_grid(mm, True, 0.5, order=locref.SORT_STABLE)
+    assert np.array_equal(got, ref) and len(got) < len(mm)
+
+
+def test_voxel_filter_non_dense_and_edge_cases(gpu_ctx, locref, api):
+    c = _rand_cloud(50000, 2)
+    d = c.copy()
+    d[::7, 0] = np.nan
+    d[3::11, 2] = np.inf
+    d[5::13, 1] = -np.inf
+    got, dense = gpu_ctx.voxel_filter(d, 1.5, is_dense=False)
+    assert dense and np.array_equal(got, locref.voxel_grid(d, False, 1.5, order=locref.SORT_STABLE))
+    # not one finite point / empty cloud → empty result
+    got, _ = gpu_ctx.voxel_filter(np.full((100, 4), np.nan, np.float32), 1.0, is_dense=False)
+    assert len(got) == 0
+    got, _ = gpu_ctx.voxel_filter(np.zeros((0, 4), np.float32), 1.0)
+    assert len(got) == 0
+    # PCL's "leaf size is too small" rule: the input comes back unchanged, flag included
+    big = _rand_cloud(5000, 3, scale=100.0)
+    got, dense = gpu_ctx.voxel_filter(big, 0.01, is_dense=False)
+    assert np.array_equal(got, big) and not dense
+    ref, info = locref.voxel_grid(big, False, 0.01, with_info=True)
+    assert info["status"] == 1
+    # single point, all points in one voxel, negative coordinates
+    for cloud, leaf in ((c[:1], 1.0), (np.abs(c[:1000]) % 1.0, 2.0), (-np.abs(c[:1000]), 0.7)):
+        cloud = np.ascontiguousarray(cloud, np.float32)
+        got, _ = gpu_ctx.voxel_filter(cloud, leaf)
+        assert np.array_equal(got, locref.voxel_grid(cloud, True, leaf, order=locref.SORT_STABLE))
+    with pytest.raises(api.LocGpuError):
+        gpu_ctx.voxel_filter(c, 0.0)
+    with pytest.raises(api.LocGpuError):
+        gpu_ctx.voxel_filter(c, float("nan"))
+
+
+def test_crop_box_and_remove_nan_exact(gpu_ctx, locref):
+    c = _rand_cloud(300000, 4)
+    mn, mx = locref.box_edges([6, 5, 4], [1.25, -0.5, 0.125])
+    got, dense = gpu_ctx.crop_box(c, mn, mx)
+    assert dense and np.array_equal(got, locref.crop_box(c, True, mn, mx))
+    d = c.copy()
+    d[::5, 2] = np.nan
+    d[1::9, 0] = np.inf
+    # dense flag trusted: NaN coordinates pass every comparison and are kept
+    got, _ = gpu_ctx.crop_box(d, mn, mx, is_dense=True)
+    assert np.array_equal(got, locref.crop_box(d, True, mn, mx), equal_nan=True)
+    got, _ = gpu_ctx.crop_box(d, mn, mx, is_dense=False)
+    assert np.array_equal(got, locref.crop_box(d, False, mn, mx))
+    # bounds are inclusive
+    e = np.array([[1, 1, 1, 0], [2, 0, 0, 1], [-2, 0, 0, 2], [2.0001, 0, 0, 3]], np.float32)
+    got, _ = gpu_ctx.crop_box(e, [-2, -2, -2], [2, 2, 2])
+    assert [int(v) for v in got[:, 3]] == [0, 1, 2]
+    # removeNaN: dense clouds pass untouched, others keep the finite points in order
+    got, dn = gpu_ctx.remove_nan(d, True)
+    assert dn and np.array_equal(got, d, equal_nan=True)
+    got, dn = gpu_ctx.remove_nan(d, False)
+    assert dn and np.array_equal(got, locref.remove_nan(d, False))
+    got, _ = gpu_ctx.crop_box(c, [100, 100, 100], [101, 101, 101])
+    assert len(got) == 0
+
+
+def test_resident_pipeline_matches_host_pipeline(gpu_ctx, locref, synth, api, small_world):
+    """Loc::Update's front (loc.cpp:217-224) on a resident cloud: removeNaN → voxel filter → ScanMatch, one upload."""
+    scan = _scan_xyzi(synth, 3, crop_half=36.0)
+    scan[::97, 1] = np.nan
+    raw = api.Cloud(gpu_ctx, scan, is_dense=False)
+    assert raw.info == (len(scan), False)
+    filt = raw.remove_nan().voxel_filter(0.5)
+    ref = locref.voxel_grid(locref.remove_nan(scan, False), True, 0.5, order=locref.SORT_STABLE)
+    assert np.array_equal(filt.download(), ref) and filt.is_dense
+    # match the filtered scan: resident path == host-pointer path == oracle
+    gpu_ctx.icp_set_target(small_world["map"])
+    opts = api.icp_opts(api.P2PLANE)
+    pose_dev, st_dev = gpu_ctx.icp_align_cloud(filt, small_world["init_pose"], opts)
+    pose_host, st_host = gpu_ctx.icp_align(ref, small_world["init_pose"], opts)
+    assert np.array_equal(pose_dev, pose_host) and st_dev["iterations"] == st_host["iterations"]
+    icp = locref.Icp(method=locref.P2PLANE)
+    icp.set_target(small_world["map"])
+    res = icp.align(ref, small_world["init_pose"])
+    dt, dr = pose_delta(pose_dev, res["pose"])
+    assert dt < 1e-8 and dr < 1e-8 and res["iters"] == st_dev["iterations"]
+    # NDT on resident clouds: target table built from a resident map
+    mapc = np.zeros((len(small_world["map"]), 4), np.float32)
+    mapc[:, :3] = small_world["map"][:, :3]
+    target = api.Cloud(gpu_ctx, mapc)
+    gpu_ctx.ndt_set_target_cloud(target)
+    pose_dev, st = gpu_ctx.ndt_align_cloud(filt, small_world["init_pose"])
+    gpu_ctx.ndt_set_target(small_world["map"])
+    pose_host, st2 = gpu_ctx.ndt_align(ref, small_world["init_pose"])
+    assert np.array_equal(pose_dev, pose_host) and st["iterations"] == st2["iterations"]
+    # ICP target from a resident cloud == from the host cloud
+    gpu_ctx.icp_set_target_cloud(target)
+    pose_t, _ = gpu_ctx.icp_align_cloud(filt, small_world["init_pose"], opts)
+    gpu_ctx.icp_set_target(small_world["map"])
+    pose_h, _ = gpu_ctx.icp_align_cloud(filt, small_world["init_pose"], opts)
+    assert np.array_equal(pose_t, pose_h)
+
+
+def test_cloud_transform_append_copy(gpu_ctx, locref, api):
+    c = _rand_cloud(100000, 6, scale=40.0)
+    q = np.array([0.05, -0.02, 0.6, 0.8])
+    pose = np.concatenate([q / np.linalg.norm(q), [12.5, -40.25, 1.0]])
+    a = api.Cloud(gpu_ctx, c)
+    t = a.transform(pose)
+    assert np.array_equal(t.download(), locref.transform_cloud_f64(pose, c))
+    a.transform(pose, out=a)  # in place
+    assert np.array_equal(a.download(), locref.transform_cloud_f64(pose, c))
+    d = c.copy()
+    d[::3, 1] = np.nan
+    nd = api.Cloud(gpu_ctx, d, is_dense=False)
+    assert np.array_equal(nd.transform(pose).download(), locref.transform_cloud_f64(pose, d, is_dense=False), equal_nan=True)
+    b = api.Cloud(gpu_ctx, c[:1000])
+    b.append(nd)
+    assert len(b) == 1000 + len(d) and not b.is_dense
+    assert np.array_equal(b.download(), np.concatenate([c[:1000], d]), equal_nan=True)
+    cp = b.copy()
+    assert np.array_equal(cp.download(), b.download(), equal_nan=True) and cp.info == b.info
+    e = api.Cloud(gpu_ctx)
+    assert e.info == (0, True) and len(e.download()) == 0
+    e.append(b)
+    assert len(e) == len(b)
+
+
+def test_submap_follows_lio_keyframe_branch(gpu_ctx, locref, synth, api):
+    """lio.cpp:268-306 over 6 keyframes with num_kfs = 3: transform, append / rebuild, in-place voxel filter."""
+    sub = api.Submap(gpu_ctx, 3, 0.5)
+    lm = locref.LocalMap(3, 0.5, order=locref.SORT_STABLE)
+    for s in range(6):
+        scan = _scan_xyzi(synth, 4 * s, subsample=30000)
+        true_pose, _ = synth.make_pose(4 * s)
+        sub.add_keyframe(api.Cloud(gpu_ctx, scan), true_pose)
+        kf = locref.transform_cloud_f64(true_pose, scan)
+        lm.add_keyframe(kf)
+        assert np.array_equal(sub.last_keyframe().download(), kf)
+        got = sub.cloud().download()
+        assert np.array_equal(got, lm.cloud())
+        assert sub.info == (min(s + 1, 3), len(got))
+    # the local map is a valid matching target: align the next scan against it, resident vs oracle
+    gpu_ctx.icp_set_target_cloud(sub.cloud())
+    scan = synth.make_scan(21, subsample=10000)
+    true_pose, init_pose = synth.make_pose(21)
+    opts = api.icp_opts(api.P2PLANE)
+    pose, st = gpu_ctx.icp_align(scan, init_pose, opts)
+    icp = locref.Icp(method=locref.P2PLANE)
+    icp.set_target(lm.cloud()[:, :3])
+    res = icp.align(scan, init_pose)
+    dt, dr = pose_delta(pose, res["pose"])
+    assert dt < 1e-8 and dr < 1e-8 and st["iterations"] == res["iters"]
+    # world-frame keyframes (pose = None) take the same path
+    sub2 = api.Submap(gpu_ctx, 2, 1.0)
+    lm2 = locref.LocalMap(2, 1.0, order=locref.SORT_STABLE)
+    for s in range(3):
+        kf = _rand_cloud(20000, 40 + s, scale=8.0)
+        sub2.add_keyframe(api.Cloud(gpu_ctx, kf))
+        lm2.add_keyframe(kf)
+        assert np.array_equal(sub2.cloud().download(), lm2.cloud())
+
+
+def test_filter_error_paths(gpu_ctx, api):
+    other = api.Context(0)
+    try:
+        a = api.Cloud(gpu_ctx, _rand_cloud(10, 1))
+        b = api.Cloud(other)
+        with pytest.raises(api.LocGpuError):
+            a.voxel_filter(1.0, out=b)  # clouds of different contexts
+        with pytest.raises(api.LocGpuError):
+            other.icp_align_cloud(a, np.array([0, 0, 0, 1, 0, 0, 0.0]), api.icp_opts(api.P2PLANE))
+        with pytest.raises(api.LocGpuError):
+            gpu_ctx.icp_set_target_cloud(api.Cloud(gpu_ctx))  # empty target
+        with pytest.raises(api.LocGpuError):
+            api.Submap(gpu_ctx, 0, 0.5)
+    finally:
+        other.close()
