@@ -8,7 +8,7 @@
 //   LocUtils/common/point_types.h (PointType = pcl::PointXYZI :18, PointCloudType :19, CloudPtr :20).
 // * In this repository's image none of those libraries exist, so the façade is compiled and tested with
 //   -DLOCGPU_FACADE_STANDALONE against the layout-compatible minimal types below: the façade only ever touches
-//   `cloud->points.data()/size()`, `sizeof(PointType)`, `pose.data()` (7 doubles: quaternion xyzw + translation, the
+//   `cloud->points.data()/size()/resize()`, `is_dense`, `width`, `height`, `sizeof(PointType)`, `pose.data()` (7 doubles: quaternion xyzw + translation, the
 //   Sophus::SE3d::data() order), `H.data()` and `B.data()`.
 #pragma once
 
@@ -29,10 +29,13 @@ struct alignas(16) PointType {  // pcl::PointXYZI: 32 bytes, x y z at 0/4/8, int
 };
 static_assert(sizeof(PointType) == 32, "pcl::PointXYZI layout");
 
-struct PointCloudType {
+struct PointCloudType {  // the members of pcl::PointCloud the façade touches
     std::vector<PointType> points;
+    unsigned width = 0, height = 0;
+    bool is_dense = true;
     std::size_t size() const { return points.size(); }
     bool empty() const { return points.empty(); }
+    void clear() { points.clear(); width = 0; height = 0; }
     using Ptr = std::shared_ptr<PointCloudType>;
 };
 using CloudPtr = PointCloudType::Ptr;

@@ -221,3 +221,36 @@ def test_filter_error_paths(gpu_ctx, api):
             api.Submap(gpu_ctx, 0, 0.5)
     finally:
         other.close()
+
+
+@pytest.mark.parametrize("dense", [1, 0])
+def test_cpp_facade_filters(locref, synth, tmp_path, dense):
+    """LocUtils::VoxelFilter / BoxFilter / gpu::RemoveNanPoint (loc_lib_amd/host) driven like Loc::Update and ResetLocalMap."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "cpp", "facade_filters")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    cloud = _scan_xyzi(synth, 9)
+    cloud[::53, 2] = np.nan
+    cloud.tofile(tmp_path / "in.bin")
+    origin, half, leaf = (3.5, -2.25, 0.5), 20.0, 0.5
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(dense), str(leaf), *[str(v) for v in origin], str(half), str(tmp_path / "out")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    tok = r.stdout.split()
+    m_scan, m_box = int(tok[0]), int(tok[1])
+    edge = np.array([float(t) for t in tok[2:8]], np.float32)
+    scan = np.fromfile(str(tmp_path / "out.scan.bin"), np.float32).reshape(-1, 4)
+    box = np.fromfile(str(tmp_path / "out.box.bin"), np.float32).reshape(-1, 4)
+    assert len(scan) == m_scan and len(box) == m_box
+    mn, mx = locref.box_edges([half] * 3, origin)
+    assert np.array_equal(edge[0::2], mn) and np.array_equal(edge[1::2], mx)
+    assert np.array_equal(box, locref.crop_box(cloud, bool(dense), mn, mx), equal_nan=True)
+    no_nan = locref.remove_nan(cloud, bool(dense))
+    if dense:
+        # a cloud flagged dense is never tested: the NaNs survive removeNaN and reach VoxelGrid, whose index arithmetic on
+        # NaN is undefined in PCL — only the finite voxels are comparable, so just check the call completed
+        assert int(tok[8]) == 1
+    else:
+        want = locref.voxel_grid(no_nan, True, leaf, order=locref.SORT_STABLE)
+        assert np.array_equal(scan, want) and int(tok[8]) == 1
