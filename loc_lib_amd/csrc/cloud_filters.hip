@@ -32,33 +32,30 @@ namespace {
 
 constexpr int kFB = 256;
 
-__device__ __forceinline__ uint32_t f2ord(float f) {  // monotone float → uint map (for atomicMin/atomicMax)
-    const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
 __device__ __forceinline__ bool finite3(const float4& p) { return isfinite(p.x) && isfinite(p.y) && isfinite(p.z); }
 
-__global__ void voxel_init_kernel(VoxelParams* P, float inv_leaf) {
-    for (int a = 0; a < 3; ++a) { P->min_enc[a] = f2ord(FLT_MAX); P->max_enc[a] = f2ord(-FLT_MAX); }
-    P->status = 0;
-    P->n_out = 0;
-    P->inv_leaf = inv_leaf;
-}
+// getMinMax3D: bounding box of the (finite, unless the cloud is flagged dense) points. Every block writes one partial box;
+// the set-up kernel folds them (same-address atomics from thousands of waves serialise at ~10 ns each).
+constexpr int kMinMaxBlocks = 1024;
 
-// getMinMax3D: bounding box of the (finite, unless the cloud is flagged dense) points.
-__global__ __launch_bounds__(kFB) void minmax_kernel(const float4* __restrict__ pts, size_t n, int dense, VoxelParams* P) {
+__global__ __launch_bounds__(kFB) void minmax_kernel(const float4* __restrict__ pts, size_t n, int dense, float* __restrict__ partial) {
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (size_t i = (size_t)blockIdx.x * kFB + threadIdx.x; i < n; i += (size_t)gridDim.x * kFB) {
-        const float4 p = pts[i];
-        if (!dense && !finite3(p)) continue;
+    const size_t stride = (size_t)gridDim.x * kFB;
+    size_t i = (size_t)blockIdx.x * kFB + threadIdx.x;
+    auto take = [&](const float4& p) {
+        if (!dense && !finite3(p)) return;
         const float c[3] = {p.x, p.y, p.z};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             mn[a] = c[a] < mn[a] ? c[a] : mn[a];
             mx[a] = c[a] > mx[a] ? c[a] : mx[a];
         }
+    };
+    for (; i + 3 * stride < n; i += 4 * stride) {  // four independent loads in flight per thread
+        const float4 p0 = pts[i], p1 = pts[i + stride], p2 = pts[i + 2 * stride], p3 = pts[i + 3 * stride];
+        take(p0); take(p1); take(p2); take(p3);
     }
+    for (; i < n; i += stride) take(pts[i]);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -67,20 +64,50 @@ __global__ __launch_bounds__(kFB) void minmax_kernel(const float4* __restrict__ 
             mx[a] = o2 > mx[a] ? o2 : mx[a];
         }
     }
+    __shared__ float s_box[kFB / 64][6];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&P->min_enc[a], f2ord(mn[a]));
-            atomicMax(&P->max_enc[a], f2ord(mx[a]));
+        for (int a = 0; a < 3; ++a) { s_box[wave][a] = mn[a]; s_box[wave][3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s_box[0][threadIdx.x];
+        for (int w = 1; w < kFB / 64; ++w) {
+            const float o = s_box[w][threadIdx.x];
+            v = threadIdx.x < 3 ? (o < v ? o : v) : (o > v ? o : v);
         }
+        partial[blockIdx.x * 6 + threadIdx.x] = v;
     }
 }
 
 // VoxelGrid::applyFilter's set-up: overflow test, min_b_, div_b_, divb_mul_ (voxel_grid.hpp), all in its float32/int arithmetic.
-__global__ void voxel_setup_kernel(VoxelParams* P) {
-    const float inv = P->inv_leaf;
-    float mn[3], mx[3];
-    for (int a = 0; a < 3; ++a) { mn[a] = ord2f(P->min_enc[a]); mx[a] = ord2f(P->max_enc[a]); }
+// One 64-thread block: lanes fold the per-block boxes, lane 0 does the scalar part.
+__global__ __launch_bounds__(64) void voxel_setup_kernel(VoxelParams* P, const float* __restrict__ partial, int n_partial, float inv_leaf) {
+    float box[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int b = threadIdx.x; b < n_partial; b += 64) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = partial[b * 6 + a], hi = partial[b * 6 + 3 + a];
+            box[a] = lo < box[a] ? lo : box[a];
+            box[3 + a] = hi > box[3 + a] ? hi : box[3 + a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o1 = __shfl_xor(box[a], off, 64), o2 = __shfl_xor(box[3 + a], off, 64);
+            box[a] = o1 < box[a] ? o1 : box[a];
+            box[3 + a] = o2 > box[3 + a] ? o2 : box[3 + a];
+        }
+    }
+    if (threadIdx.x != 0) return;
+    const float inv = inv_leaf;
+    const float* mn = box;
+    const float* mx = box + 3;
+    P->inv_leaf = inv;
+    P->n_out = 0;
+    P->status = 0;
     if (mn[0] > mx[0]) { P->status = 2; return; }  // no finite point at all
     const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
     if ((double)dx * (double)dy * (double)dz > 2147483647.0) { P->status = 1; return; }
@@ -118,41 +145,115 @@ __global__ __launch_bounds__(kFB) void voxel_head_kernel(const uint32_t* __restr
     head[i] = (valid && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
 }
 
-// One thread per run of equal keys: CentroidPoint's float32 running sums in sorted (= input) order, then one division each.
-__global__ __launch_bounds__(kFB) void voxel_centroid_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ keys,
-                                                             const uint32_t* __restrict__ vals, const uint32_t* __restrict__ head,
-                                                             const uint32_t* __restrict__ rank, size_t n, float4* __restrict__ out, VoxelParams* P) {
+// start[v] = sorted position of voxel v's first point; start[n_voxels] = number of valid points.
+__global__ __launch_bounds__(kFB) void voxel_starts_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ head,
+                                                           const uint32_t* __restrict__ rank, size_t n, int dense, uint32_t* __restrict__ start,
+                                                           VoxelParams* P) {
     const size_t i = (size_t)blockIdx.x * kFB + threadIdx.x;
     if (i >= n) return;
-    if (i == n - 1) P->n_out = rank[i] + head[i];
-    if (!head[i]) return;
-    const uint32_t k = keys[i];
+    const uint32_t h = head[i], r = rank[i];
+    if (h) start[r] = (uint32_t)i;
+    const uint32_t inv = P->invalid_key;
+    const bool valid = dense || keys[i] != inv;
+    const bool next_valid = i + 1 < n && (dense || keys[i + 1] != inv);
+    if (valid && !next_valid) {  // last valid point: closes the last run
+        start[r + h] = (uint32_t)(i + 1);
+        P->n_out = r + h;
+    }
+}
+
+// One thread per voxel: CentroidPoint's float32 running sums in sorted (= input) order, then one division each. The gathers
+// of a run do not depend on the sums, so they are issued four at a time.
+__global__ __launch_bounds__(kFB) void voxel_centroid_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ vals,
+                                                             const uint32_t* __restrict__ start, uint32_t n_voxels, float4* __restrict__ out) {
+    const uint32_t v = blockIdx.x * kFB + threadIdx.x;
+    if (v >= n_voxels) return;
+    const uint32_t b = start[v], e = start[v + 1];
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-    size_t j = i;
-    do {
+    uint32_t j = b;
+    for (; j + 4 <= e; j += 4) {
+        const uint32_t i0 = vals[j], i1 = vals[j + 1], i2 = vals[j + 2], i3 = vals[j + 3];
+        const float4 p0 = pts[i0], p1 = pts[i1], p2 = pts[i2], p3 = pts[i3];
+        sx += p0.x; sy += p0.y; sz += p0.z; si += p0.w;
+        sx += p1.x; sy += p1.y; sz += p1.z; si += p1.w;
+        sx += p2.x; sy += p2.y; sz += p2.z; si += p2.w;
+        sx += p3.x; sy += p3.y; sz += p3.z; si += p3.w;
+    }
+    for (; j < e; ++j) {
         const float4 p = pts[vals[j]];
         sx += p.x; sy += p.y; sz += p.z; si += p.w;
-        ++j;
-    } while (j < n && keys[j] == k);
-    const float cnt = (float)(j - i);
-    out[rank[i]] = float4{sx / cnt, sy / cnt, sz / cnt, si / cnt};
+    }
+    const float cnt = (float)(e - b);
+    out[v] = float4{sx / cnt, sy / cnt, sz / cnt, si / cnt};
 }
 
-// CropBox::applyFilter (identity transform): inclusive bounds, written as PCL's "outside" test so that NaN behaves alike.
-__global__ __launch_bounds__(kFB) void crop_flag_kernel(const float4* __restrict__ pts, size_t n, int dense, float mnx, float mny, float mnz, float mxx,
-                                                        float mxy, float mxz, unsigned char* __restrict__ flags) {
-    const size_t i = (size_t)blockIdx.x * kFB + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pts[i];
-    const bool skip = !dense && !finite3(p);
-    const bool outside = (p.x < mnx || p.y < mny || p.z < mnz) || (p.x > mxx || p.y > mxy || p.z > mxz);
-    flags[i] = (!skip && !outside) ? 1 : 0;
+// ---- order-preserving stream compaction (CropBox, removeNaN): count per tile → exclusive scan of the tile counts →
+// scatter with the predicate re-evaluated. 16 B read twice + 16 B written per survivor; no flag array, no atomics.
+struct CropPred {  // CropBox::applyFilter (identity transform): inclusive bounds, written as PCL's "outside" test so NaN behaves alike
+    float mnx, mny, mnz, mxx, mxy, mxz;
+    int dense;
+    __device__ __forceinline__ bool operator()(const float4& p) const {
+        const bool skip = !dense && !finite3(p);
+        const bool outside = (p.x < mnx || p.y < mny || p.z < mnz) || (p.x > mxx || p.y > mxy || p.z > mxz);
+        return !skip && !outside;
+    }
+};
+struct FinitePred {
+    __device__ __forceinline__ bool operator()(const float4& p) const { return finite3(p); }
+};
+
+constexpr int kTileItems = 4;                  // points per thread
+constexpr int kTile = kFB * kTileItems;        // points per block; item k of thread t is tile_base + k·kFB + t (coalesced)
+
+template <class Pred>
+__global__ __launch_bounds__(kFB) void compact_count_kernel(const float4* __restrict__ pts, size_t n, Pred pred, uint32_t* __restrict__ tile_count) {
+    const size_t base = (size_t)blockIdx.x * kTile;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k) {
+        const size_t i = base + (size_t)k * kFB + threadIdx.x;
+        if (i < n) c += pred(pts[i]) ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    __shared__ uint32_t s_c[kFB / 64];
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kFB / 64; ++w) t += s_c[w];
+        tile_count[blockIdx.x] = t;
+    }
 }
 
-__global__ __launch_bounds__(kFB) void finite_flag_kernel(const float4* __restrict__ pts, size_t n, unsigned char* __restrict__ flags) {
-    const size_t i = (size_t)blockIdx.x * kFB + threadIdx.x;
-    if (i >= n) return;
-    flags[i] = finite3(pts[i]) ? 1 : 0;
+template <class Pred>
+__global__ __launch_bounds__(kFB) void compact_scatter_kernel(const float4* __restrict__ pts, size_t n, Pred pred, const uint32_t* __restrict__ tile_offset,
+                                                              const uint32_t* __restrict__ tile_count, uint32_t n_tiles, float4* __restrict__ out,
+                                                              VoxelParams* P) {
+    const size_t base = (size_t)blockIdx.x * kTile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t s_seg[kTileItems * (kFB / 64)];
+    float4 p[kTileItems];
+    bool keep[kTileItems];
+    unsigned long long ballot[kTileItems];
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k) {
+        const size_t i = base + (size_t)k * kFB + threadIdx.x;
+        keep[k] = false;
+        if (i < n) { p[k] = pts[i]; keep[k] = pred(p[k]); }
+        ballot[k] = __ballot(keep[k]);
+        if (lane == 0) s_seg[k * (kFB / 64) + wave] = (uint32_t)__popcll(ballot[k]);
+    }
+    __syncthreads();
+    const uint32_t tile_base = tile_offset[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k) {
+        uint32_t seg = 0;
+        const int me = k * (kFB / 64) + wave;
+        for (int q = 0; q < kTileItems * (kFB / 64); ++q) seg += q < me ? s_seg[q] : 0u;
+        const uint32_t within = (uint32_t)__popcll(ballot[k] & ((1ull << lane) - 1ull));
+        if (keep[k]) out[tile_base + seg + within] = p[k];
+    }
+    if (blockIdx.x == n_tiles - 1 && threadIdx.x == 0) P->n_out = tile_base + tile_count[blockIdx.x];
 }
 
 struct M34 { double v[12]; };  // row-major 3×4, passed by value
@@ -189,7 +290,7 @@ hipError_t ensure_scratch(locgpu_ctx* ctx, size_t n) {
     if (!S->d_params) {
         LOCGPU_TRY(hipMalloc((void**)&S->d_params, sizeof(VoxelParams)));
         LOCGPU_TRY(hipHostMalloc((void**)&S->h_params, sizeof(VoxelParams)));
-        LOCGPU_TRY(hipMalloc((void**)&S->d_m12, 12 * sizeof(float)));
+        LOCGPU_TRY(hipMalloc((void**)&S->d_partial, kMinMaxBlocks * 6 * sizeof(float)));
     }
     if (n <= S->cap) return hipSuccess;
     const size_t cap = n + n / 4 + 1024;
@@ -200,21 +301,18 @@ hipError_t ensure_scratch(locgpu_ctx* ctx, size_t n) {
     }
     if (S->head) (void)hipFree(S->head);
     if (S->rank) (void)hipFree(S->rank);
-    if (S->flags) (void)hipFree(S->flags);
     if (S->temp) (void)hipFree(S->temp);
-    S->head = S->rank = nullptr; S->flags = nullptr; S->temp = nullptr; S->cap = 0;
+    S->head = S->rank = nullptr; S->temp = nullptr; S->cap = 0;
     for (int j = 0; j < 2; ++j) {
         LOCGPU_TRY(hipMalloc((void**)&S->keys[j], cap * sizeof(uint32_t)));
         LOCGPU_TRY(hipMalloc((void**)&S->vals[j], cap * sizeof(uint32_t)));
     }
     LOCGPU_TRY(hipMalloc((void**)&S->head, cap * sizeof(uint32_t)));
     LOCGPU_TRY(hipMalloc((void**)&S->rank, cap * sizeof(uint32_t)));
-    LOCGPU_TRY(hipMalloc((void**)&S->flags, cap));
-    size_t b1 = 0, b2 = 0, b3 = 0;
+    size_t b1 = 0, b2 = 0;
     LOCGPU_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, S->keys[0], S->keys[1], S->vals[0], S->vals[1], (int)cap, 0, 32, ctx->stream));
     LOCGPU_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, S->head, S->rank, (int)cap, ctx->stream));
-    LOCGPU_TRY(hipcub::DeviceSelect::Flagged(nullptr, b3, (float4*)nullptr, S->flags, (float4*)nullptr, &S->d_params->n_out, (int)cap, ctx->stream));
-    S->temp_bytes = std::max(b1, std::max(b2, b3)) + 256;
+    S->temp_bytes = std::max(b1, b2) + 256;
     LOCGPU_TRY(hipMalloc(&S->temp, S->temp_bytes));
     S->cap = cap;
     return hipSuccess;
@@ -267,11 +365,10 @@ void filters_free(locgpu_ctx* ctx) {
     }
     if (S->head) (void)hipFree(S->head);
     if (S->rank) (void)hipFree(S->rank);
-    if (S->flags) (void)hipFree(S->flags);
     if (S->temp) (void)hipFree(S->temp);
     if (S->d_params) (void)hipFree(S->d_params);
     if (S->h_params) (void)hipHostFree(S->h_params);
-    if (S->d_m12) (void)hipFree(S->d_m12);
+    if (S->d_partial) (void)hipFree(S->d_partial);
     if (S->d_tmp) (void)hipFree(S->d_tmp);
     if (S->h_stage) (void)hipHostFree(S->h_stage);
     delete S;
@@ -316,9 +413,9 @@ hipError_t voxel_filter_dev(locgpu_ctx* ctx, const locgpu_cloud* in, float leaf,
     hipStream_t s = ctx->stream;
     const int dense = in->is_dense;
     const float inv = 1.0f / leaf;  // inverse_leaf_size_
-    hipLaunchKernelGGL(voxel_init_kernel, dim3(1), dim3(1), 0, s, S->d_params, inv);
-    hipLaunchKernelGGL(minmax_kernel, dim3(std::min(blocks_for(n), 2048u)), dim3(kFB), 0, s, in->d, n, dense, S->d_params);
-    hipLaunchKernelGGL(voxel_setup_kernel, dim3(1), dim3(1), 0, s, S->d_params);
+    const int n_partial = (int)std::min<size_t>(blocks_for(n), (size_t)kMinMaxBlocks);
+    hipLaunchKernelGGL(minmax_kernel, dim3(n_partial), dim3(kFB), 0, s, in->d, n, dense, S->d_partial);
+    hipLaunchKernelGGL(voxel_setup_kernel, dim3(1), dim3(64), 0, s, S->d_params, S->d_partial, n_partial, inv);
     LOCGPU_TRY(hipGetLastError());
     LOCGPU_TRY(read_params(ctx));
     const VoxelParams hp = *S->h_params;
@@ -332,33 +429,41 @@ hipError_t voxel_filter_dev(locgpu_ctx* ctx, const locgpu_cloud* in, float leaf,
     hipLaunchKernelGGL(voxel_head_kernel, dim3(blocks_for(n)), dim3(kFB), 0, s, S->keys[1], n, S->d_params, dense, S->head);
     tb = S->temp_bytes;
     LOCGPU_TRY(hipcub::DeviceScan::ExclusiveSum(S->temp, tb, S->head, S->rank, (int)n, s));
-    LOCGPU_TRY(ensure_tmp(ctx, n));
-    hipLaunchKernelGGL(voxel_centroid_kernel, dim3(blocks_for(n)), dim3(kFB), 0, s, in->d, S->keys[1], S->vals[1], S->head, S->rank, n, S->d_tmp, S->d_params);
+    uint32_t* start = S->keys[0];  // free again after the sort; capacity ≥ n + 1
+    hipLaunchKernelGGL(voxel_starts_kernel, dim3(blocks_for(n)), dim3(kFB), 0, s, S->keys[1], S->head, S->rank, n, dense, start, S->d_params);
     LOCGPU_TRY(hipGetLastError());
     LOCGPU_TRY(read_params(ctx));
+    const uint32_t n_voxels = S->h_params->n_out;
+    LOCGPU_TRY(ensure_tmp(ctx, n_voxels));
+    if (n_voxels)
+        hipLaunchKernelGGL(voxel_centroid_kernel, dim3(blocks_for(n_voxels)), dim3(kFB), 0, s, in->d, S->vals[1], start, n_voxels, S->d_tmp);
+    LOCGPU_TRY(hipGetLastError());
     swap_in(ctx, out, S->h_params->n_out, 1);  // applyFilter: output.is_dense = true
     return hipSuccess;
 }
 
-static hipError_t select_flagged(locgpu_ctx* ctx, const locgpu_cloud* in, locgpu_cloud* out) {
-    FilterScratch* S = scratch(ctx);
+template <class Pred>
+static hipError_t compact(locgpu_ctx* ctx, const locgpu_cloud* in, Pred pred, locgpu_cloud* out) {
     const size_t n = in->n;
+    LOCGPU_TRY(ensure_scratch(ctx, n));
     LOCGPU_TRY(ensure_tmp(ctx, n));
+    FilterScratch* S = scratch(ctx);
+    hipStream_t s = ctx->stream;
+    const unsigned n_tiles = (unsigned)((n + kTile - 1) / kTile);
+    uint32_t *tile_count = S->head, *tile_offset = S->rank;
+    hipLaunchKernelGGL((compact_count_kernel<Pred>), dim3(n_tiles), dim3(kFB), 0, s, in->d, n, pred, tile_count);
     size_t tb = S->temp_bytes;
-    LOCGPU_TRY(hipcub::DeviceSelect::Flagged(S->temp, tb, in->d, S->flags, S->d_tmp, &S->d_params->n_out, (int)n, ctx->stream));
+    LOCGPU_TRY(hipcub::DeviceScan::ExclusiveSum(S->temp, tb, tile_count, tile_offset, (int)n_tiles, s));
+    hipLaunchKernelGGL((compact_scatter_kernel<Pred>), dim3(n_tiles), dim3(kFB), 0, s, in->d, n, pred, tile_offset, tile_count, n_tiles, S->d_tmp, S->d_params);
+    LOCGPU_TRY(hipGetLastError());
     LOCGPU_TRY(read_params(ctx));
-    swap_in(ctx, out, S->h_params->n_out, 1);  // Filter<PointT>::filter → copyPointCloud by indices; CropBox / removeNaN mark the result dense
+    swap_in(ctx, out, S->h_params->n_out, 1);  // Filter<PointT>::filter copies the survivors; CropBox / removeNaN mark the result dense
     return hipSuccess;
 }
 
 hipError_t crop_box_dev(locgpu_ctx* ctx, const locgpu_cloud* in, const float mn[3], const float mx[3], locgpu_cloud* out) {
-    const size_t n = in->n;
-    if (n == 0) { out->n = 0; out->is_dense = 1; return hipSuccess; }
-    LOCGPU_TRY(ensure_scratch(ctx, n));
-    FilterScratch* S = scratch(ctx);
-    hipLaunchKernelGGL(crop_flag_kernel, dim3(blocks_for(n)), dim3(kFB), 0, ctx->stream, in->d, n, in->is_dense, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], S->flags);
-    LOCGPU_TRY(hipGetLastError());
-    return select_flagged(ctx, in, out);
+    if (in->n == 0) { out->n = 0; out->is_dense = 1; return hipSuccess; }
+    return compact(ctx, in, CropPred{mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], in->is_dense}, out);
 }
 
 hipError_t remove_nan_dev(locgpu_ctx* ctx, const locgpu_cloud* in, locgpu_cloud* out) {
@@ -367,12 +472,7 @@ hipError_t remove_nan_dev(locgpu_ctx* ctx, const locgpu_cloud* in, locgpu_cloud*
         if (in->n == 0) { out->n = 0; out->is_dense = 1; }
         return e;
     }
-    const size_t n = in->n;
-    LOCGPU_TRY(ensure_scratch(ctx, n));
-    FilterScratch* S = scratch(ctx);
-    hipLaunchKernelGGL(finite_flag_kernel, dim3(blocks_for(n)), dim3(kFB), 0, ctx->stream, in->d, n, S->flags);
-    LOCGPU_TRY(hipGetLastError());
-    return select_flagged(ctx, in, out);
+    return compact(ctx, in, FinitePred{}, out);
 }
 
 hipError_t transform_dev(locgpu_ctx* ctx, const locgpu_cloud* in, const double pose[7], locgpu_cloud* out) {

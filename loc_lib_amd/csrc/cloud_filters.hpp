@@ -20,7 +20,6 @@ namespace locgpu {
 
 // Written by the setup kernel, read back by the host once per voxel filter.
 struct VoxelParams {
-    uint32_t min_enc[3], max_enc[3];  // order-preserving encodings of the float32 bounding box (atomicMin/Max targets)
     int32_t min_b[3], div_b[3], mul[3];
     uint32_t invalid_key;             // key given to non-finite points of a non-dense cloud (= number of cells)
     int32_t status;                   // 0 ok, 1 leaf too small (pass-through), 2 no finite point
@@ -34,12 +33,11 @@ struct FilterScratch {
     uint32_t* vals[2] = {nullptr, nullptr};
     uint32_t* head = nullptr;
     uint32_t* rank = nullptr;
-    unsigned char* flags = nullptr;
     void* temp = nullptr;
     size_t temp_bytes = 0;
     VoxelParams* d_params = nullptr;
     VoxelParams* h_params = nullptr;  // pinned
-    float* d_m12 = nullptr;
+    float* d_partial = nullptr;       // per-block bounding boxes of the min/max pass
     float4* d_tmp = nullptr;          // staging for in-place filters
     size_t tmp_cap = 0;
     float4* h_stage = nullptr;        // pinned host staging for upload/download

@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Measures the rows either side of the matcher on the GPU box:
+
+  filters   resident voxel filter / crop box / NaN removal on a 115 200-pt scan and on the 10 M-pt map, beside the CPU
+            oracle's time for the same call (1 thread), with the algorithmic bytes of DESIGN.md §3b
+  stream    BASELINE.json configs[4]: the Lio loop — per scan upload → removeNaN → voxel filter → ICP against the local map;
+            every `--kf-every` scans transform + submap update + target re-ingest — with a per-stage wall-time breakdown
+
+Prints one JSON object per section. The oracle is used only as the timed CPU baseline and the checker.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from loc_lib_amd import api, synth  # noqa: E402
+
+
+def xyzi(a):
+    out = np.zeros((len(a), 4), np.float32)
+    out[:, :3] = a[:, :3]
+    out[:, 3] = (np.arange(len(a)) % 251).astype(np.float32)
+    return out
+
+
+def timed(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+def sort_passes(cells):
+    bits = max(1, int(cells).bit_length())
+    return (bits + 7) // 8  # rocPRIM radix sort: 8-bit digits per pass (upper bound; its onesweep kernels may merge passes)
+
+
+def filters_section(ctx, locref, map_points, reps):
+    out = {}
+    scan = xyzi(synth.make_scan(7))
+    big = xyzi(synth.make_map(map_points))
+    for name, cloud, leaf in (("scan_115k_leaf0.5", scan, 0.5), ("map_%dM_leaf0.5" % (map_points // 1_000_000), big, 0.5)):
+        dev = api.Cloud(ctx, cloud)
+        res = api.Cloud(ctx)
+        t_gpu = timed(lambda: dev.voxel_filter(leaf, out=res), reps)
+        n_out = len(res)
+        t0 = time.perf_counter()
+        ref = locref.voxel_grid(cloud, True, leaf, order=locref.SORT_STABLE)
+        t_cpu = time.perf_counter() - t0
+        same = bool(np.array_equal(res.download(), ref))
+        ext = cloud[:, :3].max(0) - cloud[:, :3].min(0)
+        cells = np.prod(np.floor(ext / leaf) + 1)
+        n = len(cloud)
+        alg = n * (16 + 16 + 8 + 16 * sort_passes(cells) + 8 + 8 + 16) + n_out * 16
+        out["voxel_" + name] = dict(points=n, out_points=n_out, gpu_ms=t_gpu * 1e3, cpu_ms=t_cpu * 1e3, identical=same,
+                                    mpoints_per_s=n / t_gpu / 1e6, alg_bytes=int(alg), alg_GBs=alg / t_gpu / 1e9, frac_of_8TBs=alg / t_gpu / 8e12)
+        mn, mx = locref.box_edges([150, 150, 150], [10, -20, 0]) if n > 1_000_000 else locref.box_edges([30, 30, 30], [0, 0, 0])
+        t_gpu = timed(lambda: dev.crop_box(mn, mx, out=res), reps)
+        kept = len(res)
+        t0 = time.perf_counter()
+        ref = locref.crop_box(cloud, True, mn, mx)
+        t_cpu = time.perf_counter() - t0
+        alg = n * 16 + kept * 16  # every point read once, every survivor written once (the kernels read the input twice)
+        out["crop_" + name.split("_leaf")[0]] = dict(points=n, out_points=kept, gpu_ms=t_gpu * 1e3, cpu_ms=t_cpu * 1e3,
+                                                     identical=bool(np.array_equal(res.download(), ref)), mpoints_per_s=n / t_gpu / 1e6,
+                                                     alg_bytes=int(alg), alg_GBs=alg / t_gpu / 1e9, frac_of_8TBs=alg / t_gpu / 8e12)
+        # host-pointer one-shot (what VoxelFilter::Filter binds to): PCIe and staging included
+        t_host = timed(lambda: ctx.voxel_filter(cloud, leaf), max(1, reps // 4))
+        out["voxel_" + name]["host_pointer_ms"] = t_host * 1e3
+        dev.close()
+        res.close()
+    return out
+
+
+def stream_section(ctx, locref, n_scans, kf_every, num_kfs, scan_leaf, map_leaf, check):
+    """Lio::AddCloud (lio.cpp:206-306) with the matcher and the filters on the GPU; poses start from the perturbed truth."""
+    opts = api.icp_opts(api.P2PLANE)
+    sub = api.Submap(ctx, num_kfs, map_leaf)
+    lm = locref.LocalMap(num_kfs, map_leaf, order=locref.SORT_STABLE) if check else None
+    icp_ref = locref.Icp(method=locref.P2PLANE) if check else None
+    stage = dict(gen=0.0, upload=0.0, filter=0.0, match=0.0, keyframe=0.0, target=0.0)
+    poses, worst = [], 0.0
+    raw, filt = api.Cloud(ctx), api.Cloud(ctx)
+    n_map = 0
+    clock = time.perf_counter
+    for s in range(n_scans):
+        scan = xyzi(synth.make_scan(s))
+        truth, init = synth.make_pose(s)
+        t = clock()
+        raw.upload(scan, is_dense=False)
+        stage["upload"] += clock() - t
+        t = clock()
+        raw.remove_nan(out=filt)
+        filt.voxel_filter(scan_leaf, out=filt)
+        stage["filter"] += clock() - t
+        if s == 0:
+            pose, kf_src, kf_dense = truth, filt, True  # first frame (lio.cpp:238-256): the FILTERED scan at last_kf_pose_ seeds the map
+        else:
+            t = clock()
+            pose, st = ctx.icp_align_cloud(filt, init, opts)
+            stage["match"] += clock() - t
+            if check:
+                want = icp_ref.align(filt.download(), init)["pose"]
+                worst = max(worst, float(np.abs(pose - want).max()))
+            kf_src, kf_dense = raw, False  # later keyframes keep the RAW scan (lio.cpp:279)
+        if s % kf_every == 0:
+            t = clock()
+            sub.add_keyframe(kf_src, pose)
+            stage["keyframe"] += clock() - t
+            t = clock()
+            ctx.icp_set_target_cloud(sub.cloud())
+            stage["target"] += clock() - t
+            if check:
+                lm.add_keyframe(locref.transform_cloud_f64(pose, kf_src.download(), is_dense=kf_dense), is_dense=kf_dense)
+                icp_ref.set_target(lm.cloud()[:, :3])
+                assert np.array_equal(sub.cloud().download(), lm.cloud(), equal_nan=True)
+        poses.append(pose)
+        n_map = sub.info[1]
+    busy = sum(v for k, v in stage.items() if k != "gen")
+    return dict(scans=n_scans, kf_every=kf_every, num_kfs=num_kfs, scan_leaf=scan_leaf, map_leaf=map_leaf, local_map_points=n_map,
+                ms_per_scan={k: v / n_scans * 1e3 for k, v in stage.items() if k != "gen"}, scans_per_s=n_scans / busy,
+                checked_against_oracle=bool(check), max_pose_abs_diff=worst)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--map-points", type=int, default=10_000_000)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--scans", type=int, default=40)
+    ap.add_argument("--kf-every", type=int, default=5)
+    ap.add_argument("--num-kfs", type=int, default=10)
+    ap.add_argument("--scan-leaf", type=float, default=0.5)
+    ap.add_argument("--map-leaf", type=float, default=0.5)
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--only", choices=["filters", "stream"])
+    a = ap.parse_args()
+    from oracle import locref  # timed CPU baseline and checker only
+    api.build()
+    ctx = api.Context(0)
+    if a.only != "stream":
+        print(json.dumps({"filters": filters_section(ctx, locref, a.map_points, a.reps)}))
+    if a.only != "filters":
+        print(json.dumps({"stream": stream_section(ctx, locref, a.scans, a.kf_every, a.num_kfs, a.scan_leaf, a.map_leaf, not a.no_check)}))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
