@@ -254,3 +254,27 @@ def test_cpp_facade_filters(locref, synth, tmp_path, dense):
     else:
         want = locref.voxel_grid(no_nan, True, leaf, order=locref.SORT_STABLE)
         assert np.array_equal(scan, want) and int(tok[8]) == 1
+
+
+def test_golden_filter_fixture_gpu(gpu_ctx, api):
+    """Committed golden vectors (tests/golden/make_golden_filters.py, generated with the oracle in the build container)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "filters_small.npz"))
+    scan = g["scan"]
+    got, dense = gpu_ctx.remove_nan(scan, False)
+    assert dense and np.array_equal(got, g["no_nan"])
+    got, _ = gpu_ctx.voxel_filter(g["no_nan"], 0.4)
+    assert np.array_equal(got, g["voxel_stable"])
+    assert np.abs(got - g["voxel_std"]).max() <= 256 * EPS * np.abs(g["no_nan"]).max()
+    got, _ = gpu_ctx.voxel_filter(scan, 0.4, is_dense=False)
+    assert np.array_equal(got, g["voxel_nondense_stable"])
+    got, _ = gpu_ctx.crop_box(scan, g["box_min"], g["box_max"], is_dense=True)
+    assert np.array_equal(got, g["crop_dense"], equal_nan=True)
+    got, _ = gpu_ctx.crop_box(scan, g["box_min"], g["box_max"], is_dense=False)
+    assert np.array_equal(got, g["crop_nondense"])
+    sub = api.Submap(gpu_ctx, 3, 0.6)
+    for s in range(5):
+        sub.add_keyframe(api.Cloud(gpu_ctx, g["kf_scan_%d" % s]), g["kf_pose_%d" % s])
+        if s == 0:
+            assert np.array_equal(sub.last_keyframe().download(), g["kf_world_0"])
+        assert np.array_equal(sub.cloud().download(), g["local_map_%d" % s])
