@@ -243,6 +243,19 @@ LOCGPU_API int locgpu_crop_box(locgpu_ctx* ctx, const void* pts, size_t n, size_
 LOCGPU_API int locgpu_remove_nan(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, size_t intensity_offset, int is_dense, void* out,
                                  size_t* out_n, int* out_is_dense);
 
+/* LoamFeatureExtract::Extract + ExtractFromSector, LocUtils/src/model/feature_extract/loam_feature_extract.cpp:19-151 (called on every
+ * scan by Lio::AddCloud(FullCloudPtr), lio.cpp:323): per-ring curvature, six sectors per ring, at most 20 edge points per sector,
+ * every unmarked point a surface point; outputs ring by ring, sector by sector, edges in descending and surface points in
+ * ascending curvature. `ring` = one byte per point (FullPointType::ring, point_types.h:70). Equal curvatures (an order the
+ * reference's std::sort leaves open) are ordered by ring position. edge and surf must be distinct clouds of in's context.
+ * Limits: num_scan ≤ 256, rings of at most 6 × 2048 points. */
+LOCGPU_API int locgpu_cloud_loam_extract(const locgpu_cloud* in, const uint8_t* ring, int num_scan, locgpu_cloud* edge, locgpu_cloud* surf);
+/* Host-pointer one-shot on the reference's FullPointType layout (point_types.h:65-78: x,y,z at 0, uint8 intensity at 24, uint8 ring
+ * at 25, stride 64): intensity_is_u8 = 1 converts like `p.intensity = pt.intensity` (:33). Both outputs need room for n points. */
+LOCGPU_API int locgpu_loam_extract(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, size_t intensity_offset, int intensity_is_u8,
+                                   size_t ring_offset, int num_scan, void* edge_out, size_t* n_edge, void* surf_out, size_t* n_surf,
+                                   size_t out_stride_bytes, size_t out_intensity_offset);
+
 /* The local map of Lio::AddCloud's keyframe branch (lio.cpp:268-306), kept in HBM: a queue of at most num_kfs world-frame
  * keyframe clouds (scans_in_local_map_) and the voxel-filtered local map (local_map_) that is the next matching target.
  * add_keyframe(scan, pose): key_frame_scan = transform(scan, pose) (pose NULL: scan is already in the world frame); push;

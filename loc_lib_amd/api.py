@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblocgpu.so")
+LIB_PATH = os.environ.get("LOCGPU_LIB") or os.path.join(_HERE, "liblocgpu.so")  # LOCGPU_LIB: A/B builds of the same library
 CSRC = os.path.join(_HERE, "csrc")
 
 P2P, P2LINE, P2PLANE = 0, 1, 2
@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "locgpu_icp_set_target_cloud", "locgpu_ndt_set_target_cloud", "locgpu_icp_align_cloud", "locgpu_ndt_align_cloud",
     "locgpu_voxel_filter", "locgpu_crop_box", "locgpu_remove_nan",
     "locgpu_submap_create", "locgpu_submap_destroy", "locgpu_submap_add_keyframe", "locgpu_submap_cloud", "locgpu_submap_last_keyframe",
-    "locgpu_submap_info",
+    "locgpu_submap_info", "locgpu_cloud_loam_extract", "locgpu_loam_extract",
 ]
 NO_INTENSITY = ctypes.c_size_t(-1).value
 
@@ -114,6 +114,8 @@ def lib():
             "locgpu_submap_create": (i32, [vp, i32, f32, vp]), "locgpu_submap_destroy": (None, [vp]),
             "locgpu_submap_add_keyframe": (i32, [vp, vp, vp]), "locgpu_submap_cloud": (i32, [vp, vp]),
             "locgpu_submap_last_keyframe": (i32, [vp, vp]), "locgpu_submap_info": (i32, [vp, vp, vp]),
+            "locgpu_cloud_loam_extract": (i32, [vp, vp, i32, vp, vp]),
+            "locgpu_loam_extract": (i32, [vp, vp, sz, sz, sz, i32, sz, i32, vp, vp, vp, vp, sz, sz]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -250,6 +252,18 @@ class Context:
 
     def remove_nan(self, cloud, is_dense):
         return self._one_shot(lib().locgpu_remove_nan, cloud, is_dense)
+
+    def loam_extract_full(self, full_points, num_scan=16):
+        """One-shot on the reference's FullPointType records (64-byte structured array: x,y,z @0, uint8 intensity @24, ring @25)."""
+        a = np.ascontiguousarray(full_points)
+        if a.dtype.itemsize != 64:
+            raise ValueError("FullPointType records are 64 bytes")
+        n = len(a)
+        edge, surf = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+        ne, ns = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._check(lib().locgpu_loam_extract(self._h, a.ctypes.data, n, 64, 24, 1, 25, int(num_scan), edge.ctypes.data, ctypes.byref(ne),
+                                              surf.ctypes.data, ctypes.byref(ns), 16, 12))
+        return edge[:ne.value].copy(), surf[:ns.value].copy()
 
     # ---- matcher entry points on resident clouds
     def icp_set_target_cloud(self, cloud):
@@ -427,6 +441,15 @@ class Cloud:
     def append(self, other):
         self.ctx._check(lib().locgpu_cloud_append(self._h, other._h))
         return self
+
+    def loam_extract(self, ring, num_scan=16):
+        """LoamFeatureExtract::Extract on a resident cloud: returns (edge, surf) resident clouds."""
+        ring = np.ascontiguousarray(ring, dtype=np.uint8)
+        if len(ring) != len(self):
+            raise ValueError("one ring byte per point")
+        edge, surf = Cloud(self.ctx), Cloud(self.ctx)
+        self.ctx._check(lib().locgpu_cloud_loam_extract(self._h, ring.ctypes.data, int(num_scan), edge._h, surf._h))
+        return edge, surf
 
     def close(self):
         if self._owned and getattr(self, "_h", None) and getattr(self.ctx, "_h", None):

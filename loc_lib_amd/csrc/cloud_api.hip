@@ -313,4 +313,69 @@ int locgpu_submap_info(const locgpu_submap* m, int* n_keyframes, size_t* map_poi
     return LOCGPU_OK;
 }
 
+// ---- LOAM feature picker (loam_features.hip) ----
+int locgpu_cloud_loam_extract(const locgpu_cloud* in, const uint8_t* ring, int num_scan, locgpu_cloud* edge, locgpu_cloud* surf) {
+    if (!in) return LOCGPU_ERR_INVALID;
+    locgpu_ctx* ctx = in->ctx;
+    if (!same_ctx(in, edge) || !same_ctx(in, surf) || edge == surf || edge == in || surf == in || (in->n && !ring))
+        return fail(ctx, LOCGPU_ERR_INVALID, "cloud_loam_extract: bad arguments");
+    if (num_scan < 1 || num_scan > 256) return fail(ctx, LOCGPU_ERR_INVALID, "cloud_loam_extract: num_scan must be in 1..256");
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    bool too_long = false;
+    const hipError_t e = loam_extract_dev(ctx, in, ring, num_scan, edge, surf, &too_long);
+    if (e != hipSuccess) return hip_fail(ctx, e, "cloud_loam_extract");
+    if (too_long) return fail(ctx, LOCGPU_ERR_INVALID, "cloud_loam_extract: a ring has more than 6 x 2048 points");
+    return LOCGPU_OK;
+}
+
+int locgpu_loam_extract(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, size_t intensity_offset, int intensity_is_u8, size_t ring_offset,
+                        int num_scan, void* edge_out, size_t* n_edge, void* surf_out, size_t* n_surf, size_t out_stride_bytes,
+                        size_t out_intensity_offset) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    const size_t isz = intensity_is_u8 ? 1 : 4;
+    if ((n && (!pts || !edge_out || !surf_out)) || !n_edge || !n_surf || stride_bytes < 12 || ring_offset < 12 || ring_offset + 1 > stride_bytes ||
+        (intensity_offset != LOCGPU_NO_INTENSITY && (intensity_offset < 12 || intensity_offset + isz > stride_bytes)) ||
+        !layout_ok(out_stride_bytes, out_intensity_offset) || n > 0x7FFFFF00u)
+        return fail(ctx, LOCGPU_ERR_INVALID, "loam_extract: bad arguments");
+    if (num_scan < 1 || num_scan > 256) return fail(ctx, LOCGPU_ERR_INVALID, "loam_extract: num_scan must be in 1..256");
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    locgpu_cloud in, edge, surf;
+    in.ctx = edge.ctx = surf.ctx = ctx;
+    int rc = LOCGPU_OK;
+    hipError_t e = cloud_reserve(&in, n, false);
+    float4* stage = nullptr;
+    if (e == hipSuccess) e = cloud_stage(ctx, n, &stage);
+    std::vector<unsigned char> ring(n);
+    if (e == hipSuccess) {
+        const char* base = (const char*)pts;
+        for (size_t i = 0; i < n; ++i) {
+            float4 p{0.f, 0.f, 0.f, 0.f};
+            std::memcpy(&p, base + i * stride_bytes, 12);
+            if (intensity_offset != LOCGPU_NO_INTENSITY) {
+                if (intensity_is_u8) p.w = (float)*(const unsigned char*)(base + i * stride_bytes + intensity_offset);  // p.intensity = pt.intensity (:33)
+                else std::memcpy(&p.w, base + i * stride_bytes + intensity_offset, 4);
+            }
+            stage[i] = p;
+            ring[i] = *(const unsigned char*)(base + i * stride_bytes + ring_offset);
+        }
+        if (n) {
+            e = hipMemcpyAsync(in.d, stage, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+        in.n = n;
+    }
+    bool too_long = false;
+    if (e == hipSuccess) e = loam_extract_dev(ctx, &in, ring.data(), num_scan, &edge, &surf, &too_long);
+    if (e != hipSuccess) rc = hip_fail(ctx, e, "loam_extract");
+    else if (too_long) rc = fail(ctx, LOCGPU_ERR_INVALID, "loam_extract: a ring has more than 6 x 2048 points");
+    if (rc == LOCGPU_OK) rc = download(&edge, edge_out, out_stride_bytes, out_intensity_offset);
+    if (rc == LOCGPU_OK) rc = download(&surf, surf_out, out_stride_bytes, out_intensity_offset);
+    if (rc == LOCGPU_OK) { *n_edge = edge.n; *n_surf = surf.n; }
+    if (in.d) (void)hipFree(in.d);
+    if (edge.d) (void)hipFree(edge.d);
+    if (surf.d) (void)hipFree(surf.d);
+    return rc;
+}
+
 }  // extern "C"
+

@@ -56,4 +56,9 @@ hipError_t remove_nan_dev(locgpu_ctx* ctx, const locgpu_cloud* in, locgpu_cloud*
 hipError_t transform_dev(locgpu_ctx* ctx, const locgpu_cloud* in, const double pose[7], locgpu_cloud* out);
 hipError_t append_dev(locgpu_ctx* ctx, locgpu_cloud* dst, const locgpu_cloud* src);
 
+// loam_features.hip
+void loam_free(locgpu_ctx* ctx);
+hipError_t loam_extract_dev(locgpu_ctx* ctx, const locgpu_cloud* in, const unsigned char* ring, int num_scan, locgpu_cloud* edge, locgpu_cloud* surf,
+                            bool* too_long);
+
 }  // namespace locgpu

@@ -35,6 +35,7 @@ struct locgpu_ctx {
     locgpu_ndt_opts ndt_opts;
 
     locgpu::FilterScratch* filt = nullptr;  // workspaces of the cloud filters (cloud_filters.hip)
+    void* loam = nullptr;                   // workspaces of the LOAM feature picker (loam_features.hip)
 
     // reusable one-scan batch for the single-scan entry points
     locgpu_batch* single = nullptr;

@@ -160,6 +160,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     if (ctx->d_search_stats) (void)hipFree(ctx->d_search_stats);
     ndt_free(ctx);
     filters_free(ctx);
+    loam_free(ctx);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -29,6 +29,7 @@
 
 #include "locref_filters.hpp"
 #include "locref_kdtree.hpp"
+#include "locref_loam.hpp"
 #include "locref_math.hpp"
 
 namespace locref {
@@ -822,5 +823,16 @@ size_t locref_localmap_size(void* h) { return ((LocalMap*)h)->map.size(); }
 int locref_localmap_dense(void* h) { return ((LocalMap*)h)->map_dense ? 1 : 0; }
 void locref_localmap_copy(void* h, float* out) { LocalMap* m = (LocalMap*)h; std::memcpy(out, m->map.data(), m->map.size() * sizeof(PointXYZI)); }
 
+// ---- LOAM feature extraction (locref_loam.hpp): pts float32 [n][4] = x, y, z, intensity; ring uint8 [n]. Outputs need room for n points.
+void locref_loam_extract(const float* pts, const uint8_t* ring, size_t n, int num_scan, int order, float* edge, size_t* n_edge, float* surf, size_t* n_surf) {
+    std::vector<PointXYZI> e, s;
+    LoamExtract((const PointXYZI*)pts, ring, n, num_scan, order, e, s);
+    std::memcpy(edge, e.data(), e.size() * sizeof(PointXYZI));
+    std::memcpy(surf, s.data(), s.size() * sizeof(PointXYZI));
+    *n_edge = e.size();
+    *n_surf = s.size();
+}
+
 }  // extern "C"
+
 

@@ -19,7 +19,7 @@ TRACE_W = 50  # H36 B6 dx6 eff ok
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("locref.cpp", "locref_math.hpp", "locref_kdtree.hpp", "locref_filters.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("locref.cpp", "locref_math.hpp", "locref_kdtree.hpp", "locref_filters.hpp", "locref_loam.hpp")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liblocref.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -64,6 +64,7 @@ def lib():
             "locref_box_edges": (None, [_vp, _vp, _vp, _vp]),
             "locref_voxel_grid": (_sz, [_vp, _sz, _i, _f, _i, _vp, _vp]),
             "locref_transform_cloud_f64": (None, [_vp, _vp, _sz, _i, _vp]),
+            "locref_loam_extract": (None, [_vp, _vp, _sz, _i, _i, _vp, _vp, _vp, _vp]),
             "locref_localmap_create": (_vp, [_sz, _f, _i]),
             "locref_localmap_destroy": (None, [_vp]),
             "locref_localmap_add_keyframe": (None, [_vp, _vp, _sz, _i]),
@@ -344,3 +345,15 @@ class LocalMap:
         out = np.empty((lib().locref_localmap_size(self._h), 4), np.float32)
         lib().locref_localmap_copy(self._h, out.ctypes.data)
         return out
+
+
+def loam_extract(cloud, ring, num_scan=16, order=SORT_STD):
+    """LoamFeatureExtract::Extract (loam_feature_extract.cpp:19-91): returns (edge, surf) clouds [m, 4]."""
+    cloud = _xyzi(cloud)
+    ring = np.ascontiguousarray(ring, dtype=np.uint8)
+    assert len(ring) == len(cloud)
+    edge, surf = np.empty_like(cloud), np.empty_like(cloud)
+    ne, ns = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    lib().locref_loam_extract(cloud.ctypes.data, ring.ctypes.data, len(cloud), int(num_scan), int(order), edge.ctypes.data, ctypes.byref(ne),
+                              surf.ctypes.data, ctypes.byref(ns))
+    return edge[:ne.value].copy(), surf[:ns.value].copy()

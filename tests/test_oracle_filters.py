@@ -171,3 +171,97 @@ def test_tiny_clouds(locref, n):
     assert len(out) == 1
     assert np.allclose(out[0], c.astype(np.float64).mean(0), rtol=1e-5, atol=1e-4)
     assert len(locref.voxel_grid(np.zeros((0, 4), np.float32), True, 1.0)) == 0
+
+
+# ---- LOAM feature picker (oracle/locref_loam.hpp) -------------------------------------------------------------------------
+def _py_loam(cloud, ring, num_scan):
+    """Independent, literal Python restatement of loam_feature_extract.cpp:19-151 (float32 sums via numpy scalars)."""
+    f32 = np.float32
+    edge, surf = [], []
+    for r in range(num_scan):
+        L = cloud[ring == r]
+        if len(L) < 131:
+            continue
+        curv = []
+        for j in range(5, len(L) - 5):
+            d = []
+            for a in range(3):
+                s = f32(L[j - 5, a])
+                for k in (-4, -3, -2, -1):
+                    s = f32(s + L[j + k, a])
+                s = f32(s - f32(f32(10) * L[j, a]))
+                for k in (1, 2, 3, 4, 5):
+                    s = f32(s + L[j + k, a])
+                d.append(float(s))
+            curv.append((j, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]))
+        total = len(L) - 10
+        for sec in range(6):
+            ln = total // 6
+            start, end = ln * sec, (ln * (sec + 1) - 1 if sec < 5 else total - 1)
+            sub = sorted(curv[start:end], key=lambda t: (t[1], t[0]))
+            picked, n_pick = [], 0
+            for i in range(len(sub) - 1, -1, -1):
+                ind = sub[i][0]
+                if ind in picked:
+                    continue
+                if sub[i][1] <= 0.1:
+                    break
+                n_pick += 1
+                picked.append(ind)
+                if n_pick <= 20:
+                    edge.append(L[ind])
+                else:
+                    break
+                for sgn in (1, -1):
+                    for k in range(1, 6):
+                        a, b = L[ind + sgn * k], L[ind + sgn * (k - 1)]
+                        dd = [float(f32(a[c] - b[c])) for c in range(3)]
+                        if dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] > 0.05:
+                            break
+                        picked.append(ind + sgn * k)
+            for ind, _ in sub:
+                if ind not in picked:
+                    surf.append(L[ind])
+    as_arr = lambda x: np.array(x, np.float32).reshape(-1, 4)
+    return as_arr(edge), as_arr(surf)
+
+
+def _ring_cloud(synth, scan_id, rings, per_ring=1800):
+    s = synth.make_scan(scan_id)
+    idx = np.concatenate([np.arange(r * 1800, r * 1800 + per_ring) for r in rings])
+    c = np.zeros((len(idx), 4), np.float32)
+    c[:, :3] = s[idx, :3]
+    c[:, 3] = (idx % 256).astype(np.float32)
+    ring = np.repeat(np.arange(len(rings)), per_ring).astype(np.uint8)
+    return c, ring
+
+
+def test_loam_extract_matches_python_restatement(locref, synth):
+    c, ring = _ring_cloud(synth, 2, [3, 40, 60], per_ring=400)
+    # interleave the rings: bucketing must keep input order inside each ring
+    perm = np.argsort(np.arange(len(c)) % 400, kind="stable")
+    c, ring = c[perm], ring[perm]
+    e_ref, s_ref = _py_loam(c, ring, 3)
+    for order in (locref.SORT_STD, locref.SORT_STABLE):
+        e, s = locref.loam_extract(c, ring, 3, order=order)
+        assert np.array_equal(e, e_ref) and np.array_equal(s, s_ref)
+    assert len(e_ref) > 0 and len(s_ref) > 0
+
+
+def test_loam_extract_quirks(locref, synth):
+    c, ring = _ring_cloud(synth, 4, [10], per_ring=1800)
+    e, s = locref.loam_extract(c, ring, 16)
+    # at most 20 edges per sector, 6 sectors; each sector drops its last element; the rest is edge, surface or marked
+    assert len(e) <= 120
+    assert len(e) + len(s) <= 1790 - 6
+    # rings shorter than 131 points give nothing; points of rings >= num_scan are ignored
+    short, rs = _ring_cloud(synth, 4, [10], per_ring=130)
+    e2, s2 = locref.loam_extract(short, rs, 16)
+    assert len(e2) == 0 and len(s2) == 0
+    e3, s3 = locref.loam_extract(c, ring + 20, 16)
+    assert len(e3) == 0 and len(s3) == 0
+    # a flat, evenly sampled ring has no edges: every point of every sector (minus its last) is a surface point
+    th = np.linspace(0, 2 * np.pi, 600, endpoint=False)
+    flat = np.stack([10 * np.cos(th), 10 * np.sin(th), np.zeros_like(th), np.arange(600)], 1).astype(np.float32)
+    e4, s4 = locref.loam_extract(flat, np.zeros(600, np.uint8), 1)
+    assert len(e4) == 0 and len(s4) == 590 - 6
