@@ -8,11 +8,7 @@
 #include "LocUtils/model/matching/3d/icp/icp_registration.hpp"
 #include "LocUtils/model/matching/3d/matching_interface.h"
 
-#ifndef LOCGPU_FACADE_STANDALONE
-#include "LocUtils/model/feature_extract/loam_feature_extract.hpp"  // LoamFeatureOptions (feature extraction is not on the accelerated path)
-#else
-namespace LocUtils { struct LoamFeatureOptions {}; }
-#endif
+#include "LocUtils/model/feature_extract/loam_feature_extract.hpp"  // LoamFeatureOptions
 
 struct locgpu_ctx;
 

@@ -18,6 +18,7 @@
 #else
 #include <array>
 #include <cstddef>
+#include <cstdint>
 #include <memory>
 #include <vector>
 
@@ -39,6 +40,21 @@ struct PointCloudType {  // the members of pcl::PointCloud the façade touches
     using Ptr = std::shared_ptr<PointCloudType>;
 };
 using CloudPtr = PointCloudType::Ptr;
+
+struct alignas(16) FullPointType {  // LocUtils::FullPointType, point_types.h:65-78 (64 bytes)
+    float x = 0, y = 0, z = 0, pad0 = 1.f;
+    float range = 0, radius = 0;
+    std::uint8_t intensity = 0, ring = 0, angle = 0;
+    double time_span = 0, time_intervel = 0;
+    float height = 0;
+};
+static_assert(sizeof(FullPointType) == 64, "FullPointType layout");
+struct FullPointCloudType {
+    std::vector<FullPointType> points;
+    bool is_dense = true;
+    using Ptr = std::shared_ptr<FullPointCloudType>;
+};
+using FullCloudPtr = FullPointCloudType::Ptr;
 
 struct SE3 {  // Sophus::SE3d parameter layout
     double p[7] = {0, 0, 0, 1, 0, 0, 0};

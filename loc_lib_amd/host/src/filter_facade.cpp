@@ -13,6 +13,7 @@
 #include "../../../include/locgpu.h"
 #include "LocUtils/model/cloud_filter/box_filter.hpp"
 #include "LocUtils/model/cloud_filter/voxel_filter.hpp"
+#include "LocUtils/model/feature_extract/loam_feature_extract.hpp"
 #include "locgpu_facade/cloud_ops.hpp"
 
 namespace LocUtils {
@@ -96,6 +97,25 @@ void BoxFilter::CalculateEdge() {
 }
 
 std::vector<float> BoxFilter::GetEdge() { return edge_; }
+
+// ------------------------------------------------------------------------------------------------ LoamFeatureExtract
+LoamFeatureExtract::LoamFeatureExtract(LoamFeatureOptions option) : option_(option) {}
+LoamFeatureExtract::~LoamFeatureExtract() { locgpu_destroy(ctx_); }
+const char* LoamFeatureExtract::LastError() const { return locgpu_last_error(ctx_); }
+
+void LoamFeatureExtract::Extract(FullCloudPtr& pc_in, CloudPtr& pc_out_edge, CloudPtr& pc_out_surf) {
+    if (!pc_in || !pc_out_edge || !pc_out_surf || pc_in->points.empty() || !ensure(ctx_, device_id_)) return;
+    const size_t n = pc_in->points.size();
+    decltype(pc_out_edge->points) edge(n), surf(n);  // default-constructed PointXYZI, x/y/z/intensity filled by the library
+    size_t ne = 0, ns = 0;
+    if (locgpu_loam_extract(ctx_, pc_in->points.data(), n, sizeof(FullPointType), offsetof(FullPointType, intensity), 1, offsetof(FullPointType, ring),
+                            (int)option_.num_scan_, edge.data(), &ne, surf.data(), &ns, sizeof(PointType), kIntensityOffset) != LOCGPU_OK)
+        return;
+    pc_out_edge->points.insert(pc_out_edge->points.end(), edge.begin(), edge.begin() + ne);  // the reference push_back()s into whatever is there
+    pc_out_surf->points.insert(pc_out_surf->points.end(), surf.begin(), surf.begin() + ns);
+    pc_out_edge->width = (unsigned)pc_out_edge->points.size(); pc_out_edge->height = 1;
+    pc_out_surf->width = (unsigned)pc_out_surf->points.size(); pc_out_surf->height = 1;
+}
 
 // ------------------------------------------------------------------------------------------------ RemoveNanPoint
 namespace gpu {

@@ -13,6 +13,7 @@
 
 #include "LocUtils/model/cloud_filter/box_filter.hpp"
 #include "LocUtils/model/cloud_filter/voxel_filter.hpp"
+#include "LocUtils/model/feature_extract/loam_feature_extract.hpp"
 #include "locgpu_facade/cloud_ops.hpp"
 
 using namespace LocUtils;
@@ -27,7 +28,43 @@ static void save(const std::string& path, const CloudPtr& c) {
     std::fclose(f);
 }
 
+// loam mode: facade_filters loam <in.bin float32 [n][4]> <ring.bin uint8 [n]> <num_scan> <out_prefix>   (Lio::AddCloud(FullCloudPtr), lio.cpp:321-323)
+static int run_loam(char** argv) {
+    FILE* f = std::fopen(argv[2], "rb");
+    if (!f) return 2;
+    std::fseek(f, 0, SEEK_END);
+    const long bytes = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<float> raw(bytes / 4);
+    if (std::fread(raw.data(), 4, raw.size(), f) != raw.size()) return 2;
+    std::fclose(f);
+    const size_t n = raw.size() / 4;
+    std::vector<unsigned char> ring(n);
+    f = std::fopen(argv[3], "rb");
+    if (!f || std::fread(ring.data(), 1, n, f) != n) return 2;
+    std::fclose(f);
+    FullCloudPtr scan(new FullPointCloudType);
+    scan->points.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        auto& p = scan->points[i];
+        p.x = raw[4 * i]; p.y = raw[4 * i + 1]; p.z = raw[4 * i + 2];
+        p.intensity = (unsigned char)raw[4 * i + 3];
+        p.ring = ring[i];
+    }
+    LoamFeatureOptions opt;
+    opt.num_scan_ = (size_t)std::atoi(argv[4]);
+    std::shared_ptr<LoamFeatureExtract> loam_feature_ptr = std::make_shared<LoamFeatureExtract>(opt);  // lio.cpp:52
+    CloudPtr edge_cloud(new PointCloudType), surf_cloud(new PointCloudType);
+    loam_feature_ptr->Extract(scan, edge_cloud, surf_cloud);
+    const std::string prefix = argv[5];
+    save(prefix + ".edge.bin", edge_cloud);
+    save(prefix + ".surf.bin", surf_cloud);
+    std::printf("%zu %zu\n", edge_cloud->points.size(), surf_cloud->points.size());
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc == 6 && std::string(argv[1]) == "loam") return run_loam(argv);
     if (argc != 9) { std::fprintf(stderr, "usage\n"); return 2; }
     FILE* f = std::fopen(argv[1], "rb");
     if (!f) return 2;

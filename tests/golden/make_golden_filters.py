@@ -3,7 +3,8 @@
 The reference holds no golden vectors for its filter wrappers and PCL cannot be built here, so these vectors pin the
 ORACLE's behaviour (regression) and let the GPU box check the HIP filters without regenerating anything: a 20 k-pt scan
 with NaN returns and intensities, its removeNaN / VoxelGrid (both summation orders) / CropBox outputs, and the local map
-after each of 5 keyframes with num_kfs = 3 (Lio::AddCloud's keyframe branch).
+after each of 5 keyframes with num_kfs = 3 (Lio::AddCloud's keyframe branch), and a 6-ring scan with its LOAM edge / surface
+features (LoamFeatureExtract::Extract).
 
     python tests/golden/make_golden_filters.py
 """
@@ -48,6 +49,17 @@ def main():
             out["kf_world_0"] = kf
         lm.add_keyframe(kf)
         out["local_map_%d" % s] = lm.cloud()
+    # LOAM feature picker: 6 rings x 900 azimuths of scan 31, delivered column by column (rings interleaved)
+    full = synth.make_scan(31)
+    idx = np.concatenate([np.arange(r * 1800, r * 1800 + 900) for r in (2, 12, 25, 38, 50, 61)])
+    lo = xyzi(full[idx], 99)
+    ring = np.repeat(np.arange(6), 900).astype(np.uint8)
+    perm = np.argsort(np.arange(len(lo)) % 900, kind="stable")
+    lo, ring = np.ascontiguousarray(lo[perm]), np.ascontiguousarray(ring[perm])
+    out["loam_cloud"], out["loam_ring"] = lo, ring
+    out["loam_edge"], out["loam_surf"] = locref.loam_extract(lo, ring, 16, order=locref.SORT_STABLE)
+    e_std, s_std = locref.loam_extract(lo, ring, 16, order=locref.SORT_STD)
+    assert np.array_equal(e_std, out["loam_edge"]) and np.array_equal(s_std, out["loam_surf"])  # no equal curvatures in this input
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "filters_small.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", {k: len(v) for k, v in out.items() if k.startswith(("voxel", "crop", "local", "no_nan"))})

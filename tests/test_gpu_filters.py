@@ -278,3 +278,5 @@ def test_golden_filter_fixture_gpu(gpu_ctx, api):
         if s == 0:
             assert np.array_equal(sub.last_keyframe().download(), g["kf_world_0"])
         assert np.array_equal(sub.cloud().download(), g["local_map_%d" % s])
+    edge, surf = api.Cloud(gpu_ctx, g["loam_cloud"]).loam_extract(g["loam_ring"], 16)
+    assert np.array_equal(edge.download(), g["loam_edge"]) and np.array_equal(surf.download(), g["loam_surf"])

@@ -94,3 +94,22 @@ def test_loam_extract_edge_cases(gpu_ctx, api):
     long_ring = api.Cloud(gpu_ctx, np.random.default_rng(1).normal(size=(13000, 4)).astype(np.float32))
     with pytest.raises(api.LocGpuError):
         long_ring.loam_extract(np.zeros(13000, np.uint8), 1)
+
+
+def test_cpp_facade_loam_feature_extract(locref, synth, tmp_path):
+    """LocUtils::LoamFeatureExtract (loc_lib_amd/host) driven like Lio::AddCloud(FullCloudPtr) (lio.cpp:321-323)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "cpp", "facade_filters")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    c, ring = _scan(synth, 12)
+    c.tofile(tmp_path / "in.bin")
+    ring.tofile(tmp_path / "ring.bin")
+    r = subprocess.run([exe, "loam", str(tmp_path / "in.bin"), str(tmp_path / "ring.bin"), "64", str(tmp_path / "out")], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    edge = np.fromfile(str(tmp_path / "out.edge.bin"), np.float32).reshape(-1, 4)
+    surf = np.fromfile(str(tmp_path / "out.surf.bin"), np.float32).reshape(-1, 4)
+    e_ref, s_ref = locref.loam_extract(c, ring, 64, order=locref.SORT_STABLE)
+    assert [int(t) for t in r.stdout.split()] == [len(e_ref), len(s_ref)]
+    assert np.array_equal(edge, e_ref) and np.array_equal(surf, s_ref)
