@@ -549,8 +549,9 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
     (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);
     if (blk != 256) {
         dim3 g2((a.max_n + blk - 1) / blk, a.n_scans);
+        static const int lds_pad = [] { const char* e = getenv("LOCGPU_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiment: extra dynamic LDS lowers occupancy
         if (blk == 64)
-            hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 64>), g2, dim3(64), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+            hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 64>), g2, dim3(64), lds_pad, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                                a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
         else
             hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 128>), g2, dim3(128), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
