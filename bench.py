@@ -227,7 +227,7 @@ def main():
                                 scans_per_gpu=B, map_points=args.map_points, search_mode=dict(tree="tree_faithful_ann", tree_exact="tree_faithful_exact", grid="grid_exact")[args.search], tree_depth=tinfo["depth"],
                                 tree_bytes=tinfo["bytes"]),
                     icp_iter_ms=round((t_search + t_accum + t_solve) / max(prof["search_n"] / args.steps, 1), 5),
-                    icp_iter_ms_per_scan=round((t_search + t_accum + t_solve) * args.steps / max(gn_iters, 1), 6),
+                    icp_iter_ms_per_scan=round((t_search + t_accum + t_solve) / max(gn_iters, 1), 6),  # kernel ms of one step ÷ scan-iterations of one step
                     gn_iterations_per_scan=round(gn_iters / B, 2),
                     kernel_ms_per_step=dict(search=round(t_search, 4), fit_accumulate=round(t_accum, 4), solve=round(t_solve, 4)),
                     median_translation_error_to_truth_m=round(err_t, 4),
