@@ -225,3 +225,22 @@ def test_search_grid_invariants(api, locref, synth, case):
     a = np.sort(leaf_pts.view([("x", "f4"), ("y", "f4"), ("z", "f4")]).ravel(), order=["x", "y", "z"])
     b = np.sort(np.ascontiguousarray(gp[:, :3]).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).ravel(), order=["x", "y", "z"])
     assert np.array_equal(a, b)
+
+
+def test_host_ingest_is_clean_under_asan_ubsan(tmp_path):
+    """The multithreaded host builders (csrc/kdtree_build.cpp, grid_build.cpp) under AddressSanitizer + UBSan (CPU build only)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    csrc = os.path.join(ROOT, "loc_lib_amd", "csrc")
+    exe = str(tmp_path / "host_build_sanitize")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-I", csrc,
+           os.path.join(ROOT, "tests", "cpp", "host_build_sanitize.cpp"), os.path.join(csrc, "kdtree_build.cpp"), os.path.join(csrc, "grid_build.cpp"),
+           "-o", exe, "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "asan harness ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
