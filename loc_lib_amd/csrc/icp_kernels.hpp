@@ -246,8 +246,8 @@ __device__ __forceinline__ void tree_knn_flat(const uint2* __restrict__ tree, fl
 // (hundreds of select instructions whenever any lane of the wave sits on a leaf) and the 8-byte × depth LDS stack
 // that caps occupancy at two workgroups per CU. Both are only needed in rare situations, which this kernel detects:
 //   * result set: a sorted array with insertion (≈40 instructions). It keeps exactly the elements and the final
-//     order std::priority_queue would as long as no two distances in the set are ever equal; an insertion that ties
-//     with a resident element raises `slow`.
+//     order std::priority_queue would unless an eviction happens while the maximum is tied (which element leaves is then a
+//     matter of heap layout) or two distances of the final set are equal (their pop order is); both raise `slow`.
 //   * stack: the first T pushes of a query are always the top T tree levels of its first descent (the result set is
 //     empty, NeedExpand is unconditionally true). They are popped last, against the final bound, and are almost never
 //     expanded — so they are not stored at all, only the minimum of their d². When the stack drains down to them:
@@ -357,10 +357,6 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                 const float dis2 = dx * dx + (dy * dy + dz * dz);
                 const bool ins = dis2 < top;  // n<K: top is +inf; n==K: strict `<` (kdtree.cpp:207)
                 slow |= !ins && !full;        // inf/NaN distance while filling: the exact kernel decides
-                bool tie = false;
-#pragma unroll
-                for (int j = 0; j < K - 1; ++j) tie |= (dis2 == set.d[j]);
-                slow |= ins && tie;
                 set.d[K - 1] = ins ? dis2 : set.d[K - 1];
                 set.id[K - 1] = ins ? cur : set.id[K - 1];
 #pragma unroll
@@ -371,6 +367,9 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                     set.d[j - 1] = lo; set.d[j] = hi; set.id[j - 1] = ilo; set.id[j] = ihi;
                 }
                 set.n += (ins && !full) ? 1 : 0;
+                // The only moments the heap's layout decides WHICH elements stay: an eviction while the maximum is tied — the
+                // evicted distance then equals the new maximum. (Ties that survive to the end are caught after the loop.)
+                slow |= ins && full && top == set.d[K - 1];
             }
 
             // internal side (Knn, kdtree.cpp:177-194), predicated on !is_leaf
@@ -424,6 +423,9 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
         }
         live = live && !slow;
     }
+    // equal distances in the final set: std::priority_queue would pop them in a layout-dependent order
+#pragma unroll
+    for (int j = 0; j + 1 < K; ++j) slow |= set.d[j] == set.d[j + 1];
     if (STAMP) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         diag[0] = t_mid - t_begin; diag[1] = t_end - t_begin; diag[2] = n_trips; diag[3] = n_visit; diag[4] = n_pop;
