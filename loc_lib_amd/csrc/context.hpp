@@ -22,6 +22,7 @@ struct locgpu_ctx {
     uint2* d_tree = nullptr;
     size_t tree_slots = 0, num_leaves = 0, num_nodes = 0, num_points = 0;
     int depth = 0;
+    bool tree_bounded = true;  // PackedKdTree::bounded: the fast search kernel may be used
     unsigned long long target_epoch = 0;  // bumped by every set_target: captured graphs of older targets are never replayed
 
     // exact-search grid over the tree's leaves (built on first use of LOCGPU_SEARCH_GRID_EXACT)

@@ -73,7 +73,11 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
     SortedSet<K> set;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
     unsigned long long diag[5] = {0, 0, 0, 0, 0};
-    const bool slow = tree_knn_fast<K, DF, BLK, STAMP>(rsrc, (float)qs.x, (float)qs.y, (float)qs.z, alpha_eff, T, s_stack, tid, set, diag);
+    // The fast traversal assumes finite arithmetic (the tree is `bounded`, kdtree_build.cpp): a query that is NaN, infinite or
+    // astronomically far goes straight to the exact kernel.
+    const float fqx = (float)qs.x, fqy = (float)qs.y, fqz = (float)qs.z;
+    const bool sane = fabsf(fqx) < 1e18f && fabsf(fqy) < 1e18f && fabsf(fqz) < 1e18f;
+    const bool slow = !sane || tree_knn_fast<K, DF, BLK, STAMP>(rsrc, fqx, fqy, fqz, alpha_eff, T, s_stack, tid, set, diag);
     if (STAMP && search_stats) {
         // per-wave maxima (what the wave pays) and per-lane sums (useful work); search_stats[2..] are diagnostic slots
         unsigned long long wmax[5];

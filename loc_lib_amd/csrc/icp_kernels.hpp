@@ -308,7 +308,7 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
     unsigned int n_trips = 0, n_visit = 0, n_pop = 0;
     if (STAMP) t_begin = __builtin_amdgcn_s_memtime();
     set.init();
-    int sp = 0, replay = 0;
+    int sp = 0;
     uint32_t cur = 0;
     float min_drop = __builtin_inff();
     bool slow = false, live = true, need_pop = false;
@@ -328,7 +328,6 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
         const bool go_left = qa < th;
         if (sp < T) {
             min_drop = d2 < min_drop ? d2 : min_drop;
-            slow |= !(d2 == d2);  // NaN coordinate
         } else if (sp - T < DF) {
             s_stack[sp - T][tid] = make_uint2(go_left ? right : cur + 1u, __float_as_uint(d2));
         } else {
@@ -356,7 +355,6 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                 const float dx = qx - as_f32(w.x), dy = qy - as_f32(w.z), dz = qz - as_f32(w.w);
                 const float dis2 = dx * dx + (dy * dy + dz * dz);
                 const bool ins = dis2 < top;  // n<K: top is +inf; n==K: strict `<` (kdtree.cpp:207)
-                slow |= !ins && !full;        // inf/NaN distance while filling: the exact kernel decides
                 set.d[K - 1] = ins ? dis2 : set.d[K - 1];
                 set.id[K - 1] = ins ? cur : set.id[K - 1];
 #pragma unroll
@@ -383,13 +381,11 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
             const bool push = !is_leaf && (!full || d2 < top * alpha_eff);  // else NeedExpand can never come true later
             const bool drop = push && sp < T;
             const bool store = push && !drop && (sp - T) < DF;
-            slow |= (push && !drop && !store) || (drop && !(d2 == d2));    // deeper than the fast stack / NaN coordinate
+            slow |= push && !drop && !store;  // deeper than the fast stack
             min_drop = (drop && d2 < min_drop) ? d2 : min_drop;
             if (store) s_stack[sp - T][tid] = make_uint2(far_slot, __float_as_uint(d2));
             sp += push ? 1 : 0;
-            const bool replaying = !is_leaf && replay > 0;
-            replay -= replaying ? 1 : 0;
-            need_pop = is_leaf || (replaying && replay == 0);  // after a leaf, or once the top levels are re-pushed
+            need_pop = is_leaf;
             cur = go_left ? cur + 1u : right;
         }
         if (need_pop) {  // ------------------------------------------------- POP: NeedExpand (kdtree.cpp:214-236), youngest first
@@ -399,12 +395,33 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
             if (avail <= 0) {
                 // nothing stored is left. sp > 0: only un-stored first-descent entries (levels 0..sp-1) remain.
                 const bool may_pass = sp > 0 && (open || !(min_drop >= bound));
-                replay = may_pass ? sp : 0;  // replay them from the root …
-                live = may_pass;             // … or finish: every one of them is rejected by the final bound
-                T = may_pass ? 0 : T;
-                sp = 0;
-                cur = 0;
-                need_pop = false;
+                live = may_pass;  // otherwise finished: every un-stored entry is rejected by the final bound
+                if (may_pass) {
+                    // Rare: walk the un-stored levels 0..sp-1 again from the root (same `<` decisions, hence the same internal
+                    // nodes) and push them under the pruning rule with the CURRENT bound; from now on every position is stored.
+                    const int levels = sp;
+                    uint32_t c = 0;
+                    sp = 0;
+                    T = 0;
+                    for (int l = 0; l < levels; ++l) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(tree_rsrc, (int)(c << 3), 0, 0);
+                        const uint32_t tg = v.y >> 30;
+                        const float th = as_f32(v.x);
+                        const float qa = tg == 0u ? qx : (tg == 1u ? qy : qz);
+                        const float dd = qa - th;
+                        const float d2 = dd * dd;
+                        const uint32_t right = v.y & 0x3FFFFFFFu;
+                        const bool go_left = qa < th;
+                        if (open || d2 < bound) {
+                            if (sp < DF) s_stack[sp][tid] = make_uint2(go_left ? right : c + 1u, __float_as_uint(d2));
+                            else slow = true;
+                            sp++;
+                        }
+                        c = go_left ? c + 1u : right;
+                    }
+                    min_drop = __builtin_inff();
+                }
+                // need_pop stays set: the re-pushed entries are popped like any others (an empty stack ends the query next trip)
             } else {
                 // up to four entries per LDS round trip, examined youngest first
                 uint2 e[4];

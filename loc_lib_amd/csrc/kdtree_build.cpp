@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstring>
 #include <thread>
 
@@ -221,6 +222,25 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
     out.num_nodes = total - out.num_leaves;  // internal (1 slot) + leaves (2 slots) ⇒ nodes = slots − leaves
     out.depth = b.depth.load();
     out.num_points = n;
+    // The fast search kernel assumes squared distances cannot overflow or be NaN: true when every float in the tree (leaf
+    // coordinates and split thresholds) is finite and small enough. Otherwise searches use the exact kernel only.
+    out.bounded = true;
+    for (size_t i = 0; i < out.slots.size() && out.bounded;) {
+        const uint32_t meta = (uint32_t)(out.slots[i] >> 32);
+        const bool leaf = (meta >> 30) == 3u;
+        float f[3];
+        const uint32_t w0 = (uint32_t)out.slots[i];
+        std::memcpy(&f[0], &w0, 4);
+        int nf = 1;
+        if (leaf) {
+            const uint32_t w1 = (uint32_t)out.slots[i + 1], w2 = (uint32_t)(out.slots[i + 1] >> 32);
+            std::memcpy(&f[1], &w1, 4); std::memcpy(&f[2], &w2, 4);
+            nf = 3;
+        }
+        for (int k = 0; k < nf; ++k)
+            if (!(std::fabs(f[k]) < 1e18f)) out.bounded = false;
+        i += leaf ? 2 : 1;
+    }
     return true;
 }
 

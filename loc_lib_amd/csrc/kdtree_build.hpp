@@ -13,6 +13,7 @@ struct PackedKdTree {
     size_t num_nodes = 0;         // internal + leaf nodes
     size_t num_points = 0;
     int depth = 0;                // root = level 1
+    bool bounded = true;          // every coordinate and split threshold is finite and below 1e18 in magnitude (squared distances cannot overflow)
 };
 
 // xyz: n packed float32 triples. Returns false and sets err on failure.

@@ -190,6 +190,7 @@ int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
     ctx->num_nodes = t.num_nodes;
     ctx->num_points = t.num_points;
     ctx->depth = t.depth;
+    ctx->tree_bounded = t.bounded;
     ctx->target_epoch++;
     return LOCGPU_OK;
 }
@@ -396,6 +397,7 @@ bool IterLauncher::launch(int do_update) {
                       prm.method == LOCGPU_P2P ? 1 : 0, ctx->count_visits ? ctx->d_visits : nullptr, b->d_redo_list, b->d_redo_count,
                       b->d_redo_list2, b->d_redo_count + 1, ctx->d_search_stats};
         const bool grid_mode = alpha_eff < 0.f;
+        if (!grid_mode && !ctx->tree_bounded) sa.redo_list = nullptr;  // huge / non-finite map coordinates: exact kernel only
         if (grid_mode && !b->d_redo_list2 && !hip_ok(ctx, hipMalloc((void**)&b->d_redo_list2, b->pitch * sizeof(uint32_t)), "hipMalloc redo2")) return false;
         sa.redo_list2 = b->d_redo_list2;
         if (grid_mode) sa.alpha_eff = 1.0f;  // the tree kernel that settles the grid's leftovers runs the exact pruning rule

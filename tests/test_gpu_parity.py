@@ -86,6 +86,33 @@ def test_icp_hb_matches_oracle(gpu_ctx, api, locref, small_world, method):
     np.testing.assert_array_equal(Hg, Hg.T)
 
 
+def test_icp_hb_unbounded_map_and_far_queries_take_the_exact_kernel(gpu_ctx, api, locref, small_world):
+    """The fast search kernel assumes squared distances cannot overflow: a map with an astronomically far point
+    (kdtree_build.cpp `bounded`) and source points beyond 1e18 m are answered by the exact kernel, with the same result."""
+    m, s, pose = small_world["map"].copy(), small_world["scan2k"].copy(), small_world["init_pose"]
+    m[7] = [3e19, -2e19, 1e19]          # (3e19)^2 overflows float32
+    for method in (0, 2):
+        gpu_ctx.icp_set_target(m)
+        icp = locref.Icp(method=method)
+        icp.set_target(m)
+        ok_o, Ho, Bo, eff_o = icp.hb(s, pose)
+        ok_g, Hg, Bg, eff_g = gpu_ctx.icp_hb(s, pose, api.icp_opts(method=method))
+        assert ok_g == ok_o and eff_g == eff_o
+        _hb_close(Hg, Bg, Ho, Bo)
+    # bounded map again, but three source points far outside float32's squared range
+    m = small_world["map"]
+    s[5] = [5e19, 0, 0]
+    s[900] = [0, -7e18, 1e19]
+    s[1500] = [1e30, 1e30, 1e30]
+    gpu_ctx.icp_set_target(m)
+    icp = locref.Icp(method=0)
+    icp.set_target(m)
+    ok_o, Ho, Bo, eff_o = icp.hb(s, pose)
+    ok_g, Hg, Bg, eff_g = gpu_ctx.icp_hb(s, pose, api.icp_opts(method=0))
+    assert ok_g == ok_o and eff_g == eff_o
+    _hb_close(Hg, Bg, Ho, Bo)
+
+
 def test_icp_hb_exact_search_mode_of_the_tree(gpu_ctx, api, locref, small_world):
     """SetEnableANN(false) (kdtree.cpp:285-288): exact pruning rule through the same tree."""
     m, s, pose = small_world["map"], small_world["scan2k"], small_world["init_pose"]
