@@ -311,7 +311,9 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
     int sp = 0;
     uint32_t cur = 0;
     float min_drop = __builtin_inff();
-    bool slow = false, live = true, need_pop = false;
+    // Loop-carried flags live in VGPRs as integers: a divergent `bool` is a lane mask in SGPRs, and every region that
+    // assigns it costs three scalar mask instructions at its merge point — the scalar unit is shared by the CU's four SIMDs.
+    uint32_t slow = 0, live = 1, need_pop = 0;
 
     // ---- first descent: the result set is empty, so every internal node pushes its far side (NeedExpand is true while
     // size < k) and no lane meets a leaf or pops. A minimal loop for these ≈depth trips; lanes leave it at their first leaf.
@@ -331,12 +333,12 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
         } else if (sp - T < DF) {
             s_stack[sp - T][tid] = make_uint2(go_left ? right : cur + 1u, __float_as_uint(d2));
         } else {
-            slow = true;
+            slow = 1;
         }
         sp++;
         cur = go_left ? cur + 1u : right;
     }
-    live = !slow;
+    live = slow ^ 1u;
     if (STAMP) t_mid = __builtin_amdgcn_s_memtime();
 
     while (live) {
@@ -367,7 +369,7 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                 set.n += (ins && !full) ? 1 : 0;
                 // The only moments the heap's layout decides WHICH elements stay: an eviction while the maximum is tied — the
                 // evicted distance then equals the new maximum. (Ties that survive to the end are caught after the loop.)
-                slow |= ins && full && top == set.d[K - 1];
+                slow |= (ins && full && top == set.d[K - 1]) ? 1u : 0u;
             }
 
             // internal side (Knn, kdtree.cpp:177-194), predicated on !is_leaf
@@ -381,11 +383,11 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
             const bool push = !is_leaf && (!full || d2 < top * alpha_eff);  // else NeedExpand can never come true later
             const bool drop = push && sp < T;
             const bool store = push && !drop && (sp - T) < DF;
-            slow |= push && !drop && !store;  // deeper than the fast stack
+            slow |= (push && !drop && !store) ? 1u : 0u;  // deeper than the fast stack
             min_drop = (drop && d2 < min_drop) ? d2 : min_drop;
             if (store) s_stack[sp - T][tid] = make_uint2(far_slot, __float_as_uint(d2));
             sp += push ? 1 : 0;
-            need_pop = is_leaf;
+            need_pop = is_leaf ? 1u : 0u;
             cur = go_left ? cur + 1u : right;
         }
         if (need_pop) {  // ------------------------------------------------- POP: NeedExpand (kdtree.cpp:214-236), youngest first
@@ -395,7 +397,7 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
             if (avail <= 0) {
                 // nothing stored is left. sp > 0: only un-stored first-descent entries (levels 0..sp-1) remain.
                 const bool may_pass = sp > 0 && (open || !(min_drop >= bound));
-                live = may_pass;  // otherwise finished: every un-stored entry is rejected by the final bound
+                live = may_pass ? 1u : 0u;  // otherwise finished: every un-stored entry is rejected by the final bound
                 if (may_pass) {
                     // Rare: walk the un-stored levels 0..sp-1 again from the root (same `<` decisions, hence the same internal
                     // nodes) and push them under the pruning rule with the CURRENT bound; from now on every position is stored.
@@ -414,7 +416,7 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                         const bool go_left = qa < th;
                         if (open || d2 < bound) {
                             if (sp < DF) s_stack[sp][tid] = make_uint2(go_left ? right : c + 1u, __float_as_uint(d2));
-                            else slow = true;
+                            else slow = 1;
                             sp++;
                         }
                         c = go_left ? c + 1u : right;
@@ -435,19 +437,19 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                 const int used = found ? hit + 1 : (avail < 4 ? avail : 4);
                 sp -= used;
                 cur = found ? far_hit : cur;
-                need_pop = !found;
+                need_pop = found ? 0u : 1u;
             }
         }
-        live = live && !slow;
+        live = slow ? 0u : live;
     }
     // equal distances in the final set: std::priority_queue would pop them in a layout-dependent order
 #pragma unroll
-    for (int j = 0; j + 1 < K; ++j) slow |= set.d[j] == set.d[j + 1];
+    for (int j = 0; j + 1 < K; ++j) slow |= set.d[j] == set.d[j + 1] ? 1u : 0u;
     if (STAMP) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         diag[0] = t_mid - t_begin; diag[1] = t_end - t_begin; diag[2] = n_trips; diag[3] = n_visit; diag[4] = n_pop;
     }
-    return slow;
+    return slow != 0;
 }
 
 // Pops the heap into ascending-distance order (kdtree.cpp:160-165).
