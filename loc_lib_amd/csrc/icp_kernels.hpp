@@ -425,14 +425,20 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                 }
                 // need_pop stays set: the re-pushed entries are popped like any others (an empty stack ends the query next trip)
             } else {
-                // up to four entries per LDS round trip, examined youngest first
-                uint2 e[4];
+                // up to four entries per LDS round trip, examined youngest first: their d² first, then the far slot of the one
+                // that passes, read with a computed row (a select over four loaded slots makes the compiler branch per case)
+                const uint32_t* s32 = reinterpret_cast<const uint32_t*>(&s_stack[0][0]);
+                float ed2[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = s_stack[avail - 1 - j >= 0 ? avail - 1 - j : 0][tid];
+                for (int j = 0; j < 4; ++j) {
+                    const int row = avail - 1 - j >= 0 ? avail - 1 - j : 0;
+                    ed2[j] = __uint_as_float(s32[(row * BLK + tid) * 2 + 1]);
+                }
                 int hit = 4;
 #pragma unroll
-                for (int j = 3; j >= 0; --j) hit = (j < avail && (open || as_f32(e[j].y) < bound)) ? j : hit;
-                const uint32_t far_hit = hit == 0 ? e[0].x : (hit == 1 ? e[1].x : (hit == 2 ? e[2].x : e[3].x));
+                for (int j = 3; j >= 0; --j) hit = (j < avail && (open || ed2[j] < bound)) ? j : hit;
+                const int row_hit = avail - 1 - hit >= 0 ? avail - 1 - hit : 0;
+                const uint32_t far_hit = s32[(row_hit * BLK + tid) * 2];
                 const bool found = hit < 4;
                 const int used = found ? hit + 1 : (avail < 4 ? avail : 4);
                 sp -= used;
