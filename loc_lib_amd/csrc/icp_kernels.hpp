@@ -348,8 +348,8 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
             const uint32_t meta = w.y;
             const uint32_t tag = meta >> 30;
             const bool is_leaf = tag == 3u;
-            const bool full = set.n >= K;
-            const float top = set.top();
+            const float top = set.top();  // +inf until the set holds K points: `x < top` and `x < top·alpha` are then true for every
+                                          // finite x, which is exactly the reference's "size < k" rule (kdtree.cpp:203,222)
 
             // leaf side (ComputeDisForLeaf, kdtree.cpp:197-212). A real branch: during the first descent no lane of the
             // wave sits on a leaf and the whole block is skipped; inside it is select-only.
@@ -366,10 +366,9 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                     const uint32_t ilo = sw ? set.id[j] : set.id[j - 1], ihi = sw ? set.id[j - 1] : set.id[j];
                     set.d[j - 1] = lo; set.d[j] = hi; set.id[j - 1] = ilo; set.id[j] = ihi;
                 }
-                set.n += (ins && !full) ? 1 : 0;
                 // The only moments the heap's layout decides WHICH elements stay: an eviction while the maximum is tied — the
                 // evicted distance then equals the new maximum. (Ties that survive to the end are caught after the loop.)
-                slow |= (ins && full && top == set.d[K - 1]) ? 1u : 0u;
+                slow |= (ins && top == set.d[K - 1] && top < __builtin_inff()) ? 1u : 0u;
             }
 
             // internal side (Knn, kdtree.cpp:177-194), predicated on !is_leaf
@@ -380,23 +379,23 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
             const uint32_t right = meta & 0x3FFFFFFFu;
             const bool go_left = qa < th;
             const uint32_t far_slot = go_left ? right : cur + 1u;
-            const bool push = !is_leaf && (!full || d2 < top * alpha_eff);  // else NeedExpand can never come true later
-            const bool drop = push && sp < T;
-            const bool store = push && !drop && (sp - T) < DF;
-            slow |= (push && !drop && !store) ? 1u : 0u;  // deeper than the fast stack
+            const bool push = !is_leaf && d2 < top * alpha_eff;  // else NeedExpand can never come true later
+            const int idx = sp - T;                              // position in the stored part of the stack
+            const bool drop = push && idx < 0;
+            const bool store = push && (unsigned)idx < (unsigned)DF;
+            slow |= (push && idx >= DF) ? 1u : 0u;  // deeper than the fast stack
             min_drop = (drop && d2 < min_drop) ? d2 : min_drop;
-            if (store) s_stack[sp - T][tid] = make_uint2(far_slot, __float_as_uint(d2));
+            if (store) s_stack[idx][tid] = make_uint2(far_slot, __float_as_uint(d2));
             sp += push ? 1 : 0;
             need_pop = is_leaf ? 1u : 0u;
             cur = go_left ? cur + 1u : right;
         }
         if (need_pop) {  // ------------------------------------------------- POP: NeedExpand (kdtree.cpp:214-236), youngest first
-            const bool open = set.n < K;
-            const float bound = set.top() * alpha_eff;
+            const float bound = set.top() * alpha_eff;  // +inf while the set is not full: everything passes
             const int avail = sp - T;
             if (avail <= 0) {
                 // nothing stored is left. sp > 0: only un-stored first-descent entries (levels 0..sp-1) remain.
-                const bool may_pass = sp > 0 && (open || !(min_drop >= bound));
+                const bool may_pass = sp > 0 && !(min_drop >= bound);
                 live = may_pass ? 1u : 0u;  // otherwise finished: every un-stored entry is rejected by the final bound
                 if (may_pass) {
                     // Rare: walk the un-stored levels 0..sp-1 again from the root (same `<` decisions, hence the same internal
@@ -414,7 +413,7 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                         const float d2 = dd * dd;
                         const uint32_t right = v.y & 0x3FFFFFFFu;
                         const bool go_left = qa < th;
-                        if (open || d2 < bound) {
+                        if (d2 < bound) {
                             if (sp < DF) s_stack[sp][tid] = make_uint2(go_left ? right : c + 1u, __float_as_uint(d2));
                             else slow = 1;
                             sp++;
@@ -436,7 +435,7 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                 }
                 int hit = 4;
 #pragma unroll
-                for (int j = 3; j >= 0; --j) hit = (j < avail && (open || ed2[j] < bound)) ? j : hit;
+                for (int j = 3; j >= 0; --j) hit = (j < avail && ed2[j] < bound) ? j : hit;
                 const int row_hit = avail - 1 - hit >= 0 ? avail - 1 - hit : 0;
                 const uint32_t far_hit = s32[(row_hit * BLK + tid) * 2];
                 const bool found = hit < 4;
