@@ -224,22 +224,8 @@ __global__ __launch_bounds__(kBlock) void icp_plane_accum_kernel(const uint2* __
             D3 nb[5];
 #pragma unroll
             for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, j == 4 ? s4 : nn[(size_t)j * nn_pitch + gi]);
-            double a[4][5], v[4][4];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) { a[0][j] = nb[j].x; a[1][j] = nb[j].y; a[2][j] = nb[j].z; a[3][j] = 1.0; }
-            jacobi_svd_onesided<5, 4>(a, v);
-            int best = 0;
-            double bn = 1e300;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                double s = 0.0;
-#pragma unroll
-                for (int r = 0; r < 5; ++r) s += a[c][r] * a[c][r];
-                if (s < bn) { bn = s; best = c; }
-            }
             double n4[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) n4[r] = best == 0 ? v[0][r] : (best == 1 ? v[1][r] : (best == 2 ? v[2][r] : v[3][r]));
+            plane_null_vector(nb, n4);
             const D3 n3{n4[0], n4[1], n4[2]};
             bool fit = true;
 #pragma unroll
