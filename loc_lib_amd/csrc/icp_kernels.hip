@@ -201,7 +201,7 @@ __device__ __forceinline__ void R_hat(const double* R, const D3& q, double (&Rh)
 
 
 // K2, P2Plane: IcpRegistration::CaculateMatrixHAndBP2Plane (icp_registration.cpp:161-213) + math::FitPlane (math_utils.h:112-136).
-__global__ __launch_bounds__(kBlock) void icp_plane_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void icp_plane_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                  double max_plane_distance, double* __restrict__ partials, int kPlanePts) {
