@@ -3,7 +3,7 @@
 collects CPU R1 (the oracle is written in the reference's style: per-query std::vector + std::priority_queue, pointer nodes —
 1 thread), CPU R3 (same, scan-parallel over all host cores), GPU scans/s, ms per GN iteration, roofline fraction, pose delta.
 
-    python3 tools/baseline_table.py --out gpurun_out/baseline_table.json
+    python3 tests/perf/baseline_table.py --out gpurun_out/baseline_table.json
 """
 import argparse
 import json
@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
@@ -79,7 +79,7 @@ def main():
     rows.append(row_from_bench("3a: vs 10M-pt map, P2Plane (64 resident scans)", run_bench("--scans-per-gpu", "64", *steps)))
     rows.append(row_from_bench("3b: vs 10M-pt map, direct NDT (64 resident scans)", run_bench("--scans-per-gpu", "64", "--method", "ndt", *steps)))
     rows.append(row_from_bench("4: 256 scans vs 10M-pt map, P2Plane, 1 GPU of the 8 (scan-sharded, no data-path collective)", run_bench(*steps)))
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pipeline_microbench.py"), "--only", "stream"], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "perf", "pipeline_microbench.py"), "--only", "stream"], capture_output=True, text=True, timeout=900)
     st = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])["stream"]
     rows.append(dict(config="5: streaming loop (upload, removeNaN, voxel filter, P2Plane vs local map, keyframe every 5th: submap + re-ingest)",
                      gpu_scans_s=st["scans_per_s"], ms_per_scan=st["ms_per_scan"], pose_delta_m=st["max_pose_abs_diff"], local_map_points=st["local_map_points"]))
