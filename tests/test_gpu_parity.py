@@ -113,6 +113,30 @@ def test_icp_hb_unbounded_map_and_far_queries_take_the_exact_kernel(gpu_ctx, api
     _hb_close(Hg, Bg, Ho, Bo)
 
 
+def test_icp_hb_on_exactly_planar_neighbourhoods(gpu_ctx, api, locref):
+    """Noise-free planes: the 5×4 [x y z 1] matrix of every neighbourhood is exactly rank 3 (smallest singular value = rounding
+    noise). The plane 4-vector must still be the true plane (device: orthogonal complement of the three dominant columns)."""
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(-30, 30, (60000, 2))
+    planes = [(0.3, 0.5, 2.0), (-0.2, 0.1, -1.0), (0.0, 0.0, 5.0)]
+    pts = []
+    for k, (a, b, c) in enumerate(planes):
+        sel = xy[k::3]
+        pts.append(np.stack([sel[:, 0], sel[:, 1], a * sel[:, 0] + b * sel[:, 1] + c], 1))
+    m = np.concatenate(pts).astype(np.float32)
+    q = m[rng.choice(len(m), 4000, replace=False)].astype(np.float64) + rng.normal(0, 0.03, (4000, 3))
+    s = q.astype(np.float32)
+    pose = np.array([0.001, -0.002, 0.0015, 1.0, 0.02, -0.01, 0.015])
+    pose[:4] /= np.linalg.norm(pose[:4])
+    gpu_ctx.icp_set_target(m)
+    icp = locref.Icp(method=2)
+    icp.set_target(m)
+    ok_o, Ho, Bo, eff_o = icp.hb(s, pose)
+    ok_g, Hg, Bg, eff_g = gpu_ctx.icp_hb(s, pose, api.icp_opts(method=2))
+    assert ok_g == ok_o and eff_g == eff_o and eff_o > 3000
+    _hb_close(Hg, Bg, Ho, Bo)
+
+
 def test_icp_hb_exact_search_mode_of_the_tree(gpu_ctx, api, locref, small_world):
     """SetEnableANN(false) (kdtree.cpp:285-288): exact pruning rule through the same tree."""
     m, s, pose = small_world["map"], small_world["scan2k"], small_world["init_pose"]
