@@ -260,13 +260,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
 __global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
-                                                                 double max_nn_distance, double* __restrict__ partials) {
+                                                                 double max_nn_distance, double* __restrict__ partials, int pts) {
     const int scan = blockIdx.y;
     if (st[scan].done) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
     double acc[28];
 #pragma unroll
     for (int v = 0; v < 28; ++v) acc[v] = 0.0;
+#pragma unroll 1
+    for (int pp = 0; pp < pts; ++pp) {  // several points per thread before the 28-value wave reduction (see the plane kernel)
+    const int i = (blockIdx.x * pts + pp) * kBlock + threadIdx.x;
     if (i < counts[scan]) {
         const size_t gi = (size_t)scan * max_n + i;
         const uint32_t s0 = nn[gi];
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __
             const D3 e3 = leaf_point(tree, s0) - qs;
             const double dis2 = dot3(e3, e3);
             if (!(dis2 > max_nn_distance)) {
-                acc[27] = 1.0;
+                acc[27] += 1.0;
                 double Rh[3][3];
                 R_hat(st[scan].R, q, Rh);
                 double J[3][6];
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __
             }
         }
     }
+    }
     block_reduce_store<28>(acc, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
 }
 
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void icp_line_accum_kernel(const uint2* __r
                                                                 double max_line_distance, double* __restrict__ partials) {
     const int scan = blockIdx.y;
     if (st[scan].done) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int i = blockIdx.x * kBlock + threadIdx.x;  // one point per thread: a loop here costs 70 VGPRs and half the occupancy
     double acc[28];
 #pragma unroll
     for (int v = 0; v < 28; ++v) acc[v] = 0.0;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void icp_line_accum_kernel(const uint2* __r
                 if (dot3(c, c) > max_line_distance) fit = false;
             }
             if (fit) {
-                acc[27] = 1.0;
+                acc[27] += 1.0;
                 const D3 e3 = cross3(d, qs - p0);  // SO3::hat(d) * (qs - p0)
                 if (!(sqrt(dot3(e3, e3)) > max_line_distance)) {
                     const double hd[3][3] = {{0.0, -d.z, d.y}, {d.z, 0.0, -d.x}, {-d.y, d.x, 0.0}};
@@ -623,25 +626,20 @@ bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, i
 
 int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
     const int blocks = (a.max_n + kBlock - 1) / kBlock;
-    if (method == 2) {
-        // points per thread: amortise the wave reduction when the batch already fills the chip; 1 for small launches (latency)
-        static const int forced = [] { const char* e = getenv("LOCGPU_PLANE_PTS"); return e ? atoi(e) : 0; }();
-        const long total_blocks = (long)blocks * a.n_scans;
-        int pts = forced > 0 ? forced : (total_blocks >= 8192 ? 8 : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1)));
-        if (pts > 8) pts = 8;
-        const int gx = (blocks + pts - 1) / pts;
-        hipLaunchKernelGGL(icp_plane_accum_kernel, dim3(gx, a.n_scans), dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate,
-                           a.partials, pts);
-        return gx;
-    }
-    dim3 grid(blocks, a.n_scans);
-    if (method == 1)
-        hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate,
-                           a.partials);
+    // points per thread: amortise the wave reduction when the batch already fills the chip; 1 for small launches (latency)
+    static const int forced = [] { const char* e = getenv("LOCGPU_PLANE_PTS"); return e ? atoi(e) : 0; }();
+    const long total_blocks = (long)blocks * a.n_scans;
+    int pts = forced > 0 ? forced : (total_blocks >= 8192 ? 8 : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1)));
+    if (pts > 8) pts = 8;
+    if (method == 1) pts = 1;  // the line kernel handles one point per thread
+    const dim3 grid((blocks + pts - 1) / pts, a.n_scans);
+    if (method == 2)
+        hipLaunchKernelGGL(icp_plane_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts);
+    else if (method == 1)
+        hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials);
     else
-        hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate,
-                           a.partials);
-    return blocks;
+        hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts);
+    return (int)grid.x;
 }
 
 void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
