@@ -194,6 +194,56 @@ __device__ __forceinline__ void plane_null_vector(const D3 (&nb)[5], double (&n4
     n4[0] = w0 * rw; n4[1] = w1 * rw; n4[2] = w2 * rw; n4[3] = w3 * rw;
 }
 
+// Right singular vector of the LARGEST singular value of the 5×3 matrix of centred neighbours — the line direction
+// math::FitLine takes from JacobiSVD (math_utils.h:152-154: V.col(0)), up to its sign, which cancels in H and B. Same scheme
+// as plane_null_vector: R from modified Gram–Schmidt, one-sided Jacobi on the columns of Rᵀ; the dominant right singular
+// vector is the largest column of the rotated matrix, normalised (accurate precisely because its singular value is large).
+__device__ __forceinline__ D3 line_direction(const D3 (&dl)[5]) {
+#pragma clang fp contract(fast)
+    double a[3][5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { a[0][j] = dl[j].x; a[1][j] = dl[j].y; a[2][j] = dl[j].z; }
+    double l[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double nrm2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) nrm2 += a[k][i] * a[k][i];
+        const double rn = nrm2 > 0.0 ? rsqrt_refined(nrm2) : 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) l[k][i] = 0.0;
+        l[k][k] = nrm2 * rn;
+        double q[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) q[i] = a[k][i] * rn;
+#pragma unroll
+        for (int j = k + 1; j < 3; ++j) {
+            double r = 0.0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) r += q[i] * a[j][i];
+            l[k][j] = r;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) a[j][i] -= r * q[i];
+        }
+    }
+    double unused[3][3];
+    jacobi_svd_onesided<3, 3, false>(l, unused);
+    int best = 0;
+    double bn = -1.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double sn = (l[c][0] * l[c][0] + l[c][1] * l[c][1]) + l[c][2] * l[c][2];
+        if (sn > bn) { bn = sn; best = c; }
+    }
+    const double rw = bn > 0.0 ? rsqrt_refined(bn) : 0.0;
+    D3 d;
+    d.x = (best == 0 ? l[0][0] : (best == 1 ? l[1][0] : l[2][0])) * rw;
+    d.y = (best == 0 ? l[0][1] : (best == 1 ? l[1][1] : l[2][1])) * rw;
+    d.z = (best == 0 ? l[0][2] : (best == 1 ? l[1][2] : l[2][2])) * rw;
+    if (!(bn > 0.0)) d.x = 1.0;  // all five neighbours coincide: JacobiSVD of the zero matrix returns V = I, i.e. (1, 0, 0)
+    return d;
+}
+
 // 6×6 partial-pivot LU: determinant and (if non-zero) solution of H x = b. What Eigen's fixed-size
 // 6×6 determinant()/inverse() do (icp_registration.cpp:210,364). Runs in one thread.
 __device__ __host__ inline double lu6_det_solve(const double* H, const double* b, double* x) {

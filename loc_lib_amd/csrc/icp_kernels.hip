@@ -300,13 +300,15 @@ __global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __
 __global__ __launch_bounds__(kBlock) void icp_line_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                 const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                 const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
-                                                                double max_line_distance, double* __restrict__ partials) {
+                                                                double max_line_distance, double* __restrict__ partials, int pts) {
     const int scan = blockIdx.y;
     if (st[scan].done) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;  // one point per thread: a loop here costs 70 VGPRs and half the occupancy
     double acc[28];
 #pragma unroll
     for (int v = 0; v < 28; ++v) acc[v] = 0.0;
+#pragma unroll 1
+    for (int pp = 0; pp < pts; ++pp) {
+    const int i = (blockIdx.x * pts + pp) * kBlock + threadIdx.x;
     if (i < counts[scan]) {
         const size_t gi = (size_t)scan * max_n + i;
         const uint32_t s4 = nn[4 * nn_pitch + gi];
@@ -321,23 +323,10 @@ __global__ __launch_bounds__(kBlock) void icp_line_accum_kernel(const uint2* __r
 #pragma unroll
             for (int j = 0; j < 5; ++j) sum = sum + nb[j];
             const D3 p0{sum.x / 5.0, sum.y / 5.0, sum.z / 5.0};
-            double a[3][5], v[3][3];
+            D3 dl[5];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) { const D3 d = nb[j] - p0; a[0][j] = d.x; a[1][j] = d.y; a[2][j] = d.z; }
-            jacobi_svd_onesided<5, 3>(a, v);
-            int best = 0;
-            double bn = -1.0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double s = 0.0;
-#pragma unroll
-                for (int r = 0; r < 5; ++r) s += a[c][r] * a[c][r];
-                if (s > bn) { bn = s; best = c; }
-            }
-            D3 d;
-            d.x = best == 0 ? v[0][0] : (best == 1 ? v[1][0] : v[2][0]);
-            d.y = best == 0 ? v[0][1] : (best == 1 ? v[1][1] : v[2][1]);
-            d.z = best == 0 ? v[0][2] : (best == 1 ? v[1][2] : v[2][2]);
+            for (int j = 0; j < 5; ++j) dl[j] = nb[j] - p0;
+            const D3 d = line_direction(dl);
             bool fit = true;
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
@@ -380,6 +369,7 @@ __global__ __launch_bounds__(kBlock) void icp_line_accum_kernel(const uint2* __r
                 }
             }
         }
+    }
     }
     block_reduce_store<28>(acc, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
 }
@@ -631,12 +621,11 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
     const long total_blocks = (long)blocks * a.n_scans;
     int pts = forced > 0 ? forced : (total_blocks >= 8192 ? 8 : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1)));
     if (pts > 8) pts = 8;
-    if (method == 1) pts = 1;  // the line kernel handles one point per thread
     const dim3 grid((blocks + pts - 1) / pts, a.n_scans);
     if (method == 2)
         hipLaunchKernelGGL(icp_plane_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts);
     else if (method == 1)
-        hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials);
+        hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts);
     else
         hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts);
     return (int)grid.x;
