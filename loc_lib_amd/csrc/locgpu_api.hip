@@ -413,7 +413,7 @@ bool IterLauncher::launch(int do_update) {
             launch_inc_accum(ctx->inc, ctx->ndt_opts.res_outlier_th, ctx->ndt_opts.nearby_type == 0 ? 1 : 7, b->d_src, b->d_counts, b->d_state,
                              b->max_n, b->n_scans, b->d_partials, s);
         else
-            launch_ndt_accum(ctx->ndt, b->d_src, b->d_counts, b->d_state, b->max_n, b->n_scans, b->d_partials, s);
+            n_partial_blocks = launch_ndt_accum(ctx->ndt, b->d_src, b->d_counts, b->d_state, b->max_n, b->n_scans, b->d_partials, s);
     }
     mark();
     launch_gn_solve(b->d_partials, n_partial_blocks, b->d_state, b->n_scans, prm, do_update, b->d_hb, s);

@@ -207,13 +207,15 @@ __global__ __launch_bounds__(kBlock) void ndt_accum_kernel(const unsigned long l
                                                            const double* __restrict__ mu, const double* __restrict__ info, size_t cap_mask,
                                                            double inv_voxel, double res_th, int n_nearby, const float4* __restrict__ src,
                                                            const int* __restrict__ counts, const PoseState* __restrict__ st, int max_n,
-                                                           double* __restrict__ partials) {
+                                                           double* __restrict__ partials, int pts) {
     const int scan = blockIdx.y;
     if (st[scan].done) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
     double acc[28];
 #pragma unroll
     for (int v = 0; v < 28; ++v) acc[v] = 0.0;
+#pragma unroll 1
+    for (int pp = 0; pp < pts; ++pp) {  // several points per thread before the 28-value block reduction (≈ as costly as a point)
+    const int i = (blockIdx.x * pts + pp) * kBlock + threadIdx.x;
     if (i < counts[scan]) {
         const float4 p = src[(size_t)scan * max_n + i];
         const D3 q{(double)p.x, (double)p.y, (double)p.z};
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void ndt_accum_kernel(const unsigned long l
             n_acc += 1.0;
             esum = esum + e;
         }
-        acc[27] = 1.0;  // effective_num++ once per source point (ndt cpp:432)
+        acc[27] += 1.0;  // effective_num++ once per source point (ndt cpp:432)
         if (n_acc > 0.0) {
             double Rh[3][3];  // R·hat(q); the zeros of hat() drop out exactly
             const double* R = st[scan].R;
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(kBlock) void ndt_accum_kernel(const unsigned long l
             }
         }
     }
+    }
     // block reduce (same scheme as the ICP accumulators)
     __shared__ double s_part[kBlock / 64][kAccW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -302,11 +305,15 @@ __global__ __launch_bounds__(kBlock) void ndt_accum_kernel(const unsigned long l
     }
 }
 
-void launch_ndt_accum(const NdtTable* t, const float4* src, const int* counts, const PoseState* st, int max_n, int n_scans, double* partials,
-                      hipStream_t s) {
-    dim3 grid((max_n + kBlock - 1) / kBlock, n_scans);
+int launch_ndt_accum(const NdtTable* t, const float4* src, const int* counts, const PoseState* st, int max_n, int n_scans, double* partials,
+                     hipStream_t s) {
+    const int blocks = (max_n + kBlock - 1) / kBlock;
+    const long total_blocks = (long)blocks * n_scans;
+    const int pts = total_blocks >= 8192 ? 8 : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1));
+    dim3 grid((blocks + pts - 1) / pts, n_scans);
     hipLaunchKernelGGL(ndt_accum_kernel, grid, dim3(kBlock), 0, s, t->d_keys, t->d_vid, t->d_mu, t->d_info, t->cap - 1, t->inv_voxel, t->res_outlier_th,
-                       t->n_nearby, src, counts, st, max_n, partials);
+                       t->n_nearby, src, counts, st, max_n, partials, pts);
+    return (int)grid.x;  // partial blocks per scan
 }
 
 }  // namespace locgpu

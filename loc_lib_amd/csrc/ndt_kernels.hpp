@@ -44,7 +44,7 @@ hipError_t ndt_build(NdtTable& t, const float4* d_pts, size_t n, double voxel_si
 void ndt_table_free(NdtTable& t);
 
 // K5: per-point 7-voxel probe + χ² gate + un-weighted JᵀJ / Jᵀe sums (AlignNdt inner loop, ndt cpp:399-433).
-void launch_ndt_accum(const NdtTable* t, const float4* src, const int* counts, const PoseState* st, int max_n, int n_scans, double* partials,
+int launch_ndt_accum(const NdtTable* t, const float4* src, const int* counts, const PoseState* st, int max_n, int n_scans, double* partials,
                       hipStream_t s);
 
 }  // namespace locgpu
