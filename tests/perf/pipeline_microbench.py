@@ -76,6 +76,20 @@ def filters_section(ctx, locref, map_points, reps):
         out["voxel_" + name]["host_pointer_ms"] = t_host * 1e3
         dev.close()
         res.close()
+    # LOAM feature picker on a full 64-ring scan
+    ring = (np.arange(len(scan)) // 1800).astype(np.uint8)
+    dev = api.Cloud(ctx, scan)
+    t_gpu = timed(lambda: dev.loam_extract(ring, 64), reps)
+    edge, surf = dev.loam_extract(ring, 64)
+    t0 = time.perf_counter()
+    e_ref, s_ref = locref.loam_extract(scan, ring, 64, order=locref.SORT_STABLE)
+    t_cpu = time.perf_counter() - t0
+    n = len(scan)
+    alg = n * (16 + 1) + (len(e_ref) + len(s_ref)) * 16
+    out["loam_extract_scan_115k"] = dict(points=n, edge_points=len(e_ref), surf_points=len(s_ref), gpu_ms=t_gpu * 1e3, cpu_ms=t_cpu * 1e3,
+                                         identical=bool(np.array_equal(edge.download(), e_ref) and np.array_equal(surf.download(), s_ref)),
+                                         mpoints_per_s=n / t_gpu / 1e6, alg_bytes=int(alg), alg_GBs=alg / t_gpu / 1e9, frac_of_8TBs=alg / t_gpu / 8e12)
+    dev.close()
     return out
 
 
