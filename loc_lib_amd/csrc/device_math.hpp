@@ -55,6 +55,16 @@ __device__ __host__ inline void quat_to_R(const double* q, double* R) {
     R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
 }
 
+// 1/√x for x > 0 to double precision: v_rsq_f64 refined by two Newton steps.
+__device__ __forceinline__ double rsqrt_refined(double x) {
+#pragma clang fp contract(fast)
+    const double hx = 0.5 * x;
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - hx * r * r);
+    r = r * (1.5 - hx * r * r);
+    return r;
+}
+
 // One-sided (Hestenes) Jacobi SVD, M×N, columns in a[N][M], right vectors accumulated in v[N][N].
 // Fully unrolled over (p,q) so both arrays live in VGPRs; the sweep loop exits per lane when a sweep made no rotation.
 // This is FP64-issue bound, so FMA contraction is allowed HERE (results differ from the un-fused CPU oracle by
@@ -88,12 +98,14 @@ __device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&
                     // t = 2γ / (d + sign(d)·√(d²+4γ²)) with d = β−α: one sqrt and one divide; c = 1/√(1+t²) from
                     // v_rsq_f64 refined by two Newton steps (|c²+s²−1| ≲ 2e-16, as good as the divide-based form).
                     const double d = beta - alpha, g2 = 2.0 * gamma;
-                    const double r = sqrt(d * d + g2 * g2);
-                    const double t = g2 / (d + (d >= 0.0 ? r : -r));
-                    const double x = 1.0 + t * t, hx = 0.5 * x;
-                    double c = __builtin_amdgcn_rsq(x);
-                    c = c * (1.5 - hx * c * c);
-                    c = c * (1.5 - hx * c * c);
+                    const double x2 = d * d + g2 * g2;                 // > 0 here (γ ≠ 0)
+                    const double r = x2 * rsqrt_refined(x2);           // √x2 without the IEEE sqrt expansion
+                    const double den = d + (d >= 0.0 ? r : -r);        // |den| ≥ |2γ| > 0
+                    double inv = __builtin_amdgcn_rcp(den);            // 1/den: v_rcp_f64 + two Newton steps instead of the IEEE divide
+                    inv = inv * (2.0 - den * inv);
+                    inv = inv * (2.0 - den * inv);
+                    const double t = g2 * inv;
+                    const double c = rsqrt_refined(1.0 + t * t);
                     const double s = c * t;
 #pragma unroll
                     for (int i = 0; i < M; ++i) {
@@ -114,16 +126,6 @@ __device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&
         }
         if (!rotated) break;
     }
-}
-
-// 1/√x for x > 0 to double precision: v_rsq_f64 refined by two Newton steps.
-__device__ __forceinline__ double rsqrt_refined(double x) {
-#pragma clang fp contract(fast)
-    const double hx = 0.5 * x;
-    double r = __builtin_amdgcn_rsq(x);
-    r = r * (1.5 - hx * r * r);
-    r = r * (1.5 - hx * r * r);
-    return r;
 }
 
 // Right singular vector of the smallest singular value of the 5×4 matrix A = [x y z 1] (rows = the five neighbours) — what
