@@ -4,10 +4,15 @@
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 64×1800-point synthetic LiDAR scans
 (cityblock-v1) registered against ONE 10 M-point map with the reference's default point-to-plane ICP
 (IcpOptions defaults, icp_registration.hpp:29-37; reference-faithful alpha=0.1 KD-tree search, kdtree.h:128-129).
-One "step" = one pass of the hot path over one batch: every rank aligns its own `--scans-per-gpu` resident scans
-(batched many-scans-vs-one-map mode); the map, the tree and the scans are in HBM before the timed region starts.
-Multi-GPU: scans are sharded across ranks with no data-path collective (each scan's Gauss–Newton loop is local);
-`value` = scans all ranks completed ÷ max-over-ranks time ⇒ weak scaling.
+One "step" = one pass of the hot path over one batch: every rank aligns `--scans-per-gpu` scans (batched many-scans-vs-one-map
+mode). The map and its tree are in HBM before the timed region starts. The SCANS are not: scans/sec includes the source deep
+copy of every ScanMatch call (SetSource, icp_registration.cpp:221,252-265) — every step aligns a batch that
+was copied host → HBM for it through pinned staging on a copy stream, while the previous step's Gauss–Newton loop ran
+(two batches alternate as a double buffer; `--resident` keeps one batch in HBM instead and is reported as the secondary number).
+Multi-GPU, default (`--scaling weak`): every rank aligns its own `--scans-per-gpu` scans, no data-path collective (each scan's
+Gauss–Newton loop is local); `value` = scans all ranks completed ÷ max-over-ranks time. `--scaling strong` is BASELINE.json
+configs[3] as written: `--total-scans` (256) scans in all, sharded contiguously over the ranks, per-iteration RCCL all-reduce of
+the per-scan normal equations inside liblocgpu.so (every rank solves every scan and holds all poses).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8 ...
@@ -64,7 +69,7 @@ def cpu_baseline(map_xyz, scans, inits, seconds_budget=20.0, method="p2plane"):
 
 def load_traffic(kernel_name, scans_per_gpu, map_points, method):
     """HBM bytes per launch of `kernel_name` from the newest committed PMC collection (tools/collect_traffic.py) made on the
-    same workload, or None. bench.py cannot run rocprofv3 on itself; the collection is a separate --pmc run of this script."""
+    same workload, or None."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
@@ -81,6 +86,48 @@ def load_traffic(kernel_name, scans_per_gpu, map_points, method):
     return best
 
 
+def measure_traffic_live(kernel_name, passthrough_args, budget_s=240.0):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script (2 steps, same workload) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` — separate passes, no tracing, the program directly after `--`, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes — then (2·FETCH_SIZE + WRITE_SIZE)·1024 (both counters are KiB; gfx950
+    FETCH_SIZE counts half the bytes of wide reads). Children are ordinary subprocesses (never an exec of this process).
+    Returns (bytes_per_launch | None, note)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    base = [a for a in passthrough_args]
+    child = ["python3", os.path.abspath(__file__)] + base + ["--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--traffic", "none"]
+    want = kernel_name.split("(")[0]
+    vals = {}
+    t_start = time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        outdir = tempfile.mkdtemp(prefix="locgpu_pmc_", dir="/tmp")
+        try:
+            left = budget_s - (time.time() - t_start)
+            if left < 20:
+                return None, "PMC passes ran out of their %.0f s budget" % budget_s
+            subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", outdir, "--"] + child, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", timeout=left, check=True)
+            agg = collections.defaultdict(list)
+            for f in glob.glob(os.path.join(outdir, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and want in r["Kernel_Name"]:
+                        agg[counter].append(float(r["Counter_Value"]))
+            if not agg[counter]:
+                return None, "no %s rows for %s" % (counter, want)
+            vals[counter] = sum(agg[counter]) / len(agg[counter])
+        except Exception as e:  # a failed profile never fails the bench
+            return None, "%s pass failed: %s" % (counter, type(e).__name__)
+        finally:
+            shutil.rmtree(outdir, ignore_errors=True)
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 steps each, (2*FETCH+WRITE)*1024"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,9 +140,14 @@ def main():
     ap.add_argument("--search", choices=["tree", "tree_exact", "grid"], default="tree",
                     help="tree = the reference's default alpha=0.1 approximate KD-tree search (headline); tree_exact / grid = "
                          "SetEnableANN(false) semantics through the tree or through the exact cell grid")
-    ap.add_argument("--include-upload", action="store_true",
-                    help="time host-buffer hand-over too: every step re-creates the batch from host clouds (pack + H2D over PCIe). "
-                         "Reported for DESIGN.md only; never the headline value")
+    ap.add_argument("--resident", action="store_true",
+                    help="secondary number: the scans are uploaded once before the timed region (no per-step H2D)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --scans-per-gpu scans on every rank, no collective; strong: --total-scans in all, sharded over the "
+                         "ranks with the per-iteration RCCL all-reduce (BASELINE configs[3])")
+    ap.add_argument("--total-scans", type=int, default=256)
+    ap.add_argument("--traffic", choices=["live", "profiles", "none"], default="live",
+                    help="roofline.traffic: live = two rocprofv3 --pmc child runs now (1 GPU only), profiles = newest committed collection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -113,26 +165,44 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
 
-    from loc_lib_amd import api, synth
+    from loc_lib_amd import api, multi_gpu, synth
 
-    B = args.scans_per_gpu
+    strong = args.scaling == "strong"
     ctx = api.Context(local_rank)  # fails loudly without a GPU / without liblocgpu.so
+    use_comm = dist is not None or strong
+    if use_comm:
+        multi_gpu.init_comm(ctx, dist)  # RCCL communicator inside liblocgpu.so (one rank when not launched by torchrun)
 
-    # ---- inputs (untimed): map, tree ingest, this rank's scans, all resident in HBM
+    # ---- inputs (untimed): map, tree ingest — resident in HBM before the timed region
     t0 = time.time()
-    map_xyz = synth.make_map(args.map_points)
+    map_xyz = synth.make_map(args.map_points) if (rank == 0 or not use_comm or args.method == "ndt") else None
     t_map = time.time() - t0
     t0 = time.time()
-    ctx.icp_set_target(map_xyz)
+    if use_comm:
+        ctx.icp_set_target_bcast(map_xyz, root=0)  # ONE host tree build per node, packed tree broadcast over xGMI
+    else:
+        ctx.icp_set_target(map_xyz)
     t_ingest = time.time() - t0
     tinfo = ctx.icp_target_info()
-    scan_ids = [(rank * B + i) % 256 for i in range(B)]
-    uniq = sorted(set(scan_ids))
-    scan_of = {sid: synth.make_scan(sid) for sid in uniq}
-    scans = [scan_of[sid] for sid in scan_ids]
-    inits = np.stack([synth.make_pose(sid)[1] for sid in scan_ids])
-    truth = np.stack([synth.make_pose(sid)[0] for sid in scan_ids])
-    batch = ctx.batch(scans)
+    if strong:
+        n_total = args.total_scans
+        lo, hi = multi_gpu.shard_range(n_total, rank, world)
+        all_ids = [i % 256 for i in range(n_total)]
+    else:
+        n_total = args.scans_per_gpu
+        lo, hi = 0, n_total
+        all_ids = [(rank * n_total + i) % 256 for i in range(n_total)]
+    scan_of = {sid: synth.make_scan(sid) for sid in sorted(set(all_ids[lo:hi]))}
+    scans = [scan_of[sid] for sid in all_ids[lo:hi]]          # the scans THIS rank holds
+    inits = np.stack([synth.make_pose(sid)[1] for sid in all_ids])   # poses of the whole batch (all of it on every rank when strong)
+    truth = np.stack([synth.make_pose(sid)[0] for sid in all_ids])
+    B_local = len(scans)
+    pts_per_scan = len(scans[0])
+
+    def new_batch():
+        return ctx.batch(scans, first=lo, n_total=n_total) if strong else ctx.batch(scans)
+
+    bufs = [new_batch()] if args.resident else [new_batch(), new_batch()]
     method = dict(p2plane=api.P2PLANE, p2line=api.P2LINE, p2p=api.P2P, ndt=-1)[args.method]
     opts = api.icp_opts(method=max(method, 0))  # every other field = reference default
     if args.search == "grid":
@@ -143,30 +213,36 @@ def main():
         t0 = time.time()
         ctx.ndt_set_target(map_xyz)           # NdtOptions defaults: voxel 1.0, NEARBY6, DIRECT_NDT
         t_ingest = time.time() - t0
-    align_resident = (lambda: ctx.ndt_align_batch(batch, inits)) if method < 0 else (lambda: ctx.icp_align_batch(batch, inits, opts))
 
-    def align_with_upload():
-        b2 = ctx.batch(scans)  # host clouds → pinned pack → H2D, like a ScanMatch call that is handed host buffers
-        try:
-            return ctx.ndt_align_batch(b2, inits) if method < 0 else ctx.icp_align_batch(b2, inits, opts)
-        finally:
-            b2.close()
+    def align_batch(b):
+        return ctx.ndt_align_batch(b, inits) if method < 0 else ctx.icp_align_batch(b, inits, opts)
 
-    align = align_with_upload if args.include_upload else align_resident
+    step_no = [0]
+
+    def step():
+        """One pass of the hot path over one batch. Streaming (default): start the host → HBM copy of the NEXT step's scans
+        (returns at once: a worker packs into pinned slots, a copy stream moves them), then align the batch whose copy was
+        started one step earlier. Every step issues exactly one upload and one alignment."""
+        i = step_no[0]
+        step_no[0] += 1
+        if args.resident:
+            return align_batch(bufs[0])
+        bufs[(i + 1) % 2].upload_async(scans)
+        return align_batch(bufs[i % 2])
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()  # device-wide: covers the library's compute and copy streams
 
     # ---- visit counts of exactly this workload (separate instrumented pass, untimed) → algorithmic bytes
     ctx.visit_count_enable(True)
-    out_poses, stats = align()
+    out_poses, stats = align_batch(bufs[0])
     vc = ctx.visit_count_read(reset=True)
     ctx.visit_count_enable(False)
 
     for _ in range(args.warmup):
-        align()
+        step()
 
     # ---- timed region: exactly `steps` steps; HIP events on the library's stream time each kernel launch
     ctx.profile_read(reset=True)
@@ -174,26 +250,29 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out_poses, stats = align()
+        out_poses, stats = step()
     barrier()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     prof = ctx.profile_read(reset=True)
+    for b in bufs:
+        b.upload_wait()
 
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    total_scans = world * B * args.steps
+    total_scans = (n_total if strong else world * n_total) * args.steps
     value = total_scans / dt
-    gn_iters = sum(s["iterations"] for s in stats)
+    own = slice(lo, hi)
+    gn_iters = sum(s["iterations"] for s in stats[own])   # scan-iterations THIS rank computed per step
     err_t = float(np.median(np.linalg.norm(out_poses[:, 4:] - truth[:, 4:], axis=1)))
 
     if rank == 0:
         # roofline of the dominant kernel over the timed region (all launches, partially idle ones included)
         k = 1 if args.method == "p2p" else 5
-        q = vc["queries"] if method >= 0 else sum(s["iterations"] for s in stats) * 115200
+        q = vc["queries"] if method >= 0 else gn_iters * pts_per_scan
         search_bytes = q * 16 + vc["nodes"] * 16 + q * 4 * k            # src float4 + one 16-B slot pair per node visit + index lists
         if args.search == "grid":
             # SURVEY §8(d) exact/grid formula: 16·N_cand + N_q·(12 + 4k); N_cand (distinct leaves in the cells any query's final
@@ -211,25 +290,41 @@ def main():
         else:
             kname, kbytes, kt, kn, kavg = ("ndt_accum_kernel" if method < 0 else "icp_%s_accum_kernel" % args.method), accum_bytes, t_accum, prof["accum_n"], prof["accum_ms"]
         launches_per_step = kn / args.steps
-        traffic = load_traffic(kname, B, args.map_points, args.method)
+        traffic, traffic_note = None, "not collected"
+        if args.traffic == "live" and world == 1 and dist is None:
+            passthrough = ["--scans-per-gpu", str(args.scans_per_gpu), "--map-points", str(args.map_points), "--method", args.method,
+                           "--search", args.search, "--scaling", args.scaling, "--total-scans", str(args.total_scans)] + (["--resident"] if args.resident else [])
+            traffic, traffic_note = measure_traffic_live(kname, passthrough)
+        if traffic is None and args.traffic != "none":
+            t2 = load_traffic(kname, args.scans_per_gpu, args.map_points, args.method)
+            if t2 is not None:
+                traffic, traffic_note = t2, "copied from the newest committed profiles/*traffic*.json of this workload (" + traffic_note + ")"
         achieved = (kbytes / 1e9) / (kt / 1e3) if kt > 0 else 0.0
         roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                        hbm_frac=(round(traffic / (kavg / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and kavg > 0 else None),
+                        traffic_source=traffic_note,
                         algorithmic_bytes_per_launch=int(kbytes / max(launches_per_step, 1)), avg_launch_ms=round(kavg, 5),
                         launches_per_step=launches_per_step,
                         nodes_per_query=round(vc["nodes"] / max(q, 1), 2), leaves_per_query=round(vc["leaves"] / max(q, 1), 2))
+        mode = "scans resident in HBM before the timed region (secondary number)" if args.resident else \
+               "includes scan H2D: every step aligns a batch copied host->HBM for it (pinned double buffer, copy stream, overlapped with the previous step)"
+        shard = ("strong scaling: %d scans in all sharded over %d rank(s), per-iteration RCCL all-reduce of the per-scan normal equations" % (n_total, world)) if strong \
+            else "scans sharded by rank, no collective"
         line = dict(metric="scans/sec (64x1800-pt scan vs 10M-pt map) + ICP iter ms", value=round(value, 3), unit="scans/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 4),
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", search_dtype="f32", data="synthetic",
-                    config=dict(workload="BASELINE configs[2]: %d scans/GPU x 115200 pts (64x1800, cityblock-v1) vs one %d-pt map, "
-                                         "%s, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), scans sharded by rank, no collective"
-                                         % (B, args.map_points, "direct NDT (voxel 1.0, NEARBY6)" if method < 0 else args.method.upper() + " ICP"),
-                                scans_per_gpu=B, map_points=args.map_points, search_mode=dict(tree="tree_faithful_ann", tree_exact="tree_faithful_exact", grid="grid_exact")[args.search], tree_depth=tinfo["depth"],
+                    higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f64", search_dtype="f32", data="synthetic",
+                    config=dict(workload="BASELINE configs[2]: %d scans/GPU x %d pts (64x1800, cityblock-v1) vs one %d-pt map, "
+                                         "%s, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), %s; %s"
+                                         % (B_local, pts_per_scan, args.map_points, "direct NDT (voxel 1.0, NEARBY6)" if method < 0 else args.method.upper() + " ICP", shard, mode),
+                                scans_per_gpu=B_local, map_points=args.map_points, scan_h2d_in_timed_region=not args.resident,
+                                search_mode=dict(tree="tree_faithful_ann", tree_exact="tree_faithful_exact", grid="grid_exact")[args.search], tree_depth=tinfo["depth"],
                                 tree_bytes=tinfo["bytes"]),
                     icp_iter_ms=round((t_search + t_accum + t_solve) / max(prof["search_n"] / args.steps, 1), 5),
                     icp_iter_ms_per_scan=round((t_search + t_accum + t_solve) / max(gn_iters, 1), 6),  # kernel ms of one step ÷ scan-iterations of one step
-                    gn_iterations_per_scan=round(gn_iters / B, 2),
+                    gn_iterations_per_scan=round(gn_iters / max(B_local, 1), 2),
                     kernel_ms_per_step=dict(search=round(t_search, 4), fit_accumulate=round(t_accum, 4), solve=round(t_solve, 4)),
+                    h2d_bytes_per_step=(0 if args.resident else B_local * pts_per_scan * 16),
                     median_translation_error_to_truth_m=round(err_t, 4),
                     setup_s=dict(map_gen=round(t_map, 2), tree_ingest=round(t_ingest, 2)),
                     roofline=roofline)
@@ -242,7 +337,8 @@ def main():
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
 
-    batch.close()
+    for b in bufs:
+        b.close()
     ctx.close()
     if dist is not None:
         dist.barrier()

@@ -133,6 +133,16 @@ LOCGPU_API int locgpu_transform_cloud(locgpu_ctx* ctx, const double pose[7], con
 LOCGPU_API int locgpu_batch_create(locgpu_ctx* ctx, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_scans,
                                    locgpu_batch** out);
 LOCGPU_API void locgpu_batch_destroy(locgpu_batch* b);
+/* The source deep copy of ScanMatch (SetSource, icp_registration.cpp:221,252-265) for a whole batch, overlapped with the GPU's work:
+ * locgpu_batch_create_empty reserves room for n_scans scans of at most max_points_per_scan points; locgpu_batch_upload_async
+ * replaces the batch's scans (counts[s] <= max_points_per_scan) and returns at once — a worker packs the strided host points
+ * into pinned slots and streams them to HBM on a copy stream of the batch's own, under whatever the context's compute stream
+ * is running (e.g. the align call of ANOTHER batch: two batches alternate as a double buffer). The host clouds must stay valid
+ * until locgpu_batch_upload_wait returns (it returns the upload's status); every align / hb call on the batch waits for its
+ * pending upload first. */
+LOCGPU_API int locgpu_batch_create_empty(locgpu_ctx* ctx, int n_scans, size_t max_points_per_scan, locgpu_batch** out);
+LOCGPU_API int locgpu_batch_upload_async(locgpu_batch* b, const void* const* srcs, const size_t* counts, size_t stride_bytes);
+LOCGPU_API int locgpu_batch_upload_wait(locgpu_batch* b);
 /* init_poses / out_poses: n_scans × 7 doubles (host). stats: n_scans entries or NULL. */
 LOCGPU_API int locgpu_icp_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const locgpu_icp_opts* opts,
                                       double* out_poses, locgpu_align_stats* stats);
@@ -145,6 +155,24 @@ LOCGPU_API int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const doubl
  * returns 1 in *stop when |dx| < eps. method selects the P2P "/16" quirk (icp cpp:287). */
 LOCGPU_API int locgpu_gn_update(const double hb[44], int method, int min_effective_pts, double eps, double pose[7], double dx[6],
                                 int* applied, int* stop);
+
+/* ---- One node, several GPUs (BASELINE.json configs[3]; no reference counterpart): one process per GPU, one context per process,
+ * the ranks joined by an RCCL communicator. A SHARDED batch has n_total scans; this rank holds the points of scans
+ * [first_scan, first_scan + n_local) — or, for one large alignment split by points, a slice of the points of every scan
+ * (first_scan = 0, n_local = n_total). Poses, convergence flags and normal equations exist for all n_total scans on every rank:
+ * in each Gauss–Newton iteration the per-scan sums (21 H + 6 B + effective_num; zeros for scans a rank does not hold) are
+ * all-reduced over xGMI on the compute stream and every rank solves every scan, so all ranks take the same decisions.
+ * The align / hb entry points are then COLLECTIVE (every rank calls them with the same poses and options; init_poses, out_poses
+ * and stats have n_total entries) and scan-sharded results are bit-identical to the single-GPU ones. */
+#define LOCGPU_COMM_ID_BYTES 128
+LOCGPU_API int locgpu_comm_unique_id(void* id_out /* LOCGPU_COMM_ID_BYTES, made on one rank and handed to all */);
+LOCGPU_API int locgpu_comm_init(locgpu_ctx* ctx, int rank, int world, const void* id);
+LOCGPU_API int locgpu_comm_info(const locgpu_ctx* ctx, int* rank, int* world);
+LOCGPU_API int locgpu_batch_create_sharded(locgpu_ctx* ctx, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_local,
+                                           int first_scan, int n_total, locgpu_batch** out);
+/* IcpRegistration::SetInputTarget, collective: rank `root` builds the KD-tree from ITS pts (the others' are ignored) and
+ * broadcasts the packed tree — one host build per node instead of one per GPU. */
+LOCGPU_API int locgpu_icp_set_target_bcast(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, int root);
 
 /* ---- NDT target: NdtRegistration::SetInputTarget → SetDirectNdtTargetCloud (ndt_registration.cpp:65-85, 87-148), or with
  * opts->method == 2 → SetIncNdtTargetCloud (:150-183): the voxel set then PERSISTS across calls (LRU of opts->capacity voxels,

@@ -35,7 +35,10 @@ ABI_SYMBOLS = [
     "locgpu_voxel_filter", "locgpu_crop_box", "locgpu_remove_nan",
     "locgpu_submap_create", "locgpu_submap_destroy", "locgpu_submap_add_keyframe", "locgpu_submap_cloud", "locgpu_submap_last_keyframe",
     "locgpu_submap_info", "locgpu_cloud_loam_extract", "locgpu_loam_extract",
+    "locgpu_batch_create_empty", "locgpu_batch_upload_async", "locgpu_batch_upload_wait",
+    "locgpu_comm_unique_id", "locgpu_comm_init", "locgpu_comm_info", "locgpu_batch_create_sharded", "locgpu_icp_set_target_bcast",
 ]
+COMM_ID_BYTES = 128
 NO_INTENSITY = ctypes.c_size_t(-1).value
 
 
@@ -116,6 +119,11 @@ def lib():
             "locgpu_submap_last_keyframe": (i32, [vp, vp]), "locgpu_submap_info": (i32, [vp, vp, vp]),
             "locgpu_cloud_loam_extract": (i32, [vp, vp, i32, vp, vp]),
             "locgpu_loam_extract": (i32, [vp, vp, sz, sz, sz, i32, sz, i32, vp, vp, vp, vp, sz, sz]),
+            "locgpu_batch_create_empty": (i32, [vp, i32, sz, vp]), "locgpu_batch_upload_async": (i32, [vp, vp, vp, sz]),
+            "locgpu_batch_upload_wait": (i32, [vp]),
+            "locgpu_comm_unique_id": (i32, [vp]), "locgpu_comm_init": (i32, [vp, i32, i32, vp]), "locgpu_comm_info": (i32, [vp, vp, vp]),
+            "locgpu_batch_create_sharded": (i32, [vp, vp, vp, sz, i32, i32, i32, vp]),
+            "locgpu_icp_set_target_bcast": (i32, [vp, vp, sz, sz, i32]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -127,6 +135,15 @@ def lib():
 
 def device_count():
     return int(lib().locgpu_device_count())
+
+
+def comm_unique_id():
+    """RCCL unique id (COMM_ID_BYTES bytes): make it on one rank, hand it to every rank's Context.comm_init."""
+    buf = (ctypes.c_char * COMM_ID_BYTES)()
+    rc = lib().locgpu_comm_unique_id(buf)
+    if rc != 0:
+        raise LocGpuError(rc, "locgpu_comm_unique_id failed")
+    return bytes(buf)
 
 
 def _cloud(a):
@@ -284,11 +301,34 @@ class Context:
         self._check(lib().locgpu_ndt_align_cloud(self._h, cloud._h, _pose(init_pose).ctypes.data, out.ctypes.data, ctypes.byref(st)))
         return out, _stats_dict(st)
 
+    # ---- several GPUs of one node: RCCL communicator + sharded batches
+    def comm_init(self, rank, world, uid):
+        """uid: COMM_ID_BYTES bytes from comm_unique_id() of one rank, handed to all (e.g. torch.distributed.broadcast)."""
+        buf = (ctypes.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(uid))
+        self._check(lib().locgpu_comm_init(self._h, int(rank), int(world), buf))
+
+    def comm_info(self):
+        r, w = ctypes.c_int(0), ctypes.c_int(1)
+        self._check(lib().locgpu_comm_info(self._h, ctypes.byref(r), ctypes.byref(w)))
+        return int(r.value), int(w.value)
+
+    def icp_set_target_bcast(self, cloud, root=0):
+        """Collective SetInputTarget: rank `root` builds the tree from its cloud and broadcasts it (other ranks may pass None)."""
+        if cloud is None:
+            self._check(lib().locgpu_icp_set_target_bcast(self._h, None, 0, 12, int(root)))
+        else:
+            c = _cloud(cloud)
+            self._check(lib().locgpu_icp_set_target_bcast(self._h, c.ctypes.data, c.shape[0], c.strides[0], int(root)))
+
     # ---- batches
-    def batch(self, scans):
-        return Batch(self, scans)
+    def batch(self, scans, first=None, n_total=None):
+        return Batch(self, scans, first=first, n_total=n_total)
+
+    def batch_empty(self, n_scans, max_points):
+        return Batch(self, None, n_scans=n_scans, max_points=max_points)
 
     def icp_align_batch(self, batch, init_poses, opts):
+        batch.upload_wait()
         ip = _pose(init_poses).reshape(batch.n_scans, 7)
         out = np.zeros_like(ip)
         st = (AlignStats * batch.n_scans)()
@@ -296,6 +336,7 @@ class Context:
         return out, [_stats_dict(s) for s in st]
 
     def ndt_align_batch(self, batch, init_poses):
+        batch.upload_wait()
         ip = _pose(init_poses).reshape(batch.n_scans, 7)
         out = np.zeros_like(ip)
         st = (AlignStats * batch.n_scans)()
@@ -303,6 +344,7 @@ class Context:
         return out, [_stats_dict(s) for s in st]
 
     def icp_hb_batch(self, batch, poses, opts):
+        batch.upload_wait()
         p = _pose(poses).reshape(batch.n_scans, 7)
         hb = np.zeros((batch.n_scans, 44))
         self._check(lib().locgpu_icp_hb_batch(self._h, batch._h, p.ctypes.data, ctypes.byref(opts), hb.ctypes.data))
@@ -497,27 +539,58 @@ class Submap:
 
 
 class Batch:
-    """A batch of scans resident in HBM (locgpu_batch)."""
+    """A batch of scans resident in HBM (locgpu_batch). ``n_scans`` = the scans poses are kept for (all n_total of a sharded batch)."""
 
-    def __init__(self, ctx, scans):
+    def __init__(self, ctx, scans, first=None, n_total=None, n_scans=None, max_points=None):
         self.ctx = ctx
+        self._h = ctypes.c_void_p()
+        self._keep = None
+        if scans is None:  # capacity only; fill with upload_async
+            self.n_local = self.n_scans = int(n_scans)
+            ctx._check(lib().locgpu_batch_create_empty(ctx._h, self.n_scans, int(max_points), ctypes.byref(self._h)))
+            return
+        scans, ptrs, cnts, stride = self._marshal(scans)
+        self.n_local = len(scans)
+        if n_total is None:
+            self.n_scans = self.n_local
+            ctx._check(lib().locgpu_batch_create(ctx._h, ptrs, cnts, stride, self.n_local, ctypes.byref(self._h)))
+        else:  # sharded: this rank holds scans [first, first + len(scans)) of n_total
+            self.n_scans = int(n_total)
+            ctx._check(lib().locgpu_batch_create_sharded(ctx._h, ptrs, cnts, stride, self.n_local, int(first or 0), self.n_scans, ctypes.byref(self._h)))
+
+    @staticmethod
+    def _marshal(scans):
         scans = [_cloud(s) for s in scans]
         if not scans:
             raise ValueError("empty batch")
         stride = scans[0].strides[0]
         if any(s.strides[0] != stride for s in scans):
             raise ValueError("all scans of a batch must share one point stride")
-        self.n_scans = len(scans)
-        self.counts = [s.shape[0] for s in scans]
-        ptrs = (ctypes.c_void_p * self.n_scans)(*[s.ctypes.data for s in scans])
-        cnts = (ctypes.c_size_t * self.n_scans)(*self.counts)
-        self._h = ctypes.c_void_p()
-        ctx._check(lib().locgpu_batch_create(ctx._h, ptrs, cnts, stride, self.n_scans, ctypes.byref(self._h)))
+        ptrs = (ctypes.c_void_p * len(scans))(*[s.ctypes.data for s in scans])
+        cnts = (ctypes.c_size_t * len(scans))(*[s.shape[0] for s in scans])
+        return scans, ptrs, cnts, stride
+
+    def upload_async(self, scans):
+        """Replace the batch's scans; returns at once (the copy runs beside the GPU's current work). The arrays are kept
+        alive here until upload_wait() / the next align call on this batch."""
+        self.upload_wait()
+        scans, ptrs, cnts, stride = self._marshal(scans)
+        if len(scans) != self.n_local:
+            raise ValueError("upload_async needs %d scans" % self.n_local)
+        self._keep = (scans, ptrs, cnts)
+        self.ctx._check(lib().locgpu_batch_upload_async(self._h, ptrs, cnts, stride))
+
+    def upload_wait(self):
+        if self._keep is not None:
+            rc = lib().locgpu_batch_upload_wait(self._h)
+            self._keep = None
+            self.ctx._check(rc)
 
     def close(self):
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
             lib().locgpu_batch_destroy(self._h)
         self._h = None
+        self._keep = None
 
     def __del__(self):
         self.close()

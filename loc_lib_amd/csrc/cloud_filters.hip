@@ -408,7 +408,7 @@ hipError_t voxel_filter_dev(locgpu_ctx* ctx, const locgpu_cloud* in, float leaf,
     const size_t n = in->n;
     *status = 0;
     if (n == 0) { *status = 2; out->n = 0; out->is_dense = 1; return hipSuccess; }
-    LOCGPU_TRY(ensure_scratch(ctx, n));
+    LOCGPU_TRY(ensure_scratch(ctx, n + 1));  // + 1: keys[0] is reused below as `start`, which has n_voxels + 1 ≤ n + 1 entries
     FilterScratch* S = scratch(ctx);
     hipStream_t s = ctx->stream;
     const int dense = in->is_dense;
@@ -429,7 +429,7 @@ hipError_t voxel_filter_dev(locgpu_ctx* ctx, const locgpu_cloud* in, float leaf,
     hipLaunchKernelGGL(voxel_head_kernel, dim3(blocks_for(n)), dim3(kFB), 0, s, S->keys[1], n, S->d_params, dense, S->head);
     tb = S->temp_bytes;
     LOCGPU_TRY(hipcub::DeviceScan::ExclusiveSum(S->temp, tb, S->head, S->rank, (int)n, s));
-    uint32_t* start = S->keys[0];  // free again after the sort; capacity ≥ n + 1
+    uint32_t* start = S->keys[0];  // free again after the sort; capacity ≥ n + 1 (ensure_scratch above)
     hipLaunchKernelGGL(voxel_starts_kernel, dim3(blocks_for(n)), dim3(kFB), 0, s, S->keys[1], S->head, S->rank, n, dense, start, S->d_params);
     LOCGPU_TRY(hipGetLastError());
     LOCGPU_TRY(read_params(ctx));

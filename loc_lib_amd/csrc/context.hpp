@@ -11,7 +11,7 @@
 #include "icp_kernels.hpp"
 
 struct NdtTable;  // ndt_kernels.hpp
-namespace locgpu { struct IncNdtState; struct FilterScratch; }  // ndt_inc.hpp, cloud_filters.hpp
+namespace locgpu { struct IncNdtState; struct FilterScratch; struct BatchUploader; }  // ndt_inc.hpp, cloud_filters.hpp
 
 struct locgpu_ctx {
     int device = 0;
@@ -42,6 +42,10 @@ struct locgpu_ctx {
     locgpu_batch* single = nullptr;
     size_t single_cap = 0;
 
+    // multi-GPU (locgpu_comm_init): RCCL communicator of the ranks that share sharded batches
+    void* comm = nullptr;  // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
+
     // measurement
     bool profile = false;
     std::vector<hipEvent_t> events;
@@ -55,7 +59,13 @@ struct locgpu_ctx {
 
 struct locgpu_batch {
     locgpu_ctx* ctx = nullptr;
-    int n_scans = 0, max_n = 0, blocks_per_scan = 0;
+    int n_scans = 0, max_n = 0, blocks_per_scan = 0;  // n_scans: the scans whose points THIS rank holds
+    // Sharded batch (locgpu_batch_create_sharded): the batch has n_total scans, this rank holds the points of scans
+    // [first, first + n_scans) — or, point-sharded, a slice of the points of every scan (first = 0, n_scans = n_total). Poses, flags
+    // and normal equations exist for all n_total scans on every rank. Unsharded: n_total = n_scans, first = 0.
+    int n_total = 0, first = 0;
+    bool sharded = false;
+    double* d_acc = nullptr;  // [n_total][kAccW] per-scan sums, all-reduced over the communicator (sharded batches only)
     size_t pitch = 0;  // n_scans * max_n
     float4* d_src = nullptr;
     int* d_counts = nullptr;
@@ -78,6 +88,7 @@ struct locgpu_batch {
     locgpu::PoseState* h_state = nullptr;  // pinned
     double* h_hb = nullptr;                // pinned
     std::vector<int> counts;
+    locgpu::BatchUploader* up = nullptr;   // pinned slots + copy stream of locgpu_batch_upload_async (batch_upload.hpp)
 };
 
 namespace locgpu {

@@ -169,13 +169,46 @@ __device__ __forceinline__ void plane_null_vector(const D3 (&nb)[5], double (&n4
     double unused[4][4];
     jacobi_svd_onesided<4, 4, false>(l, unused);
     int best = 0;
-    double bn = 1e300;
+    double bn = 1e300, mx = 0.0, sn4[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         double sn = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sn += l[c][r] * l[c][r];
+        sn4[c] = sn;
         if (sn < bn) { bn = sn; best = c; }
+        mx = sn > mx ? sn : mx;
+    }
+    // Rank-deficient neighbourhood (five collinear / coincident neighbours, exactly): fewer than three singular values above
+    // 1e-13·σmax. The null space then has two or more dimensions and Eigen's choice inside it is an accident of rounding; the rule
+    // used here ("rank-deficient neighbourhoods"; the CPU checker restates the same rule): the unit vector of the orthogonal complement of the dominant
+    // right singular vectors closest to e4, else e3, e2, e1 (first whose projection keeps ≥ 0.4 of its squared length).
+    const double thr = 1e-26 * mx;
+    const int rank = (sn4[0] > thr ? 1 : 0) + (sn4[1] > thr ? 1 : 0) + (sn4[2] > thr ? 1 : 0) + (sn4[3] > thr ? 1 : 0);
+    if (__builtin_expect(rank < 3, 0)) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        double nn = 0.0;
+#pragma unroll 1
+        for (int k = 3; k >= 0; --k) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = (i == k) ? 1.0 : 0.0;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (sn4[c] > thr) {  // dominant column: l[c] = σ·v, so (t·v)v = (t·l) l / |l|²
+                        const double d = ((t[0] * l[c][0] + t[1] * l[c][1]) + (t[2] * l[c][2] + t[3] * l[c][3])) / sn4[c];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t[i] -= d * l[c][i];
+                    }
+                }
+            }
+            nn = (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+            if (nn >= 0.4) break;
+        }
+        const double rn = nn > 0.0 ? 1.0 / sqrt(nn) : 0.0;
+        n4[0] = t[0] * rn; n4[1] = t[1] * rn; n4[2] = t[2] * rn; n4[3] = t[3] * rn;
+        return;
     }
     // the three other columns, by static selects (a dynamic register index would go through scratch)
     double u[3][4];

@@ -97,18 +97,24 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
     }
 }
 
-// Exact recomputation of the queries the fast kernel could not finish. Persistent-style 1-D grid over the list.
+// Exact recomputation of the queries the fast kernel could not finish (≈1e-6 of them on real maps: ≈30 per 256-scan launch).
+// One-wave workgroups over the list. A short list is dealt one query per WAVE (lane 0): 30 queries sharing a wave would each
+// pay the others' heap-emulation branches and the longest traversal; alone in its wave a query costs its own ≈40 dependent loads.
+// A long list (a lattice map: every distance ties) fills all 64 lanes of every wave.
+constexpr int kRedoWaves = 2048;
 template <int KMAX, int D>
-__global__ __launch_bounds__(kBlock) void icp_search_redo_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
-                                                                 const PoseState* __restrict__ st, uint32_t* __restrict__ nn, size_t nn_pitch,
-                                                                 int max_n, int k, float alpha_eff, const uint32_t* __restrict__ redo_list,
-                                                                 const unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats) {
-    __shared__ uint32_t s_far[D][kBlock];
-    __shared__ float s_d2[D][kBlock];
+__global__ __launch_bounds__(64) void icp_search_redo_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+                                                             const PoseState* __restrict__ st, uint32_t* __restrict__ nn, size_t nn_pitch,
+                                                             int max_n, int k, float alpha_eff, const uint32_t* __restrict__ redo_list,
+                                                             const unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats) {
+    __shared__ uint32_t s_far[D][64];
+    __shared__ float s_d2[D][64];
     const unsigned int n = *redo_count;
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0 && search_stats) atomicAdd(&search_stats[1], (unsigned long long)n);
-    for (unsigned int r = blockIdx.x * kBlock + tid; r < n; r += gridDim.x * kBlock) {
+    const unsigned int per_wave = min(64u, (n + gridDim.x - 1) / gridDim.x);  // queries a wave takes per round
+    if ((unsigned)tid >= per_wave) return;
+    for (unsigned int r = blockIdx.x * per_wave + tid; r < n; r += gridDim.x * per_wave) {
         const size_t gi = redo_list[r];
         const int scan = (int)(gi / (size_t)max_n);
         const float4 p = src[gi];
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void icp_search_redo_kernel(const uint2* __
         KnnHeap<KMAX> heap;
         uint32_t nvis = 0, lvis = 0, out[KMAX];
         int cnt;
-        tree_knn_flat<KMAX, D, false>(tree, (float)qs.x, (float)qs.y, (float)qs.z, k, alpha_eff, s_far, s_d2, tid, heap, nvis, lvis);
+        tree_knn_flat<KMAX, D, false, 64>(tree, (float)qs.x, (float)qs.y, (float)qs.z, k, alpha_eff, s_far, s_d2, tid, heap, nvis, lvis);
         heap_to_sorted<KMAX>(heap, out, cnt);
 #pragma unroll
         for (int j = 0; j < KMAX; ++j)
@@ -448,6 +454,27 @@ __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restri
     if (ps.iterations >= prm.max_iteration) ps.done = 1;
 }
 
+// First half of gn_solve_kernel for sharded batches (see launch.hpp): one block per GLOBAL scan.
+__global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* __restrict__ partials, int blocks_per_scan, const PoseState* __restrict__ st_all,
+                                                              int first, int n_local, double* __restrict__ acc) {
+    __shared__ double s_sum[kBlock / kAccW][kAccW];
+    const int g = blockIdx.x;
+    const int col = threadIdx.x & (kAccW - 1), chunk = threadIdx.x / kAccW;
+    constexpr int kChunks = kBlock / kAccW;
+    const int scan = g - first;
+    const bool mine = scan >= 0 && scan < n_local && !st_all[g].done;  // a finished scan's partials are stale: contribute zeros (nobody reads them)
+    double s = 0.0;
+    if (mine && col < 28)
+        for (int b = chunk; b < blocks_per_scan; b += kChunks) s += partials[((size_t)scan * blocks_per_scan + b) * kAccW + col];
+    s_sum[chunk][col] = s;
+    __syncthreads();
+    if (threadIdx.x < kAccW) {
+        double t = s_sum[0][threadIdx.x];
+        for (int c = 1; c < kChunks; ++c) t += s_sum[c][threadIdx.x];
+        acc[(size_t)g * kAccW + threadIdx.x] = threadIdx.x < 28 ? t : 0.0;
+    }
+}
+
 // pcl::transformPointCloud with the float32 4×4 (icp_registration.cpp:241): ((m0·x + m1·y) + m2·z) + m3 per row.
 __global__ __launch_bounds__(kBlock) void transform_cloud_kernel(const float4* __restrict__ src, size_t n, const float* __restrict__ m12,
                                                                  float4* __restrict__ dst) {
@@ -524,7 +551,7 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         dim3 g2((a.max_n + 63) / 64, a.n_scans);
         hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 64, true>), g2, dim3(64), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                            a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
-        hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(512), dim3(kBlock), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
+        hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                            a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
         return;
     }
@@ -539,14 +566,14 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         else
             hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 128>), g2, dim3(128), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                                a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
-        hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(512), dim3(kBlock), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
+        hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                            a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
         return;
     }
     dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
     hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, kBlock>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                        a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
-    hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(512), dim3(kBlock), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
+    hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                        a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
 }
 template <int K, int D>
@@ -568,7 +595,7 @@ static bool launch_fast_k(const SearchArgs& a, hipStream_t s) {
 
 template <int K>
 static bool launch_redo_k(const SearchArgs& a, hipStream_t s) {
-#define LOCGPU_REDO(D) hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(512), dim3(kBlock), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k, \
+#define LOCGPU_REDO(D) hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k, \
                                           a.alpha_eff, a.redo_list, a.redo_count, a.search_stats)
     if (a.depth <= 32) LOCGPU_REDO(32);
     else if (a.depth <= 40) LOCGPU_REDO(40);
@@ -634,6 +661,11 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
 void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
                      hipStream_t s) {
     hipLaunchKernelGGL(gn_solve_kernel, dim3(n_scans), dim3(kBlock), 0, s, partials, blocks_per_scan, st, prm, do_update, hb_out);
+}
+
+void launch_sum_partials(const double* partials, int blocks_per_scan, const PoseState* st_all, int first, int n_local, int n_total, double* acc,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(n_total), dim3(kBlock), 0, s, partials, blocks_per_scan, st_all, first, n_local, acc);
 }
 
 void launch_transform_cloud(const float4* src, size_t n, const float* m12, float4* dst, hipStream_t s) {

@@ -30,6 +30,10 @@ struct GnParams {
     int min_effective_pts;
     double eps;
     double max_nn_distance, max_plane_distance, max_line_distance;
+    bool operator==(const GnParams& o) const {  // field by field: the struct has padding bytes
+        return method == o.method && max_iteration == o.max_iteration && min_effective_pts == o.min_effective_pts && eps == o.eps &&
+               max_nn_distance == o.max_nn_distance && max_plane_distance == o.max_plane_distance && max_line_distance == o.max_line_distance;
+    }
 };
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __uint_as_float(u); }
@@ -189,9 +193,9 @@ __device__ __forceinline__ void tree_knn(const uint2* __restrict__ tree, float q
 // (load → leaf: result-set update + backtrack | internal: push far side, step to the near side). All lanes of a wave
 // issue their node load at the same point, so a wave keeps up to 64 loads in flight instead of serialising the
 // descend / backtrack phases of different lanes.
-template <int KMAX, int D, bool COUNT>
+template <int KMAX, int D, bool COUNT, int BLK = kBlock>
 __device__ __forceinline__ void tree_knn_flat(const uint2* __restrict__ tree, float qx, float qy, float qz, int k, float alpha_eff,
-                                              uint32_t (*s_far)[kBlock], float (*s_d2)[kBlock], int tid, KnnHeap<KMAX>& heap,
+                                              uint32_t (*s_far)[BLK], float (*s_d2)[BLK], int tid, KnnHeap<KMAX>& heap,
                                               uint32_t& nvis, uint32_t& lvis) {
     heap.n = 0;
     int sp = 0;

@@ -50,6 +50,11 @@ bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, i
 int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s);
 void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
                      hipStream_t s);
+// Sharded batches: acc[g][0..28) = sum of the block partials of global scan g when this rank holds it (local index g - first),
+// zeros otherwise — in exactly the order gn_solve_kernel sums them, so that all-reduce(acc) followed by gn_solve on acc
+// (blocks_per_scan = 1) gives bit for bit the single-GPU result.
+void launch_sum_partials(const double* partials, int blocks_per_scan, const PoseState* st_all, int first, int n_local, int n_total, double* acc,
+                         hipStream_t s);
 void launch_transform_cloud(const float4* src, size_t n, const float* m12, float4* dst, hipStream_t s);
 
 }  // namespace locgpu

@@ -13,17 +13,23 @@
 #include <string>
 #include <vector>
 
+#include "batch_upload.hpp"
 #include "context.hpp"
 #include "cloud_filters.hpp"
 #include "grid_build.hpp"
 #include "kdtree_build.hpp"
 #include "launch.hpp"
 
+#include <rccl/rccl.h>
+
 using namespace locgpu;
 
 namespace {
 std::string g_create_err;
-constexpr int kChunk = 2;  // GN iterations enqueued between two host reads of the convergence flags
+// GN iterations enqueued between two host reads of the convergence flags. Kernels of a finished scan return at once (device-side
+// `done` flag), so running ahead costs ≈2 µs per empty launch while a host round trip costs tens of µs: the first chunk covers the
+// typical alignment (7-8 iterations with the reference's eps), later ones are shorter.
+constexpr int kFirstChunk = 8, kNextChunk = 4;
 }  // namespace
 
 namespace locgpu {
@@ -78,12 +84,14 @@ static int ensure_grid(locgpu_ctx* ctx) {
 
 static void free_batch(locgpu_batch* b) {
     if (!b) return;
+    upload_free(b);
     if (b->d_src) (void)hipFree(b->d_src);
     if (b->d_counts) (void)hipFree(b->d_counts);
     if (b->d_state) (void)hipFree(b->d_state);
     if (b->d_nn) (void)hipFree(b->d_nn);
     if (b->d_partials) (void)hipFree(b->d_partials);
     if (b->d_hb) (void)hipFree(b->d_hb);
+    if (b->d_acc) (void)hipFree(b->d_acc);
     if (b->d_redo_list) (void)hipFree(b->d_redo_list);
     if (b->d_redo_count) (void)hipFree(b->d_redo_count);
     if (b->d_redo_list2) (void)hipFree(b->d_redo_list2);
@@ -154,6 +162,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_batch(ctx->single);
+    if (ctx->comm) { (void)ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
     if (ctx->d_tree) (void)hipFree(ctx->d_tree);
     free_grid(ctx);
     if (ctx->d_visits) (void)hipFree(ctx->d_visits);
@@ -169,29 +178,78 @@ void locgpu_destroy(locgpu_ctx* ctx) {
 const char* locgpu_last_error(const locgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 // --------------------------------------------------------------------------------------------- target
-int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes) {
-    if (!ctx) return LOCGPU_ERR_INVALID;
+// The reference's tree for `pts`, built on the host (kdtree_build.cpp).
+static int build_host_tree(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, PackedKdTree& t) {
     if (!pts || n == 0 || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: empty cloud or stride < 12");
-    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     // deep copy (icp_registration.cpp:16 + kdtree.cpp:267 copy too): pack xyz
     std::vector<float> xyz(3 * n);
     const char* base = (const char*)pts;
     for (size_t i = 0; i < n; ++i) std::memcpy(&xyz[3 * i], base + i * stride_bytes, 12);
-    PackedKdTree t;
     std::string err;
     if (!build_packed_kdtree(xyz.data(), n, t, err)) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: " + err);
     if (t.depth > 64) return fail(ctx, LOCGPU_ERR_DEPTH, "icp_set_target: KD-tree depth " + std::to_string(t.depth) + " exceeds the 64-entry traversal stack");
+    return LOCGPU_OK;
+}
+
+// meta = {slots, leaves, nodes, points, depth, bounded}; (re)allocates the device tree.
+static int install_tree_meta(locgpu_ctx* ctx, const long long meta[6]) {
     if (ctx->d_tree) { LOCGPU_HIP(ctx, hipFree(ctx->d_tree)); ctx->d_tree = nullptr; }
     free_grid(ctx);
-    LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_tree, t.slots.size() * sizeof(uint64_t)));
-    LOCGPU_HIP(ctx, hipMemcpy(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    ctx->tree_slots = t.slots.size();
-    ctx->num_leaves = t.num_leaves;
-    ctx->num_nodes = t.num_nodes;
-    ctx->num_points = t.num_points;
-    ctx->depth = t.depth;
-    ctx->tree_bounded = t.bounded;
+    LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_tree, (size_t)meta[0] * sizeof(uint64_t)));
+    ctx->tree_slots = (size_t)meta[0];
+    ctx->num_leaves = (size_t)meta[1];
+    ctx->num_nodes = (size_t)meta[2];
+    ctx->num_points = (size_t)meta[3];
+    ctx->depth = (int)meta[4];
+    ctx->tree_bounded = meta[5] != 0;
     ctx->target_epoch++;
+    return LOCGPU_OK;
+}
+
+int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    PackedKdTree t;
+    int rc = build_host_tree(ctx, pts, n, stride_bytes, t);
+    if (rc != LOCGPU_OK) return rc;
+    const long long meta[6] = {(long long)t.slots.size(), (long long)t.num_leaves, (long long)t.num_nodes, (long long)t.num_points, t.depth, t.bounded ? 1 : 0};
+    rc = install_tree_meta(ctx, meta);
+    if (rc != LOCGPU_OK) return rc;
+    LOCGPU_HIP(ctx, hipMemcpy(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return LOCGPU_OK;
+}
+
+// Collective over the context's communicator: rank `root` builds the tree from its `pts` (the other ranks' pts/n are ignored)
+// and broadcasts the packed tree over xGMI — one host build per node instead of one per GPU.
+int locgpu_icp_set_target_bcast(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, int root) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!ctx->comm) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target_bcast: locgpu_comm_init has not been called");
+    if (root < 0 || root >= ctx->comm_world) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target_bcast: bad root");
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    hipStream_t s = ctx->stream;
+    PackedKdTree t;
+    long long meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [6] = the root's status
+    int rc = LOCGPU_OK;
+    if (ctx->comm_rank == root) {
+        rc = build_host_tree(ctx, pts, n, stride_bytes, t);
+        if (rc == LOCGPU_OK) { meta[0] = (long long)t.slots.size(); meta[1] = (long long)t.num_leaves; meta[2] = (long long)t.num_nodes; meta[3] = (long long)t.num_points; meta[4] = t.depth; meta[5] = t.bounded ? 1 : 0; }
+        meta[6] = rc;
+    }
+    long long* d_meta = nullptr;
+    LOCGPU_HIP(ctx, hipMalloc((void**)&d_meta, sizeof(meta)));
+    bool ok = hip_ok(ctx, hipMemcpyAsync(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, s), "bcast meta H2D");
+    ok = ok && ncclBroadcast(d_meta, d_meta, sizeof(meta), ncclChar, root, comm, s) == ncclSuccess;
+    ok = ok && hip_ok(ctx, hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, s), "bcast meta D2H") && hip_ok(ctx, hipStreamSynchronize(s), "sync");
+    (void)hipFree(d_meta);
+    if (!ok) return fail(ctx, LOCGPU_ERR_NO_DEVICE, "icp_set_target_bcast: broadcast of the tree header failed");
+    if (meta[6] != LOCGPU_OK) return ctx->comm_rank == root ? (int)meta[6] : fail(ctx, (int)meta[6], "icp_set_target_bcast: the root rank could not build the tree");
+    rc = install_tree_meta(ctx, meta);
+    if (rc != LOCGPU_OK) return rc;
+    if (ctx->comm_rank == root) LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    if (ncclBroadcast(ctx->d_tree, ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ncclChar, root, comm, s) != ncclSuccess)
+        return fail(ctx, LOCGPU_ERR_NO_DEVICE, "icp_set_target_bcast: broadcast of the tree failed");
+    LOCGPU_HIP(ctx, hipStreamSynchronize(s));
     return LOCGPU_OK;
 }
 
@@ -268,64 +326,123 @@ int locgpu_knn(locgpu_ctx* ctx, const float* queries, size_t nq, int k, int appr
 }
 
 // --------------------------------------------------------------------------------------------- batches
-static int make_batch(locgpu_ctx* ctx, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_scans, locgpu_batch** out) {
+// Device buffers + pinned result staging for n_scans scans of at most max_n points each; no points yet.
+static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch** out, int first = 0, int n_total = -1) {
     if (!ctx || !out) return LOCGPU_ERR_INVALID;
     *out = nullptr;
-    if (n_scans <= 0 || !srcs || !counts || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: bad arguments");
+    const bool sharded = n_total >= 0;
+    if (!sharded) n_total = n_scans;
+    if (n_scans <= 0 || first < 0 || first + n_scans > n_total) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: bad arguments");
+    if (n_total > 65535) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: at most 65535 scans per batch");
     if (n_scans > 65535) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: at most 65535 scans per batch");
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
-    size_t max_n = 0;
-    for (int s = 0; s < n_scans; ++s) max_n = std::max(max_n, counts[s]);
     if (max_n == 0 || max_n > 0x7FFFFF00u || (size_t)n_scans * max_n > 0xFFFFFFF0ull)
         return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: scans are empty or the batch exceeds 2^32 points");
     auto* b = new locgpu_batch();
     b->ctx = ctx;
     b->n_scans = n_scans;
+    b->n_total = n_total;
+    b->first = first;
+    b->sharded = sharded;
     b->max_n = (int)max_n;
     b->blocks_per_scan = (int)((max_n + kBlock - 1) / kBlock);
     b->pitch = (size_t)n_scans * max_n;
-    b->counts.resize(n_scans);
-    for (int s = 0; s < n_scans; ++s) b->counts[s] = (int)counts[s];
+    b->counts.assign(n_scans, 0);
     bool ok = hip_ok(ctx, hipMalloc((void**)&b->d_src, b->pitch * sizeof(float4)), "hipMalloc src") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_counts, n_scans * sizeof(int)), "hipMalloc counts") &&
-              hip_ok(ctx, hipMalloc((void**)&b->d_state, n_scans * sizeof(PoseState)), "hipMalloc state") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_state, n_total * sizeof(PoseState)), "hipMalloc state") &&
+              (!sharded || hip_ok(ctx, hipMalloc((void**)&b->d_acc, (size_t)n_total * kAccW * sizeof(double)), "hipMalloc acc")) &&
               hip_ok(ctx, hipMalloc((void**)&b->d_nn, 5 * b->pitch * sizeof(uint32_t)), "hipMalloc nn") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_partials, (size_t)n_scans * b->blocks_per_scan * kAccW * sizeof(double)), "hipMalloc partials") &&
-              hip_ok(ctx, hipMalloc((void**)&b->d_hb, (size_t)n_scans * 44 * sizeof(double)), "hipMalloc hb") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_hb, (size_t)n_total * 44 * sizeof(double)), "hipMalloc hb") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_list, b->pitch * sizeof(uint32_t)), "hipMalloc redo") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, 2 * sizeof(unsigned int)), "hipMalloc redo") &&
-              hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_scans * sizeof(PoseState)), "hipHostMalloc state") &&
-              hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_scans * 44 * sizeof(double)), "hipHostMalloc hb");
+              hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_total * sizeof(PoseState)), "hipHostMalloc state") &&
+              hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_total * 44 * sizeof(double)), "hipHostMalloc hb") &&
+              hip_ok(ctx, hipMemset(b->d_counts, 0, n_scans * sizeof(int)), "hipMemset counts");
     if (!ok) { free_batch(b); return LOCGPU_ERR_OOM; }
-    // deep copy of the sources (icp_registration.cpp:259): pack to float4 {x,y,z,0}
-    std::vector<float4> host(b->pitch, float4{0.f, 0.f, 0.f, 0.f});
+    *out = b;
+    return LOCGPU_OK;
+}
+
+// Batch with the given scans resident when the call returns (deep copy of the sources, icp_registration.cpp:259).
+static int make_batch(locgpu_ctx* ctx, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_scans, locgpu_batch** out,
+                      int first = 0, int n_total = -1) {
+    if (!ctx || !out) return LOCGPU_ERR_INVALID;
+    *out = nullptr;
+    if (n_scans <= 0 || !srcs || !counts || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: bad arguments");
+    size_t max_n = 0;
+    for (int s = 0; s < n_scans; ++s) max_n = std::max(max_n, counts[s]);
     for (int s = 0; s < n_scans; ++s)
-        if (!srcs[s] && counts[s]) { free_batch(b); return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: NULL scan pointer"); }
-    {
-        // pack in parallel over scans (a 256-scan batch is 29.5 M points)
-        std::atomic<int> next{0};
-        auto work = [&]() {
-            for (int s = next.fetch_add(1); s < n_scans; s = next.fetch_add(1)) {
-                const char* base = (const char*)srcs[s];
-                float4* dst = host.data() + (size_t)s * max_n;
-                for (size_t i = 0; i < counts[s]; ++i) std::memcpy(&dst[i], base + i * stride_bytes, 12);
-            }
-        };
-        unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), (unsigned)std::min(n_scans, 16));
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
-        work();
-        for (auto& t : th) t.join();
-    }
-    ok = hip_ok(ctx, hipMemcpy(b->d_src, host.data(), b->pitch * sizeof(float4), hipMemcpyHostToDevice), "H2D src") &&
-         hip_ok(ctx, hipMemcpy(b->d_counts, b->counts.data(), n_scans * sizeof(int), hipMemcpyHostToDevice), "H2D counts");
-    if (!ok) { free_batch(b); return LOCGPU_ERR_NO_DEVICE; }
+        if (!srcs[s] && counts[s]) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: NULL scan pointer");
+    locgpu_batch* b = nullptr;
+    int rc = alloc_batch(ctx, n_scans, max_n, &b, first, n_total);
+    if (rc != LOCGPU_OK) return rc;
+    rc = upload_start(b, srcs, counts, stride_bytes);
+    if (rc == LOCGPU_OK) rc = upload_join(b);
+    if (rc == LOCGPU_OK && !hip_ok(ctx, hipStreamSynchronize(b->up->stream), "batch_create: H2D")) rc = LOCGPU_ERR_NO_DEVICE;
+    if (rc != LOCGPU_OK) { free_batch(b); return rc; }
     *out = b;
     return LOCGPU_OK;
 }
 
 int locgpu_batch_create(locgpu_ctx* ctx, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_scans, locgpu_batch** out) {
     return make_batch(ctx, srcs, counts, stride_bytes, n_scans, out);
+}
+
+int locgpu_batch_create_empty(locgpu_ctx* ctx, int n_scans, size_t max_points_per_scan, locgpu_batch** out) {
+    return alloc_batch(ctx, n_scans, max_points_per_scan, out);
+}
+
+int locgpu_batch_upload_async(locgpu_batch* b, const void* const* srcs, const size_t* counts, size_t stride_bytes) {
+    if (!b) return LOCGPU_ERR_INVALID;
+    LOCGPU_HIP(b->ctx, hipSetDevice(b->ctx->device));
+    return upload_start(b, srcs, counts, stride_bytes);
+}
+
+int locgpu_batch_upload_wait(locgpu_batch* b) {
+    if (!b) return LOCGPU_ERR_INVALID;
+    return upload_join(b);
+}
+
+int locgpu_batch_create_sharded(locgpu_ctx* ctx, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_local, int first_scan,
+                                int n_total, locgpu_batch** out) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (n_total <= 0) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create_sharded: n_total must be positive");
+    if (ctx->comm_world > 1 && !ctx->comm) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create_sharded: locgpu_comm_init has not been called");
+    return make_batch(ctx, srcs, counts, stride_bytes, n_local, out, first_scan, n_total);
+}
+
+int locgpu_comm_unique_id(void* id_out) {
+    if (!id_out) return LOCGPU_ERR_INVALID;
+    static_assert(LOCGPU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "locgpu.h and rccl.h disagree on the id size");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return LOCGPU_ERR_NO_DEVICE;
+    std::memcpy(id_out, &id, sizeof(id));
+    return LOCGPU_OK;
+}
+
+int locgpu_comm_init(locgpu_ctx* ctx, int rank, int world, const void* id) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(ctx, LOCGPU_ERR_INVALID, "comm_init: bad arguments");
+    if (ctx->comm) return fail(ctx, LOCGPU_ERR_INVALID, "comm_init: this context already has a communicator");
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t nr = ncclCommInitRank(&comm, world, uid, rank);
+    if (nr != ncclSuccess) return fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(nr));
+    ctx->comm = comm;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return LOCGPU_OK;
+}
+
+int locgpu_comm_info(const locgpu_ctx* ctx, int* rank, int* world) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (rank) *rank = ctx->comm_rank;
+    if (world) *world = ctx->comm ? ctx->comm_world : 1;
+    return LOCGPU_OK;
 }
 
 void locgpu_batch_destroy(locgpu_batch* b) {
@@ -341,13 +458,12 @@ void locgpu_batch_destroy(locgpu_batch* b) {
 namespace locgpu {
 
 static void init_states(locgpu_batch* b, const double* poses) {
-    for (int s = 0; s < b->n_scans; ++s) {
+    for (int s = 0; s < b->n_total; ++s) {  // an empty scan still runs the loop: effective_num < min ⇒ no-op iterations
         PoseState& ps = b->h_state[s];
         std::memset(&ps, 0, sizeof(ps));
         for (int i = 0; i < 4; ++i) ps.q[i] = poses[7 * s + i];
         for (int i = 0; i < 3; ++i) ps.t[i] = poses[7 * s + 4 + i];
         quat_to_R(ps.q, ps.R);
-        if (b->counts[s] == 0) ps.done = 0;  // an empty scan still runs the loop: effective_num < min ⇒ no-op iterations
     }
 }
 
@@ -363,7 +479,7 @@ static hipEvent_t get_event(locgpu_ctx* ctx, size_t i) {
 struct IterLauncher {
     locgpu_ctx* ctx;
     locgpu_batch* b;
-    GnParams prm;
+    GnParams prm{};
     int k;
     float alpha_eff;
     size_t ev_used = 0;
@@ -392,31 +508,44 @@ bool IterLauncher::launch(int do_update) {
     };
     mark();
     int n_partial_blocks = b->blocks_per_scan;
+    PoseState* st_local = b->d_state + b->first;  // kernels index the scans this rank holds: 0..n_scans-1
     if (!ndt) {
-        SearchArgs sa{ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ctx->depth, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, k, alpha_eff,
+        SearchArgs sa{ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ctx->depth, b->d_src, b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, k, alpha_eff,
                       prm.method == LOCGPU_P2P ? 1 : 0, ctx->count_visits ? ctx->d_visits : nullptr, b->d_redo_list, b->d_redo_count,
                       b->d_redo_list2, b->d_redo_count + 1, ctx->d_search_stats};
         const bool grid_mode = alpha_eff < 0.f;
         if (!grid_mode && !ctx->tree_bounded) sa.redo_list = nullptr;  // huge / non-finite map coordinates: exact kernel only
-        if (grid_mode && !b->d_redo_list2 && !hip_ok(ctx, hipMalloc((void**)&b->d_redo_list2, b->pitch * sizeof(uint32_t)), "hipMalloc redo2")) return false;
+        if (grid_mode && !b->d_redo_list2) { fail(ctx, LOCGPU_ERR_INVALID, "grid search: work list missing (ensure_grid_lists was not called)"); return false; }
         sa.redo_list2 = b->d_redo_list2;
         if (grid_mode) sa.alpha_eff = 1.0f;  // the tree kernel that settles the grid's leftovers runs the exact pruning rule
         const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, s) : launch_icp_search(sa, s);
         if (!ok_search) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
         mark();
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
-        AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
+        AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
         n_partial_blocks = launch_icp_accum(prm.method, aa, s);
     } else {
         mark();  // NDT has no separate search kernel: search slot stays empty
         if (prm.method == 4)
-            launch_inc_accum(ctx->inc, ctx->ndt_opts.res_outlier_th, ctx->ndt_opts.nearby_type == 0 ? 1 : 7, b->d_src, b->d_counts, b->d_state,
+            launch_inc_accum(ctx->inc, ctx->ndt_opts.res_outlier_th, ctx->ndt_opts.nearby_type == 0 ? 1 : 7, b->d_src, b->d_counts, st_local,
                              b->max_n, b->n_scans, b->d_partials, s);
         else
-            n_partial_blocks = launch_ndt_accum(ctx->ndt, b->d_src, b->d_counts, b->d_state, b->max_n, b->n_scans, b->d_partials, s);
+            n_partial_blocks = launch_ndt_accum(ctx->ndt, b->d_src, b->d_counts, st_local, b->max_n, b->n_scans, b->d_partials, s);
     }
     mark();
-    launch_gn_solve(b->d_partials, n_partial_blocks, b->d_state, b->n_scans, prm, do_update, b->d_hb, s);
+    if (b->sharded) {
+        // The exchange step of the sharded mode: per scan 28 sums (21 H + 6 B + effective_num), zeros from the
+        // ranks that do not hold the scan, summed over xGMI on this stream; then every rank solves every scan, so all ranks see the
+        // same convergence flags and stay in lock-step.
+        launch_sum_partials(b->d_partials, n_partial_blocks, b->d_state, b->first, b->n_scans, b->n_total, b->d_acc, s);
+        if (ctx->comm) {
+            const ncclResult_t nr = ncclAllReduce(b->d_acc, b->d_acc, (size_t)b->n_total * kAccW, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
+            if (nr != ncclSuccess) { fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(nr)); return false; }
+        }
+        launch_gn_solve(b->d_acc, 1, b->d_state, b->n_total, prm, do_update, b->d_hb, s);
+    } else {
+        launch_gn_solve(b->d_partials, n_partial_blocks, b->d_state, b->n_scans, prm, do_update, b->d_hb, s);
+    }
     mark();
     return hip_ok(ctx, hipGetLastError(), "kernel launch");
 }
@@ -439,6 +568,21 @@ void IterLauncher::collect_profile() {
 
 static void write_results(locgpu_batch* b, const double* init_poses, double* out_poses, locgpu_align_stats* stats);
 
+// The grid search hands its leftovers through a second work list. It is allocated here, by every entry point that may run the
+// grid search on `b`, BEFORE any launch: launch() can run under hipStreamBeginCapture, where hipMalloc is not allowed.
+// A pending locgpu_batch_upload_async of `b`: wait until the host side is through, then order the compute stream behind the copies.
+static int batch_ready(locgpu_ctx* ctx, locgpu_batch* b) {
+    const int rc = upload_join(b);
+    if (rc != LOCGPU_OK) return rc;
+    LOCGPU_HIP(ctx, upload_order_after(b, ctx->stream));
+    return LOCGPU_OK;
+}
+
+static int ensure_grid_lists(locgpu_ctx* ctx, locgpu_batch* b, float alpha_eff) {
+    if (alpha_eff < 0.f && !b->d_redo_list2) LOCGPU_HIP(ctx, hipMalloc((void**)&b->d_redo_list2, b->pitch * sizeof(uint32_t)));
+    return LOCGPU_OK;
+}
+
 // hipGraph path (BASELINE config 5): every GN iteration of the batch is captured once — the kernels early-out per scan on
 // the device-side `done` flag, so a fixed node sequence gives the same result as the data-dependent eager loop — and
 // replayed per call with a single host synchronisation at the end.
@@ -449,17 +593,17 @@ static int run_align_graph(locgpu_ctx* ctx, locgpu_batch* b, const double* init_
     const void* target = !ndt ? (const void*)ctx->d_tree : (prm.method == 4 ? inc_ndt_table_ptr(ctx->inc) : (const void*)ctx->ndt->d_keys);
     const bool same = b->graph_exec && b->graph_k == k && b->graph_alpha == alpha_eff && b->graph_ndt == ndt && b->graph_target == target &&
                       b->graph_epoch == ctx->target_epoch &&
-                      std::memcmp(&b->graph_prm, &prm, sizeof(GnParams)) == 0;
+                      b->graph_prm == prm;
     if (!same) {
         if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
         hipGraph_t graph = nullptr;
         LOCGPU_HIP(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        bool ok = hip_ok(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_scans * sizeof(PoseState), hipMemcpyHostToDevice, s), "capture H2D");
+        bool ok = hip_ok(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, s), "capture H2D");
         IterLauncher it{ctx, b, prm, k, alpha_eff};
         it.ndt = ndt;
         it.capturing = true;
         for (int i = 0; ok && i < prm.max_iteration; ++i) ok = it.launch(1);
-        ok = ok && hip_ok(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_scans * sizeof(PoseState), hipMemcpyDeviceToHost, s), "capture D2H");
+        ok = ok && hip_ok(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_total * sizeof(PoseState), hipMemcpyDeviceToHost, s), "capture D2H");
         const hipError_t e = hipStreamEndCapture(s, &graph);
         if (!ok || !hip_ok(ctx, e, "hipStreamEndCapture")) { if (graph) (void)hipGraphDestroy(graph); return LOCGPU_ERR_NO_DEVICE; }
         const bool inst = hip_ok(ctx, hipGraphInstantiate(&b->graph_exec, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
@@ -477,24 +621,26 @@ static int run_align_graph(locgpu_ctx* ctx, locgpu_batch* b, const double* init_
 static int run_align(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt,
                      double* out_poses, locgpu_align_stats* stats) {
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->use_graph && !ctx->count_visits && prm.max_iteration > 0) return run_align_graph(ctx, b, init_poses, prm, k, alpha_eff, ndt, out_poses, stats);
+    if (!ndt) { const int grc = ensure_grid_lists(ctx, b, alpha_eff); if (grc != LOCGPU_OK) return grc; }
+    { const int urc = batch_ready(ctx, b); if (urc != LOCGPU_OK) return urc; }
+    if (ctx->use_graph && !ctx->count_visits && !b->sharded && prm.max_iteration > 0) return run_align_graph(ctx, b, init_poses, prm, k, alpha_eff, ndt, out_poses, stats);
     init_states(b, init_poses);
     hipStream_t s = ctx->stream;
-    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_scans * sizeof(PoseState), hipMemcpyHostToDevice, s));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, s));
     IterLauncher it{ctx, b, prm, k, alpha_eff};
     it.ndt = ndt;
     int launched = 0;
     bool all_done = prm.max_iteration <= 0;
     while (!all_done) {
-        const int todo = std::min(kChunk, prm.max_iteration - launched);
+        const int todo = std::min(launched == 0 ? kFirstChunk : kNextChunk, prm.max_iteration - launched);
         for (int c = 0; c < todo; ++c)
             if (!it.launch(1)) return LOCGPU_ERR_NO_DEVICE;
         launched += todo;
-        LOCGPU_HIP(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_scans * sizeof(PoseState), hipMemcpyDeviceToHost, s));
+        LOCGPU_HIP(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_total * sizeof(PoseState), hipMemcpyDeviceToHost, s));
         LOCGPU_HIP(ctx, hipStreamSynchronize(s));
         it.collect_profile();
         all_done = true;
-        for (int i = 0; i < b->n_scans; ++i)
+        for (int i = 0; i < b->n_total; ++i)
             if (!b->h_state[i].done) { all_done = false; break; }
         if (launched >= prm.max_iteration) all_done = true;
     }
@@ -503,7 +649,7 @@ static int run_align(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses,
 }
 
 static void write_results(locgpu_batch* b, const double* init_poses, double* out_poses, locgpu_align_stats* stats) {
-    for (int i = 0; i < b->n_scans; ++i) {
+    for (int i = 0; i < b->n_total; ++i) {
         const PoseState& ps = b->h_state[i];
         if (ps.status == 1) {  // direct NDT aborted: reference leaves result_pose unassigned; hand back init_pose
             for (int j = 0; j < 7; ++j) out_poses[7 * i + j] = init_poses[7 * i + j];
@@ -554,12 +700,9 @@ static int single_reserve(locgpu_ctx* ctx, size_t n, locgpu_batch** out) {
     locgpu_batch* b = ctx->single;
     if (!b || (size_t)b->max_n < n || !b->h_src) {
         if (b) { free_batch(b); ctx->single = nullptr; }
-        // allocate with headroom through the normal path (a zero-filled dummy scan of the capacity), then attach pinned staging
+        // device buffers with headroom, then pinned staging of the same capacity
         const size_t cap = n + n / 4 + 1024;
-        std::vector<float> dummy(3 * cap, 0.f);
-        const void* srcs[1] = {dummy.data()};
-        const size_t counts[1] = {cap};
-        const int rc = make_batch(ctx, srcs, counts, 12, 1, &ctx->single);
+        const int rc = alloc_batch(ctx, 1, cap, &ctx->single);
         if (rc != LOCGPU_OK) return rc;
         b = ctx->single;
         if (!hip_ok(ctx, hipHostMalloc((void**)&b->h_src, cap * sizeof(float4)), "hipHostMalloc src")) { free_batch(b); ctx->single = nullptr; return LOCGPU_ERR_OOM; }
@@ -603,7 +746,7 @@ extern "C" {
 
 int locgpu_icp_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const locgpu_icp_opts* opts, double* out_poses,
                            locgpu_align_stats* stats) {
-    GnParams prm;
+    GnParams prm{};
     int k;
     float alpha_eff;
     const int rc = check_icp(ctx, opts, prm, k, alpha_eff);
@@ -614,7 +757,7 @@ int locgpu_icp_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_
 
 int locgpu_icp_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7], const locgpu_icp_opts* opts,
                      double out_pose[7], locgpu_align_stats* stats) {
-    GnParams prm;
+    GnParams prm{};
     int k;
     float alpha_eff;
     int rc = check_icp(ctx, opts, prm, k, alpha_eff);
@@ -627,27 +770,29 @@ int locgpu_icp_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_b
 }
 
 int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* poses, const locgpu_icp_opts* opts, double* hb) {
-    GnParams prm;
+    GnParams prm{};
     int k;
     float alpha_eff;
     const int rc = check_icp(ctx, opts, prm, k, alpha_eff);
     if (rc != LOCGPU_OK) return rc;
     if (!b || b->ctx != ctx || !poses || !hb) return fail(ctx, LOCGPU_ERR_INVALID, "icp_hb_batch: bad arguments");
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    { const int grc = ensure_grid_lists(ctx, b, alpha_eff); if (grc != LOCGPU_OK) return grc; }
+    { const int urc = batch_ready(ctx, b); if (urc != LOCGPU_OK) return urc; }
     init_states(b, poses);
-    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_scans * sizeof(PoseState), hipMemcpyHostToDevice, ctx->stream));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, ctx->stream));
     IterLauncher it{ctx, b, prm, k, alpha_eff};
     if (!it.launch(0)) return LOCGPU_ERR_NO_DEVICE;
-    LOCGPU_HIP(ctx, hipMemcpyAsync(b->h_hb, b->d_hb, (size_t)b->n_scans * 44 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->h_hb, b->d_hb, (size_t)b->n_total * 44 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     it.collect_profile();
-    std::memcpy(hb, b->h_hb, (size_t)b->n_scans * 44 * sizeof(double));
+    std::memcpy(hb, b->h_hb, (size_t)b->n_total * 44 * sizeof(double));
     return LOCGPU_OK;
 }
 
 int locgpu_icp_hb(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double pose[7], const locgpu_icp_opts* opts, double H[36],
                   double B[6], int64_t* effective_num, int* ok) {
-    GnParams prm;
+    GnParams prm{};
     int k;
     float alpha_eff;
     int rc = check_icp(ctx, opts, prm, k, alpha_eff);
@@ -908,7 +1053,7 @@ int locgpu_ndt_dump(locgpu_ctx* ctx, int32_t* keys, double* mu, double* info, si
 }
 
 int locgpu_ndt_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, double* out_poses, locgpu_align_stats* stats) {
-    GnParams prm;
+    GnParams prm{};
     const int rc = check_ndt(ctx, prm);
     if (rc != LOCGPU_OK) return rc;
     if (!b || b->ctx != ctx || !init_poses || !out_poses) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_batch: bad arguments");
@@ -917,7 +1062,7 @@ int locgpu_ndt_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_
 
 int locgpu_ndt_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7], double out_pose[7],
                      locgpu_align_stats* stats) {
-    GnParams prm;
+    GnParams prm{};
     int rc = check_ndt(ctx, prm);
     if (rc != LOCGPU_OK) return rc;
     if (!src || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align: bad arguments");
@@ -954,7 +1099,7 @@ int locgpu_ndt_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* target, con
 
 int locgpu_icp_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const double init_pose[7], const locgpu_icp_opts* opts, double out_pose[7],
                            locgpu_align_stats* stats) {
-    GnParams prm;
+    GnParams prm{};
     int k;
     float alpha_eff;
     int rc = check_icp(ctx, opts, prm, k, alpha_eff);
@@ -967,7 +1112,7 @@ int locgpu_icp_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const doubl
 }
 
 int locgpu_ndt_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const double init_pose[7], double out_pose[7], locgpu_align_stats* stats) {
-    GnParams prm;
+    GnParams prm{};
     int rc = check_ndt(ctx, prm);
     if (rc != LOCGPU_OK) return rc;
     if (!src || src->ctx != ctx || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_cloud: bad arguments");

@@ -32,6 +32,13 @@ bool filter_into(const CloudPtr& in, CloudPtr& out, Run run) {
     int dense = 1;
     if (!run(tmp.data(), &m, &dense)) return false;
     tmp.resize(m);
+#ifndef LOCGPU_FACADE_STANDALONE
+    // pcl::Filter::filter copies these from the input (and VoxelGrid's "leaf size is too small" branch copies the whole cloud,
+    // whose points carry nothing beyond x, y, z, intensity); the stand-in cloud type of the standalone build has no such members.
+    out->header = in->header;
+    out->sensor_origin_ = in->sensor_origin_;
+    out->sensor_orientation_ = in->sensor_orientation_;
+#endif
     out->points.swap(tmp);
     out->width = (unsigned)m;
     out->height = 1;

@@ -12,6 +12,39 @@ Two ways the path shards:
 import numpy as np
 
 
+def init_comm(ctx, dist=None):
+    """Join this rank's context to the RCCL communicator of the job (native collectives inside liblocgpu.so: the per-iteration
+    all-reduce of sharded batches and the tree broadcast). The 128-byte RCCL id is made on rank 0 and handed round through
+    torch.distributed's store (works on gloo and nccl process groups alike). Without a process group: a one-rank communicator."""
+    from . import api
+    if dist is None or not dist.is_initialized():
+        ctx.comm_init(0, 1, api.comm_unique_id())
+        return 0, 1
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [api.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init(rank, world, box[0])
+    return rank, world
+
+
+def scan_sharded_batch(ctx, scans, n_total, rank, world):
+    """BASELINE configs[3]: a batch of n_total scans split contiguously over the ranks; `scans` = this rank's slice
+    (shard_range(n_total, rank, world)). Aligning the batch is collective and returns all n_total poses on every rank."""
+    lo, hi = shard_range(n_total, rank, world)
+    if len(scans) != hi - lo:
+        raise ValueError("rank %d holds scans [%d, %d) of %d" % (rank, lo, hi, n_total))
+    return ctx.batch(scans, first=lo, n_total=n_total)
+
+
+def point_sharded_batch(ctx, scans, rank, world):
+    """One large alignment split by points: every rank holds the slice shard_range(len(scan), rank, world) of every scan."""
+    parts = []
+    for s in scans:
+        lo, hi = shard_range(len(s), rank, world)
+        parts.append(s[lo:hi])
+    return ctx.batch(parts, first=0, n_total=len(scans))
+
+
 def shard_range(n_items, rank, world):
     """Contiguous [lo, hi) slice of n_items for `rank` of `world` (sizes differ by at most one)."""
     base, rem = divmod(n_items, world)

@@ -35,6 +35,58 @@
 namespace locref {
 
 // ---------------------------------------------------------------------------------------------
+// The plane 4-vector from a one-sided Jacobi SVD: columns of `a` = U·Σ, `v` = right singular vectors.
+//
+// Full-rank case (at least three singular values above 1e-13·σmax — every neighbourhood of a real map): V.col(3) of JacobiSVD
+// (math_utils.h:124-125) = the right singular vector of the smallest singular value.
+//
+// Rank-deficient case (five collinear or coincident neighbours, exactly, in FP64): the null space of [x y z 1] has two or more
+// dimensions, every unit vector in it is a valid V.col(3), and which one Eigen's JacobiSVD returns is an accident of its
+// rotation sequence on rounding noise — it cannot be restated without Eigen itself. What the reference DOES define there is
+// the control flow: any null vector has zero residual on the five points, so the fit passes and effective_num counts the
+// point (icp cpp:184). The vector is fixed here by a rule the device kernel shares (loc_lib_amd/csrc/device_math.hpp,
+// plane_null_vector): with r = number of dominant singular values, the unit vector of the orthogonal complement of the r
+// dominant right singular vectors that is closest to e4 = (0,0,0,1) — or to e3, e2, e1, the first whose projection keeps
+// at least 0.4 of its squared length (one always keeps ≥ 0.5). For r = 3 this IS V.col(3).
+template <int M>
+static void PlaneVectorFromSvd(const double a[4][M], const double v[4][4], double n[4]) {
+    double sn[4], mx = 0.0;
+    int best = 0;
+    double bn = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        double s = 0;
+        for (int i = 0; i < M; ++i) s += a[c][i] * a[c][i];
+        sn[c] = s;
+        if (s < bn) { bn = s; best = c; }
+        if (s > mx) mx = s;
+    }
+    int r = 0;
+    bool dom[4];
+    for (int c = 0; c < 4; ++c) { dom[c] = sn[c] > 1e-26 * mx; r += dom[c] ? 1 : 0; }
+    if (r >= 3) {
+        for (int i = 0; i < 4; ++i) n[i] = v[best][i];
+        return;
+    }
+    for (int k = 3; k >= 0; --k) {
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+        t[k] = 1.0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int c = 0; c < 4; ++c) {
+                if (!dom[c]) continue;
+                double d = 0;
+                for (int i = 0; i < 4; ++i) d += t[i] * v[c][i];
+                for (int i = 0; i < 4; ++i) t[i] -= d * v[c][i];
+            }
+        double nn = 0;
+        for (int i = 0; i < 4; ++i) nn += t[i] * t[i];
+        if (nn >= 0.4 || k == 0) {
+            const double inv = nn > 0.0 ? 1.0 / std::sqrt(nn) : 0.0;
+            for (int i = 0; i < 4; ++i) n[i] = t[i] * inv;
+            return;
+        }
+    }
+}
+
 // math_utils.h:112-136  FitPlane<double>: rows [x y z 1], smallest right singular vector, eps check.
 static bool FitPlane(const std::vector<V3>& data, double n[4], double eps = 1e-2) {
     if (data.size() < 3) return false;
@@ -47,22 +99,12 @@ static bool FitPlane(const std::vector<V3>& data, double n[4], double eps = 1e-2
         double a[4][5];
         for (int i = 0; i < 5; ++i) { a[0][i] = data[i].x; a[1][i] = data[i].y; a[2][i] = data[i].z; a[3][i] = 1.0; }
         jacobi_svd_onesided<5, 4>(a, v);
-        int best = 0; double bn = 1e300;
-        for (int c = 0; c < 4; ++c) {
-            double s = 0; for (int i = 0; i < 5; ++i) s += a[c][i] * a[c][i];
-            if (s < bn) { bn = s; best = c; }
-        }
-        for (int i = 0; i < 4; ++i) n[i] = v[best][i];
+        PlaneVectorFromSvd<5>(a, v, n);
     } else {
         double a[4][4];
         for (int i = 0; i < 4; ++i) { a[0][i] = data[i].x; a[1][i] = data[i].y; a[2][i] = data[i].z; a[3][i] = 1.0; }
         jacobi_svd_onesided<4, 4>(a, v);
-        int best = 0; double bn = 1e300;
-        for (int c = 0; c < 4; ++c) {
-            double s = 0; for (int i = 0; i < 4; ++i) s += a[c][i] * a[c][i];
-            if (s < bn) { bn = s; best = c; }
-        }
-        for (int i = 0; i < 4; ++i) n[i] = v[best][i];
+        PlaneVectorFromSvd<4>(a, v, n);
     }
     for (size_t i = 0; i < data.size(); ++i) {
         const double err = dot(V3{n[0], n[1], n[2]}, data[i]) + n[3];

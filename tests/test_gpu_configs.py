@@ -1,0 +1,282 @@
+"""GPU parity tests at the sizes and compositions BASELINE.json's configs name (the HIP path through the C ABI vs the CPU oracle).
+
+configs[2]  115 200-pt scans vs the 10 M-pt map — the direct-NDT half (the P2Plane half is test_gpu_parity.py::test_bench_config_parity_10m)
+configs[3]  a 256-scan batch vs the 10 M-pt map: four spread-out scans against the oracle, all 256 finite, deterministic run to run
+configs[4]  the composed streaming loop of Lio::AddCloud (lio.cpp:236-306): removeNaN → voxel filter → ScanMatch against the local map →
+            keyframe every 3rd scan (transform, submap update, target re-ingest), eager and with the captured hipGraph
+plus the degenerate neighbourhoods ring-structured LiDAR maps produce: five collinear neighbours (rank-2 plane-fit matrices).
+"""
+import numpy as np
+import pytest
+
+from conftest import pose_delta
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4    # north_star tolerance, metres
+POSE_TOL_RAD = 1e-4  # north_star tolerance, radians
+
+
+@pytest.fixture(scope="module")
+def world10m(synth):
+    return synth.make_map(10_000_000)
+
+
+def xyzi(a):
+    out = np.zeros((len(a), 4), np.float32)
+    out[:, :3] = a[:, :3]
+    out[:, 3] = (np.arange(len(a)) % 251).astype(np.float32)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- configs[2], NDT half
+def test_ndt_10m_parity(gpu_ctx, locref, synth, world10m):
+    """Direct NDT (NdtOptions defaults: voxel 1.0, NEARBY6; ndt_registration.cpp:87-148, 374-464), two full scans vs the 10 M-pt map:
+    same voxel count, pose Δ < 1e-9 m / rad, equal iteration counts."""
+    gpu_ctx.ndt_set_target(world10m)
+    ndt = locref.Ndt()
+    ndt.set_target(world10m)
+    assert gpu_ctx.ndt_target_info()["num_voxels"] == ndt.num_voxels()
+    for sid in (5, 130):
+        s = synth.make_scan(sid)
+        init = synth.make_pose(sid)[1]
+        pg, st = gpu_ctx.ndt_align(s, init)
+        ro = ndt.align(s, init)
+        dt, dr = pose_delta(pg, ro["pose"])
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and dt < 1e-9 and dr < 1e-9, (sid, dt, dr)
+        assert st["iterations"] == ro["iters"] and st["status"] == ro["status"] == 0
+
+
+# ----------------------------------------------------------------------------------------------- configs[3], one GPU's view
+def test_batch_256_scans_vs_10m(gpu_ctx, api, locref, synth, world10m):
+    """The whole 256-scan batch of configs[3] on one GPU: scans 3, 77, 150 and 241 against the oracle (pose Δ < 1e-9 m, equal
+    iterations), every pose finite and within the perturbation of its truth, and two runs bitwise equal (fixed reduction order)."""
+    gpu_ctx.icp_set_target(world10m)
+    sids = list(range(256))
+    scans = [synth.make_scan(sid) for sid in sids]
+    inits = np.stack([synth.make_pose(sid)[1] for sid in sids])
+    truth = np.stack([synth.make_pose(sid)[0] for sid in sids])
+    opts = api.icp_opts(method=api.P2PLANE)
+    b = gpu_ctx.batch(scans)
+    try:
+        out1, st1 = gpu_ctx.icp_align_batch(b, inits, opts)
+        out2, st2 = gpu_ctx.icp_align_batch(b, inits, opts)
+    finally:
+        b.close()
+    np.testing.assert_array_equal(out1, out2)
+    assert [s["iterations"] for s in st1] == [s["iterations"] for s in st2]
+    assert np.all(np.isfinite(out1))
+    assert np.all(np.linalg.norm(out1[:, 4:] - truth[:, 4:], axis=1) < 0.3)  # started ≤ 0.52 m away, ends within the stopping tolerance's reach
+    assert all(1 <= s["iterations"] <= 20 for s in st1)
+    icp = locref.Icp(method=locref.P2PLANE)
+    icp.set_target(world10m)
+    for sid in (3, 77, 150, 241):
+        ro = icp.align(scans[sid], inits[sid])
+        dt, dr = pose_delta(out1[sid], ro["pose"])
+        assert dt < 1e-9 and dr < 1e-9, (sid, dt, dr)
+        assert st1[sid]["iterations"] == ro["iters"]
+
+
+# ----------------------------------------------------------------------------------------------- configs[4]
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
+def test_streaming_loop_matches_oracle(api, locref, synth, graph):
+    """Lio::AddCloud's loop (lio.cpp:236-306) composed from the resident entry points: 10 scans, keyframe every 3rd, at most 3
+    keyframes in the local map (so the drop-oldest-and-rebuild branch runs), every pose and every local map equal to the oracle's."""
+    ctx = api.Context(0)
+    try:
+        ctx.graph_enable(graph)
+        opts = api.icp_opts(api.P2PLANE)
+        sub = api.Submap(ctx, 3, 0.5)
+        lm = locref.LocalMap(3, 0.5, order=locref.SORT_STABLE)
+        icp_ref = locref.Icp(method=locref.P2PLANE)
+        raw, filt = api.Cloud(ctx), api.Cloud(ctx)
+        for s in range(10):
+            scan = xyzi(synth.make_scan(s))
+            scan[s::997, 1] = np.nan  # a few missing returns: removeNaN has something to do
+            truth, init = synth.make_pose(s)
+            raw.upload(scan, is_dense=False)
+            raw.remove_nan(out=filt)
+            filt.voxel_filter(0.5, out=filt)
+            want_filt = locref.voxel_grid(locref.remove_nan(scan, False), True, 0.5, order=locref.SORT_STABLE)
+            assert np.array_equal(filt.download(), want_filt)
+            if s == 0:
+                pose, kf_src, kf_dense = truth, filt, True       # first frame seeds the map with the FILTERED scan (lio.cpp:238-256)
+            else:
+                pose, st = ctx.icp_align_cloud(filt, init, opts)
+                ro = icp_ref.align(want_filt, init)
+                dt, dr = pose_delta(pose, ro["pose"])
+                assert dt < 1e-8 and dr < 1e-8, (s, dt, dr)
+                assert st["iterations"] == ro["iters"]
+                kf_src, kf_dense = raw, False                     # later keyframes keep the RAW scan (lio.cpp:279)
+            if s % 3 == 0:
+                sub.add_keyframe(kf_src, pose)
+                ctx.icp_set_target_cloud(sub.cloud())
+                lm.add_keyframe(locref.transform_cloud_f64(pose, kf_src.download(), is_dense=kf_dense), is_dense=kf_dense)
+                icp_ref.set_target(lm.cloud()[:, :3])
+                assert np.array_equal(sub.cloud().download(), lm.cloud(), equal_nan=True)
+        assert sub.info[0] == 3  # four keyframes were added, the oldest was dropped
+    finally:
+        ctx.graph_enable(False)
+        ctx.close()
+
+
+def test_graph_mode_with_grid_search(gpu_ctx, api, small_world):
+    """hipGraph capture of the exact grid search (its second work list must exist before the capture starts)."""
+    m, s, init = small_world["map"], small_world["scan10k"], small_world["init_pose"]
+    gpu_ctx.icp_set_target(m)
+    b = gpu_ctx.batch([s, small_world["scan2k"]])
+    inits = np.stack([init, init])
+    opts = api.icp_opts(method=api.P2PLANE, search_mode=api.SEARCH_GRID_EXACT)
+    try:
+        gpu_ctx.graph_enable(True)
+        got, gst = gpu_ctx.icp_align_batch(b, inits, opts)   # first use of grid mode on this batch happens under capture
+        gpu_ctx.graph_enable(False)
+        want, wst = gpu_ctx.icp_align_batch(b, inits, opts)
+        np.testing.assert_array_equal(got, want)
+        assert [x["iterations"] for x in gst] == [x["iterations"] for x in wst]
+    finally:
+        gpu_ctx.graph_enable(False)
+        b.close()
+
+
+# ----------------------------------------------------------------------------------------------- degenerate neighbourhoods
+def _lines_map(rng, exact):
+    """A map made of straight lines only: every 5-neighbourhood is collinear, so FitPlane's 5×4 matrix has rank 2.
+    exact=True: axis-parallel lines on a 2^-4 m lattice (float32 holds them exactly ⇒ exactly rank 2);
+    exact=False: oblique lines rounded to float32 (rank 2 up to 1e-7 relative rounding of the inputs)."""
+    pts = []
+    t = np.arange(-20, 20, 0.0625)
+    for i in range(60):
+        o = np.round(rng.uniform(-20, 20, 3) * 16) / 16
+        if exact:
+            d = np.eye(3)[i % 3]
+        else:
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+        pts.append(o[None, :] + t[:, None] * d[None, :])
+    return np.concatenate(pts).astype(np.float32)
+
+
+def _rings_map():
+    """Scan-ring arcs on a ground plane (what a single LiDAR sweep leaves in a map): points dense along a ring, rings far apart,
+    so five nearest neighbours sit on one arc — nearly collinear, curvature-limited rank 3."""
+    pts = []
+    for r in np.arange(4.0, 40.0, 1.5):
+        az = np.arange(0, 2 * np.pi, 0.002)
+        pts.append(np.stack([r * np.cos(az), r * np.sin(az), np.zeros_like(az)], 1))
+    return np.concatenate(pts).astype(np.float32)
+
+
+@pytest.mark.parametrize("world", ["lines_exact", "lines_oblique", "rings"])
+@pytest.mark.parametrize("method", [1, 2], ids=["p2line", "p2plane"])
+def test_collinear_neighbourhoods(gpu_ctx, api, locref, world, method):
+    """Rank-deficient plane fits. For five collinear neighbours the smallest right singular vector of [x y z 1] is not unique
+    (a two-dimensional null space): Eigen's JacobiSVD (math_utils.h:124-125) returns whichever its rotation sequence leaves, which
+    cannot be known without Eigen. What IS defined by the reference: every such neighbourhood passes the fit test (any null vector
+    has zero residual), so effective_num counts it (icp cpp:184). The oracle and the device use the same documented rule for the
+    vector ("rank-deficient neighbourhoods"): the null-space direction closest to (0,0,0,1)."""
+    rng = np.random.default_rng(11)
+    m = _lines_map(rng, world == "lines_exact") if world.startswith("lines") else _rings_map()
+    q = m[rng.choice(len(m), 3000, replace=False)].astype(np.float64) + rng.normal(0, 0.02, (3000, 3))
+    s = q.astype(np.float32)
+    pose = np.array([0.002, -0.001, 0.003, 1.0, 0.01, -0.02, 0.005])
+    pose[:4] /= np.linalg.norm(pose[:4])
+    gpu_ctx.icp_set_target(m)
+    icp = locref.Icp(method=method)
+    icp.set_target(m)
+    ok_o, Ho, Bo, eff_o = icp.hb(s, pose)
+    ok_g, Hg, Bg, eff_g = gpu_ctx.icp_hb(s, pose, api.icp_opts(method=method))
+    assert eff_g == eff_o and ok_g == ok_o
+    assert eff_o > 2000
+    scale = max(np.abs(Ho).max(), 1e-300)
+    assert np.abs(Hg - Ho).max() <= 1e-6 * scale, np.abs(Hg - Ho).max() / scale
+    assert np.abs(Bg - Bo).max() <= 1e-6 * max(np.abs(Bo).max(), scale * 1e-6)
+
+
+# ----------------------------------------------------------------------------------------------- configs[3], the exchange step
+def test_sharded_batch_over_rccl_equals_plain_batch(api, small_world):
+    """The sharded mode's data path on one GPU: an RCCL communicator of ONE rank (ncclCommInitRank + ncclAllReduce really run),
+    per-scan sums → all-reduce → solve on every rank. A batch this rank holds completely must reproduce the plain batch bit for
+    bit; held partially (scans [1, 3) of 3) the scans it holds are unchanged and the one it does not hold gets no residuals
+    (effective_num = 0 ⇒ 20 no-op iterations, pose = initial guess: icp_registration.cpp:204-207,358-376)."""
+    from loc_lib_amd import multi_gpu
+    m = small_world["map"]
+    scans = [small_world["scan10k"], small_world["scan2k"], small_world["scan10k"][::3]]
+    init = small_world["init_pose"]
+    inits = np.stack([init, init, init])
+    inits[1, 4:] += [0.04, -0.03, 0.01]
+    ctx = api.Context(0)
+    try:
+        assert multi_gpu.init_comm(ctx, None) == (0, 1) and ctx.comm_info() == (0, 1)
+        ctx.icp_set_target_bcast(m, root=0)          # collective SetInputTarget (root builds, ncclBroadcast of the packed tree)
+        ctx.ndt_set_target(m)
+        plain = ctx.batch(scans)
+        full = multi_gpu.scan_sharded_batch(ctx, scans, 3, 0, 1)
+        part = ctx.batch(scans[1:], first=1, n_total=3)
+        try:
+            for method in (api.P2PLANE, api.P2P):
+                opts = api.icp_opts(method=method)
+                want, wst = ctx.icp_align_batch(plain, inits, opts)
+                got, gst = ctx.icp_align_batch(full, inits, opts)
+                np.testing.assert_array_equal(got, want)
+                assert [s["iterations"] for s in gst] == [s["iterations"] for s in wst]
+                got, gst = ctx.icp_align_batch(part, inits, opts)
+                np.testing.assert_array_equal(got[1:], want[1:])
+                np.testing.assert_array_equal(got[0], inits[0])
+                assert gst[0]["iterations"] == 20 and gst[0]["last_effective_num"] == 0
+                hb_w = ctx.icp_hb_batch(plain, inits, opts)
+                hb_g = ctx.icp_hb_batch(full, inits, opts)
+                np.testing.assert_array_equal(hb_g, hb_w)
+            want, _ = ctx.ndt_align_batch(plain, inits)
+            got, _ = ctx.ndt_align_batch(full, inits)
+            np.testing.assert_array_equal(got, want)
+            # point sharding degenerates to the same thing with one rank
+            pts = multi_gpu.point_sharded_batch(ctx, scans, 0, 1)
+            got, _ = ctx.icp_align_batch(pts, inits, api.icp_opts(method=api.P2PLANE))
+            want, _ = ctx.icp_align_batch(plain, inits, api.icp_opts(method=api.P2PLANE))
+            np.testing.assert_array_equal(got, want)
+            pts.close()
+        finally:
+            plain.close(); full.close(); part.close()
+    finally:
+        ctx.close()
+
+
+def test_async_upload_double_buffer(gpu_ctx, api, small_world):
+    """locgpu_batch_upload_async: two batches alternating as a double buffer give the poses of freshly created batches; ragged
+    counts, a re-upload with other scans, and the error for a scan larger than the reserved capacity."""
+    m = small_world["map"]
+    a, b2, c = small_world["scan10k"], small_world["scan2k"], small_world["scan10k"][::3]
+    init = small_world["init_pose"]
+    inits = np.stack([init, init])
+    gpu_ctx.icp_set_target(m)
+    opts = api.icp_opts(method=api.P2PLANE)
+    sets = [[a, b2], [c, a], [b2, c], [a[:5000], np.ascontiguousarray(a[::2])]]
+    want = []
+    for s in sets:
+        fresh = gpu_ctx.batch(s)
+        want.append(gpu_ctx.icp_align_batch(fresh, inits, opts)[0])
+        fresh.close()
+    bufs = [gpu_ctx.batch_empty(2, len(a)), gpu_ctx.batch_empty(2, len(a))]
+    try:
+        bufs[0].upload_async(sets[0])
+        for i, s in enumerate(sets):
+            if i + 1 < len(sets):
+                bufs[(i + 1) % 2].upload_async(sets[i + 1])   # runs under the align call below
+            got, _ = gpu_ctx.icp_align_batch(bufs[i % 2], inits, opts)
+            np.testing.assert_array_equal(got, want[i])
+        # strided host layout (pcl::PointXYZI: 32 bytes per point)
+        wide = [np.zeros((len(x), 8), np.float32) for x in sets[0]]
+        for w, x in zip(wide, sets[0]):
+            w[:, :3] = x[:, :3]
+            w[:, 4] = 7.0
+        bufs[0].upload_async(wide)
+        got, _ = gpu_ctx.icp_align_batch(bufs[0], inits, opts)
+        np.testing.assert_array_equal(got, want[0])
+        big = np.zeros((len(a) + 1, 3), np.float32)
+        with pytest.raises(api.LocGpuError) as e:
+            bufs[0].upload_async([big, a])
+        assert e.value.code == -1
+    finally:
+        for x in bufs:
+            x.close()
