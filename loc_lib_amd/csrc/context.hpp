@@ -25,10 +25,11 @@ struct locgpu_ctx {
     bool tree_bounded = true;  // PackedKdTree::bounded: the fast search kernel may be used
     unsigned long long target_epoch = 0;  // bumped by every set_target: captured graphs of older targets are never replayed
 
-    // exact-search grid over the tree's leaves (built on first use of LOCGPU_SEARCH_GRID_EXACT)
+    uint32_t* d_leaf_slots = nullptr;  // slot of every leaf, preorder (what the exact-search grid is built from)
+
+    // exact-search grid over the tree's leaves (built on the device on first use of LOCGPU_SEARCH_GRID_EXACT)
     locgpu::GridView grid;
-    uint32_t* d_cell_start = nullptr;
-    float4* d_grid_pts = nullptr;
+    locgpu::GridBuffers grid_buf;
 
     // NDT target
     NdtTable* ndt = nullptr;
@@ -76,6 +77,8 @@ struct locgpu_batch {
     uint32_t* d_redo_list = nullptr;      // [pitch]
     unsigned int* d_redo_count = nullptr;  // [2]: the two lists' counters
     uint32_t* d_redo_list2 = nullptr;      // [pitch], allocated on first use of the grid search
+    uint32_t* d_grid_qkey = nullptr;       // [pitch] grid search: tile of each query
+    uint2* d_grid_sorted = nullptr;        // [pitch] grid search: {query, tile} in tile order
     // hipGraph of {H2D state, max_iteration × (search, fit+accumulate, solve), D2H state}, keyed by the launch parameters
     hipGraphExec_t graph_exec = nullptr;
     locgpu::GnParams graph_prm{};

@@ -1,23 +1,60 @@
-// loc_lib_amd/csrc/grid_kernels.hpp — device view of the exact-search grid and its launchers (see grid_kernels.hip).
+// loc_lib_amd/csrc/grid_kernels.hpp — the exact-search grid in HBM (LOCGPU_SEARCH_GRID_EXACT): device view, build, launchers.
+//
+// Layout (built on the device by grid_build.hip from the tree's leaves):
+//   pts    float4 {x, y, z, bits(tree leaf slot)} sorted by linear cell index (x fastest) — a cell's points are one run
+//   cells  open-addressing hash, 16 bytes per entry {cell key, start, count, -}: only occupied cells exist, so the cell edge is
+//          set by the data (≈4 leaves per occupied cell), not by the size of a dense offset array over the map's bounding box
+//   tiles  4×4×4 cells; the per-iteration query binning counts queries per tile in a dense array of n_tiles counters
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <string>
 
 #include "launch.hpp"
 
 namespace locgpu {
 
+constexpr int kGridTile = 4;                    // cells per tile edge
+constexpr uint32_t kEmptyCell = 0xFFFFFFFFu;
+
 struct GridView {
-    const uint32_t* cell_start = nullptr;  // [nx*ny*nz + 1]
-    const float4* pts = nullptr;           // leaves sorted by cell: x, y, z, bits(tree leaf slot)
-    int dims[3] = {0, 0, 0};
+    const uint4* cells = nullptr;   // [cell_cap] hash table, key kEmptyCell = free
+    uint32_t cell_mask = 0;         // cell_cap - 1 (power of two)
+    const float4* pts = nullptr;    // leaves sorted by cell
+    int dims[3] = {0, 0, 0};        // cells per axis
+    int tdims[3] = {0, 0, 0};       // tiles per axis
     float origin[3] = {0, 0, 0};
     float cell = 1.f, inv_cell = 1.f, slack = 0.f;
-    size_t num_points = 0, bytes = 0;
+    size_t num_points = 0, num_cells = 0, bytes = 0;
+    uint32_t n_tiles = 0;
+    // per-iteration query binning (scratch owned by the context)
+    uint32_t* tile_count = nullptr;  // [n_tiles + 1]
+    void* scan_temp = nullptr;
+    size_t scan_temp_bytes = 0;
 };
 
-// Search stage of one GN iteration in grid mode: grid kernel + exact tree kernel for the queries it could not settle.
-bool launch_icp_search_grid(const GridView& grid, const SearchArgs& a, hipStream_t s);
+struct GridBuffers {  // device allocations behind a GridView
+    uint4* cells = nullptr;
+    float4* pts = nullptr;
+    uint32_t* tile_count = nullptr;
+    void* scan_temp = nullptr;
+};
+
+// Builds the grid from the packed tree's leaves (d_tree, d_leaf_slots). Returns hipSuccess or the failing call's error;
+// `msg` explains a logical failure (e.g. non-finite coordinates), reported with hipErrorInvalidValue.
+hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, size_t n_leaves, hipStream_t s, GridBuffers& buf, GridView& view,
+                             std::string& msg);
+void grid_free(GridBuffers& buf);
+
+struct GridSearchScratch {  // per batch: the queries of one iteration, binned by tile
+    uint32_t* qkey;     // [pitch] tile key of query gi (kEmptyCell: not binned)
+    uint2* sorted;      // [pitch] {gi, tile key} in tile order
+};
+
+// Search stage of one GN iteration in grid mode: bin by tile → tile kernel (LDS-staged candidate blocks) → ring walk for the
+// queries the 3×3×3 block did not settle → exact tree kernel for what is still open / tied.
+bool launch_icp_search_grid(const GridView& grid, const SearchArgs& a, const GridSearchScratch& scratch, hipStream_t s);
 bool launch_knn_grid_query(const GridView& grid, const uint2* tree, const float* q, size_t nq, int k, int32_t* out, unsigned int* n_flagged,
                            hipStream_t s);
 

@@ -225,9 +225,11 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
     // The fast search kernel assumes squared distances cannot overflow or be NaN: true when every float in the tree (leaf
     // coordinates and split thresholds) is finite and small enough. Otherwise searches use the exact kernel only.
     out.bounded = true;
-    for (size_t i = 0; i < out.slots.size() && out.bounded;) {
+    out.leaf_slots.reserve(out.num_leaves);
+    for (size_t i = 0; i < out.slots.size();) {
         const uint32_t meta = (uint32_t)(out.slots[i] >> 32);
         const bool leaf = (meta >> 30) == 3u;
+        if (leaf) out.leaf_slots.push_back((uint32_t)i);
         float f[3];
         const uint32_t w0 = (uint32_t)out.slots[i];
         std::memcpy(&f[0], &w0, 4);

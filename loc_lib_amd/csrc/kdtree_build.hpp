@@ -9,6 +9,7 @@ namespace locgpu {
 
 struct PackedKdTree {
     std::vector<uint64_t> slots;  // 8-byte slots, preorder (layout in kdtree_build.cpp)
+    std::vector<uint32_t> leaf_slots;  // slot index of every leaf, in preorder (what the exact-search grid is built from on the device)
     size_t num_leaves = 0;        // KdTree::size_ (kdtree.h:124)
     size_t num_nodes = 0;         // internal + leaf nodes
     size_t num_points = 0;

@@ -16,7 +16,6 @@
 #include "batch_upload.hpp"
 #include "context.hpp"
 #include "cloud_filters.hpp"
-#include "grid_build.hpp"
 #include "kdtree_build.hpp"
 #include "launch.hpp"
 
@@ -46,39 +45,21 @@ bool hip_ok(locgpu_ctx* ctx, hipError_t e, const char* what) {
 }  // namespace locgpu
 
 static void free_grid(locgpu_ctx* ctx) {
-    if (ctx->d_cell_start) (void)hipFree(ctx->d_cell_start);
-    if (ctx->d_grid_pts) (void)hipFree(ctx->d_grid_pts);
-    ctx->d_cell_start = nullptr;
-    ctx->d_grid_pts = nullptr;
+    locgpu::grid_free(ctx->grid_buf);
     ctx->grid = locgpu::GridView();
 }
 
 // Build the exact-search grid from the packed tree already in HBM (first use of LOCGPU_SEARCH_GRID_EXACT after a set_target).
 static int ensure_grid(locgpu_ctx* ctx) {
     if (ctx->grid.pts) return LOCGPU_OK;
-    std::vector<uint64_t> slots(ctx->tree_slots);
-    LOCGPU_HIP(ctx, hipMemcpy(slots.data(), ctx->d_tree, slots.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    locgpu::SearchGrid g;
-    std::string err;
-    if (!locgpu::build_search_grid(slots.data(), slots.size(), g, err)) return locgpu::fail(ctx, LOCGPU_ERR_INVALID, "grid search: " + err);
-    LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_cell_start, g.cell_start.size() * sizeof(uint32_t)));
-    LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_grid_pts, g.num_points * sizeof(float4)));
-    LOCGPU_HIP(ctx, hipMemcpy(ctx->d_cell_start, g.cell_start.data(), g.cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    LOCGPU_HIP(ctx, hipMemcpy(ctx->d_grid_pts, g.points.data(), g.num_points * sizeof(float4), hipMemcpyHostToDevice));
-    locgpu::GridView& v = ctx->grid;
-    v.cell_start = ctx->d_cell_start;
-    v.pts = ctx->d_grid_pts;
-    float max_abs = 0.f;
-    for (int a = 0; a < 3; ++a) {
-        v.dims[a] = g.dims[a];
-        v.origin[a] = g.origin[a];
-        max_abs = std::max(max_abs, std::max(std::fabs(g.origin[a]), std::fabs(g.origin[a] + g.dims[a] * g.cell)));
+    std::string msg;
+    const hipError_t e = locgpu::grid_build_device(ctx->d_tree, ctx->d_leaf_slots, ctx->num_leaves, ctx->stream, ctx->grid_buf, ctx->grid, msg);
+    if (e != hipSuccess) {
+        free_grid(ctx);
+        if (!msg.empty()) return locgpu::fail(ctx, LOCGPU_ERR_INVALID, "grid search: " + msg);
+        locgpu::hip_ok(ctx, e, "grid build");
+        return LOCGPU_ERR_NO_DEVICE;
     }
-    v.cell = g.cell;
-    v.inv_cell = g.inv_cell;
-    v.slack = 1e-3f * g.cell + 16.f * 1.2e-7f * max_abs;  // float32 rounding of the point→cell assignment and of the face positions
-    v.num_points = g.num_points;
-    v.bytes = g.cell_start.size() * sizeof(uint32_t) + g.num_points * sizeof(float4);
     return LOCGPU_OK;
 }
 
@@ -95,6 +76,8 @@ static void free_batch(locgpu_batch* b) {
     if (b->d_redo_list) (void)hipFree(b->d_redo_list);
     if (b->d_redo_count) (void)hipFree(b->d_redo_count);
     if (b->d_redo_list2) (void)hipFree(b->d_redo_list2);
+    if (b->d_grid_qkey) (void)hipFree(b->d_grid_qkey);
+    if (b->d_grid_sorted) (void)hipFree(b->d_grid_sorted);
     if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
     if (b->h_src) (void)hipHostFree(b->h_src);
     if (b->h_state) (void)hipHostFree(b->h_state);
@@ -164,6 +147,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     free_batch(ctx->single);
     if (ctx->comm) { (void)ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
     if (ctx->d_tree) (void)hipFree(ctx->d_tree);
+    if (ctx->d_leaf_slots) (void)hipFree(ctx->d_leaf_slots);
     free_grid(ctx);
     if (ctx->d_visits) (void)hipFree(ctx->d_visits);
     if (ctx->d_search_stats) (void)hipFree(ctx->d_search_stats);
@@ -194,8 +178,10 @@ static int build_host_tree(locgpu_ctx* ctx, const void* pts, size_t n, size_t st
 // meta = {slots, leaves, nodes, points, depth, bounded}; (re)allocates the device tree.
 static int install_tree_meta(locgpu_ctx* ctx, const long long meta[6]) {
     if (ctx->d_tree) { LOCGPU_HIP(ctx, hipFree(ctx->d_tree)); ctx->d_tree = nullptr; }
+    if (ctx->d_leaf_slots) { LOCGPU_HIP(ctx, hipFree(ctx->d_leaf_slots)); ctx->d_leaf_slots = nullptr; }
     free_grid(ctx);
     LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_tree, (size_t)meta[0] * sizeof(uint64_t)));
+    LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_leaf_slots, (size_t)meta[1] * sizeof(uint32_t)));
     ctx->tree_slots = (size_t)meta[0];
     ctx->num_leaves = (size_t)meta[1];
     ctx->num_nodes = (size_t)meta[2];
@@ -216,6 +202,7 @@ int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
     rc = install_tree_meta(ctx, meta);
     if (rc != LOCGPU_OK) return rc;
     LOCGPU_HIP(ctx, hipMemcpy(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    LOCGPU_HIP(ctx, hipMemcpy(ctx->d_leaf_slots, t.leaf_slots.data(), t.leaf_slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return LOCGPU_OK;
 }
 
@@ -246,8 +233,12 @@ int locgpu_icp_set_target_bcast(locgpu_ctx* ctx, const void* pts, size_t n, size
     if (meta[6] != LOCGPU_OK) return ctx->comm_rank == root ? (int)meta[6] : fail(ctx, (int)meta[6], "icp_set_target_bcast: the root rank could not build the tree");
     rc = install_tree_meta(ctx, meta);
     if (rc != LOCGPU_OK) return rc;
-    if (ctx->comm_rank == root) LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    if (ncclBroadcast(ctx->d_tree, ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ncclChar, root, comm, s) != ncclSuccess)
+    if (ctx->comm_rank == root) {
+        LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_leaf_slots, t.leaf_slots.data(), t.leaf_slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    }
+    if (ncclBroadcast(ctx->d_tree, ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ncclChar, root, comm, s) != ncclSuccess ||
+        ncclBroadcast(ctx->d_leaf_slots, ctx->d_leaf_slots, ctx->num_leaves * sizeof(uint32_t), ncclChar, root, comm, s) != ncclSuccess)
         return fail(ctx, LOCGPU_ERR_NO_DEVICE, "icp_set_target_bcast: broadcast of the tree failed");
     LOCGPU_HIP(ctx, hipStreamSynchronize(s));
     return LOCGPU_OK;
@@ -518,7 +509,8 @@ bool IterLauncher::launch(int do_update) {
         if (grid_mode && !b->d_redo_list2) { fail(ctx, LOCGPU_ERR_INVALID, "grid search: work list missing (ensure_grid_lists was not called)"); return false; }
         sa.redo_list2 = b->d_redo_list2;
         if (grid_mode) sa.alpha_eff = 1.0f;  // the tree kernel that settles the grid's leftovers runs the exact pruning rule
-        const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, s) : launch_icp_search(sa, s);
+        const GridSearchScratch gsc{b->d_grid_qkey, b->d_grid_sorted};
+        const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, gsc, s) : launch_icp_search(sa, s);
         if (!ok_search) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
         mark();
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
@@ -579,7 +571,11 @@ static int batch_ready(locgpu_ctx* ctx, locgpu_batch* b) {
 }
 
 static int ensure_grid_lists(locgpu_ctx* ctx, locgpu_batch* b, float alpha_eff) {
-    if (alpha_eff < 0.f && !b->d_redo_list2) LOCGPU_HIP(ctx, hipMalloc((void**)&b->d_redo_list2, b->pitch * sizeof(uint32_t)));
+    if (alpha_eff < 0.f && !b->d_redo_list2) {
+        LOCGPU_HIP(ctx, hipMalloc((void**)&b->d_redo_list2, b->pitch * sizeof(uint32_t)));
+        LOCGPU_HIP(ctx, hipMalloc((void**)&b->d_grid_qkey, b->pitch * sizeof(uint32_t)));
+        LOCGPU_HIP(ctx, hipMalloc((void**)&b->d_grid_sorted, b->pitch * sizeof(uint2)));
+    }
     return LOCGPU_OK;
 }
 
@@ -943,6 +939,21 @@ int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset) {
 }
 
 }  // extern "C"
+
+// Test hook (not part of include/locgpu.h): the device-built exact-search grid of the current target, copied out so the test-suite
+// can check its invariants. info = {dims x,y,z, occupied cells, hash capacity, tiles}; params = {origin x,y,z, cell, inv_cell, slack};
+// pts: n × 4 floats (x, y, z, bits(leaf slot)) in cell order; cells: hash entries {key, start, count, -} × capacity. Returns the
+// number of grid points (0 on failure).
+extern "C" __attribute__((visibility("default"))) size_t locgpu_debug_grid_dump(locgpu_ctx* ctx, int64_t info[6], float params[6], float* pts, size_t pts_cap,
+                                                                                 uint32_t* cells, size_t cells_cap) {
+    if (!ctx || !ctx->d_tree || ensure_grid(ctx) != LOCGPU_OK) return 0;
+    const locgpu::GridView& g = ctx->grid;
+    if (info) { for (int a = 0; a < 3; ++a) info[a] = g.dims[a]; info[3] = (int64_t)g.num_cells; info[4] = (int64_t)g.cell_mask + 1; info[5] = g.n_tiles; }
+    if (params) { for (int a = 0; a < 3; ++a) params[a] = g.origin[a]; params[3] = g.cell; params[4] = g.inv_cell; params[5] = g.slack; }
+    if (pts && hipMemcpy(pts, g.pts, std::min(pts_cap, g.num_points * 4) * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (cells && hipMemcpy(cells, g.cells, std::min(cells_cap, ((size_t)g.cell_mask + 1) * 4) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return g.num_points;
+}
 
 // --------------------------------------------------------------------------------------------- NDT
 namespace locgpu {

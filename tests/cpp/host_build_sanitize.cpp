@@ -1,4 +1,4 @@
-// tests/cpp/host_build_sanitize.cpp — the host-side target ingest (packed KD-tree + exact-search grid builders) on random, duplicate-heavy, planar
+// tests/cpp/host_build_sanitize.cpp — the host-side target ingest (packed KD-tree builder and its leaf list) on random, duplicate-heavy, planar
 // and tiny clouds, meant to be compiled with -fsanitize=address,undefined (tests/test_abi_and_host.py). GPU sanitizers do not exist on this pool.
 #include <cstdio>
 #include <cstdint>
@@ -7,7 +7,6 @@
 #include <string>
 #include <vector>
 #include "kdtree_build.hpp"
-#include "grid_build.hpp"
 int main() {
     std::mt19937 rng(7);
     for (int trial = 0; trial < 40; ++trial) {
@@ -19,9 +18,8 @@ int main() {
         if (trial % 7 == 2) for (size_t i = 0; i < n; ++i) xyz[3*i+2] = 0.f;                                            // planar
         locgpu::PackedKdTree t; std::string err;
         if (!locgpu::build_packed_kdtree(xyz.data(), n, t, err)) { std::printf("build failed: %s\n", err.c_str()); return 1; }
-        locgpu::SearchGrid gr;
-        if (!locgpu::build_search_grid(t.slots.data(), t.slots.size(), gr, err)) { std::printf("grid failed: %s\n", err.c_str()); return 1; }
-        if (gr.num_points != t.num_leaves) { std::printf("leaf mismatch\n"); return 1; }
+        if (t.leaf_slots.size() != t.num_leaves) { std::printf("leaf list mismatch\n"); return 1; }
+        for (uint32_t sl : t.leaf_slots) if (((uint32_t)(t.slots[sl] >> 32) >> 30) != 3u) { std::printf("leaf list points at a non-leaf\n"); return 1; }
     }
     std::puts("asan harness ok");
     return 0;

@@ -186,49 +186,8 @@ def test_gn_update_matches_oracle(api, locref):
     assert not applied and np.array_equal(p2, pose)
 
 
-# ---------------------------------------------------------------------------------------------- host logic: exact-search grid
-@pytest.mark.parametrize("case", ["city", "duplicates"])
-def test_search_grid_invariants(api, locref, synth, case):
-    """Grid ingest (csrc/grid_build.cpp): holds exactly the tree's leaves, each inside its cell, cells sorted x-fastest."""
-    rng = np.random.RandomState(11)
-    if case == "city":
-        pts = synth.make_local_map(80000, 3, half=30.0)
-    else:
-        pts = (rng.rand(5000, 3) * 8).astype(np.float32)
-        pts[50:300] = pts[50]
-    L = api.lib()
-    L.locgpu_debug_build_grid.restype = ctypes.c_size_t
-    L.locgpu_debug_build_grid.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
-                                          ctypes.c_void_p, ctypes.c_void_p]
-    xyz = np.ascontiguousarray(pts[:, :3], dtype=np.float32)
-    dims = np.zeros(3, dtype=np.int32)
-    prm = np.zeros(5, dtype=np.float32)
-    n = L.locgpu_debug_build_grid(xyz.ctypes.data, len(xyz), None, 0, None, 0, dims.ctypes.data, prm.ctypes.data)
-    tree = locref.KdTree(pts)
-    assert n == tree.num_leaves
-    ncell = int(dims[0]) * int(dims[1]) * int(dims[2])
-    gp = np.zeros((n, 4), dtype=np.float32)
-    cs = np.zeros(ncell + 1, dtype=np.uint32)
-    L.locgpu_debug_build_grid(xyz.ctypes.data, len(xyz), gp.ctypes.data, gp.size, cs.ctypes.data, cs.size, dims.ctypes.data, prm.ctypes.data)
-    assert cs[0] == 0 and cs[-1] == n and np.all(np.diff(cs.astype(np.int64)) >= 0)
-    occupied = np.diff(cs.astype(np.int64))
-    assert 1.5 <= occupied[occupied > 0].mean() <= 12.0   # the cell edge targets ≈3 leaves per occupied cell
-    # every grid point lies in the cell its position in the sorted array says
-    cell_of_pos = np.repeat(np.arange(ncell), occupied)
-    c = np.floor((gp[:, :3] - prm[:3]) * prm[4]).astype(np.int64)
-    c = np.clip(c, 0, dims.astype(np.int64) - 1)
-    lin = (c[:, 2] * dims[1] + c[:, 1]) * dims[0] + c[:, 0]
-    np.testing.assert_array_equal(lin, cell_of_pos)
-    # the points are exactly the tree's leaf points (multiset)
-    _, _, pidx = tree.dump()
-    leaf_pts = xyz[pidx[pidx >= 0]]
-    a = np.sort(leaf_pts.view([("x", "f4"), ("y", "f4"), ("z", "f4")]).ravel(), order=["x", "y", "z"])
-    b = np.sort(np.ascontiguousarray(gp[:, :3]).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).ravel(), order=["x", "y", "z"])
-    assert np.array_equal(a, b)
-
-
 def test_host_ingest_is_clean_under_asan_ubsan(tmp_path):
-    """The multithreaded host builders (csrc/kdtree_build.cpp, grid_build.cpp) under AddressSanitizer + UBSan (CPU build only)."""
+    """The multithreaded host tree builder (csrc/kdtree_build.cpp) under AddressSanitizer + UBSan (CPU build only)."""
     import shutil
     import subprocess
     if not shutil.which("g++"):
@@ -236,7 +195,7 @@ def test_host_ingest_is_clean_under_asan_ubsan(tmp_path):
     csrc = os.path.join(ROOT, "loc_lib_amd", "csrc")
     exe = str(tmp_path / "host_build_sanitize")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-I", csrc,
-           os.path.join(ROOT, "tests", "cpp", "host_build_sanitize.cpp"), os.path.join(csrc, "kdtree_build.cpp"), os.path.join(csrc, "grid_build.cpp"),
+           os.path.join(ROOT, "tests", "cpp", "host_build_sanitize.cpp"), os.path.join(csrc, "kdtree_build.cpp"),
            "-o", exe, "-pthread"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     if r.returncode != 0 and "sanitize" in r.stderr:

@@ -280,3 +280,53 @@ def test_async_upload_double_buffer(gpu_ctx, api, small_world):
     finally:
         for x in bufs:
             x.close()
+
+
+# ----------------------------------------------------------------------------------------------- exact-search grid ingest (device)
+@pytest.mark.parametrize("case", ["city", "duplicates"])
+def test_device_grid_invariants(api, locref, synth, case):
+    """Grid ingest on the GPU (csrc/grid_build.hip): holds exactly the tree's leaves, sorted by linear cell index (x fastest), every
+    occupied cell in the hash table with the right start and count, the cell edge near the target occupancy."""
+    import ctypes
+    rng = np.random.RandomState(11)
+    if case == "city":
+        pts = synth.make_local_map(80000, 3, half=30.0)
+    else:
+        pts = (rng.rand(5000, 3) * 8).astype(np.float32)
+        pts[50:300] = pts[50]
+    ctx = api.Context(0)
+    try:
+        ctx.icp_set_target(pts)
+        L = api.lib()
+        L.locgpu_debug_grid_dump.restype = ctypes.c_size_t
+        L.locgpu_debug_grid_dump.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        info = np.zeros(6, np.int64)
+        prm = np.zeros(6, np.float32)
+        n = L.locgpu_debug_grid_dump(ctx._h, info.ctypes.data, prm.ctypes.data, None, 0, None, 0)
+        tree = locref.KdTree(pts)
+        assert n == tree.num_leaves
+        dims, n_occ, cap = info[:3], int(info[3]), int(info[4])
+        gp = np.zeros((n, 4), np.float32)
+        cells = np.zeros((cap, 4), np.uint32)
+        L.locgpu_debug_grid_dump(ctx._h, info.ctypes.data, prm.ctypes.data, gp.ctypes.data, gp.size, cells.ctypes.data, cells.size)
+        c = np.floor((gp[:, :3] - prm[:3]) * prm[4]).astype(np.int64)
+        assert np.all(c >= 0) and np.all(c < dims)
+        lin = (c[:, 2] * dims[1] + c[:, 1]) * dims[0] + c[:, 0]
+        assert np.all(np.diff(lin) >= 0)                                        # cell order
+        keys, starts, counts = np.unique(lin, return_index=True, return_counts=True)
+        assert len(keys) == n_occ and 1.5 <= counts.mean() <= 16.0              # the edge targets ≈4 leaves per occupied cell
+        used = cells[cells[:, 0] != 0xFFFFFFFF]
+        assert len(used) == n_occ and cap >= 2 * n_occ
+        order = np.argsort(used[:, 0])
+        np.testing.assert_array_equal(used[order, 0].astype(np.int64), keys)
+        np.testing.assert_array_equal(used[order, 1].astype(np.int64), starts)
+        np.testing.assert_array_equal(used[order, 2].astype(np.int64), counts)
+        # the points are exactly the tree's leaf points (multiset)
+        _, _, pidx = tree.dump()
+        xyz = np.ascontiguousarray(pts[:, :3], dtype=np.float32)
+        leaf_pts = xyz[pidx[pidx >= 0]]
+        a = np.sort(leaf_pts.view([("x", "f4"), ("y", "f4"), ("z", "f4")]).ravel(), order=["x", "y", "z"])
+        b = np.sort(np.ascontiguousarray(gp[:, :3]).view([("x", "f4"), ("y", "f4"), ("z", "f4")]).ravel(), order=["x", "y", "z"])
+        assert np.array_equal(a, b)
+    finally:
+        ctx.close()
