@@ -207,8 +207,9 @@ LOCGPU_API int locgpu_visit_count_enable(locgpu_ctx* ctx, int on);
 LOCGPU_API int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset);
 
 /* Search bookkeeping since the last reset (enabled by the first call): out[0] = queries handled by the fast search
- * kernel's launches, out[1] = queries it handed to the exact redo kernel (distance ties / near-misses on the top tree levels). */
-LOCGPU_API int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[2], int reset);
+ * kernel's launches, out[1] = queries it handed to the exact redo kernel (distance ties / near-misses on the top tree levels),
+ * out[2] = grid mode: queries the tile kernel handed to the ring-walk kernel, out[3] = reserved (0). */
+LOCGPU_API int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset);
 
 /* =====================================================================================================================
  * Clouds resident in HBM and the filters either side of the matcher.

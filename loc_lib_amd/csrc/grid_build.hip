@@ -8,9 +8,10 @@
 //
 // Everything runs on the GPU from the tree that is already in HBM (no copy of the map back to the host):
 //   gather the leaves → bounding box (block partials) → cell edge: the smallest of a geometric ladder for which an occupied
-//   cell holds ≥ kTargetOccupancy leaves on average (64-bit cell keys, radix sort, count of distinct keys) → 32-bit linear
-//   cell keys (x fastest) → stable radix sort of (key, leaf) → leaves gathered in cell order → run-length encode (occupied
-//   cells, counts) → exclusive scan (starts) → open-addressing hash table cell → {start, count}.
+//   cell holds ≥ the target occupancy on average (64-bit cell keys, radix sort, count of distinct keys) → 32-bit keys
+//   (tile · 64 + cell inside the tile) → stable radix sort of (key, leaf) → leaves gathered in that order → run-length encode of
+//   the tile part (occupied tiles, leaf counts) → exclusive scan (first leaf of every tile) → one wave per occupied tile writes
+//   its record (65 prefix sums of the cells' counts) → open-addressing hash table tile → record.
 #include "grid_kernels.hpp"
 
 #include <hipcub/hipcub.hpp>
@@ -83,37 +84,62 @@ __global__ __launch_bounds__(kGB) void count_distinct_kernel(const unsigned long
 }
 
 __global__ __launch_bounds__(kGB) void cell_key_kernel(const float4* __restrict__ pts, size_t n, float ox, float oy, float oz, float inv, int nx, int ny,
-                                                       int nz, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+                                                       int nz, int ntx, int nty, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
     const size_t i = (size_t)blockIdx.x * kGB + threadIdx.x;
     if (i >= n) return;
     const float4 p = pts[i];
     // the SAME float32 expression the query kernels evaluate (grid_kernels.hip: cell_coord)
     int cx = (int)floorf((p.x - ox) * inv), cy = (int)floorf((p.y - oy) * inv), cz = (int)floorf((p.z - oz) * inv);
     cx = min(max(cx, 0), nx - 1); cy = min(max(cy, 0), ny - 1); cz = min(max(cz, 0), nz - 1);
-    keys[i] = (uint32_t)(((size_t)cz * ny + cy) * nx + cx);
+    const uint32_t tile = (uint32_t)(((cz / kGridTile) * nty + (cy / kGridTile)) * ntx + (cx / kGridTile));
+    const uint32_t in_tile = (uint32_t)(((cz % kGridTile) * kGridTile + (cy % kGridTile)) * kGridTile + (cx % kGridTile));
+    keys[i] = tile * (uint32_t)kTileCells + in_tile;
     idx[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(kGB) void gather_sorted_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ idx, size_t n, float4* __restrict__ out) {
+__global__ __launch_bounds__(kGB) void gather_sorted_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ key_s,
+                                                            size_t n, float4* __restrict__ out, uint32_t* __restrict__ tile_of) {
     const size_t i = (size_t)blockIdx.x * kGB + threadIdx.x;
-    if (i < n) out[i] = in[idx[i]];
+    if (i < n) { out[i] = in[idx[i]]; tile_of[i] = key_s[i] / (uint32_t)kTileCells; }
 }
 
-__device__ __forceinline__ uint32_t cell_hash(uint32_t k) {
+__device__ __forceinline__ uint32_t tile_hash_fn(uint32_t k) {
     k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16;
     return k;
 }
 
-__global__ __launch_bounds__(kGB) void hash_insert_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ starts,
-                                                          const uint32_t* __restrict__ counts, uint32_t n_occ, uint4* __restrict__ cells, uint32_t mask) {
-    const uint32_t i = blockIdx.x * kGB + threadIdx.x;
-    if (i >= n_occ) return;
-    const uint32_t key = keys[i];
-    uint32_t h = cell_hash(key) & mask;
-    for (;;) {
-        const uint32_t prev = atomicCAS(&cells[h].x, kEmptyCell, key);
-        if (prev == kEmptyCell) { cells[h].y = starts[i]; cells[h].z = counts[i]; return; }
-        h = (h + 1) & mask;
+// One wave per occupied tile: lane c counts the tile's leaves in cell c, a wave prefix sum gives cstart[].
+__global__ __launch_bounds__(64) void tile_record_kernel(const uint32_t* __restrict__ key_s, const uint32_t* __restrict__ tile_lin,
+                                                         const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ tile_cnt, uint32_t n_tocc,
+                                                         TileRec* __restrict__ tiles, uint2* __restrict__ hash, uint32_t mask, unsigned int* __restrict__ flags) {
+    const uint32_t t = blockIdx.x;
+    if (t >= n_tocc) return;
+    const int lane = threadIdx.x;
+    const uint32_t s0 = tile_start[t], cnt = tile_cnt[t];
+    uint32_t mine = 0;
+    for (uint32_t i = 0; i < cnt; ++i) mine += ((key_s[s0 + i] & (uint32_t)(kTileCells - 1)) == (uint32_t)lane) ? 1u : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    TileRec& r = tiles[t];
+    r.cstart[lane] = (uint16_t)(incl - mine);
+    const unsigned long long occ = __ballot(mine != 0);
+    if (lane == 63) {
+        r.cstart[64] = (uint16_t)incl;
+        r.cstart[65] = 0;
+        r.pt_start = s0;
+        r.tile_lin = tile_lin[t];
+        if (cnt > 65535u) atomicOr(&flags[0], 2u);  // a tile must fit 16-bit prefix sums
+        atomicAdd(&flags[1], (unsigned int)__popcll(occ));
+        uint32_t h = tile_hash_fn(tile_lin[t]) & mask;
+        for (;;) {
+            const uint32_t prev = atomicCAS(&hash[h].x, kEmptyCell, tile_lin[t]);
+            if (prev == kEmptyCell) { hash[h].y = t; break; }
+            h = (h + 1) & mask;
+        }
     }
 }
 
@@ -138,7 +164,8 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + kGB - 1) / kGB); }
 }  // namespace
 
 void grid_free(GridBuffers& b) {
-    if (b.cells) (void)hipFree(b.cells);
+    if (b.tile_hash) (void)hipFree(b.tile_hash);
+    if (b.tiles) (void)hipFree(b.tiles);
     if (b.pts) (void)hipFree(b.pts);
     if (b.tile_count) (void)hipFree(b.tile_count);
     if (b.scan_temp) (void)hipFree(b.scan_temp);
@@ -205,7 +232,7 @@ hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, 
         cell = c;
         if (occ == 0 || (double)n / (double)occ >= target_occ) break;
     }
-    // 32-bit linear cell keys and at most 2^26 tiles (the binning histogram is dense over tiles)
+    // the 32-bit sort key is tile·64 + cell-in-tile: at most 2^26 tiles
     int dims[3], tdims[3];
     float cellf, inv;
     for (;;) {
@@ -230,39 +257,49 @@ hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, 
         tdims[a] = (dims[a] + kGridTile - 1) / kGridTile;
     }
 
-    // ---- sort the leaves by cell
-    uint32_t *d_key = nullptr, *d_idx = nullptr, *d_key_s = nullptr, *d_idx_s = nullptr, *d_ukey = nullptr, *d_cnt = nullptr, *d_start = nullptr, *d_nocc = nullptr;
+    // ---- sort the leaves by (tile, cell inside the tile)
+    uint32_t *d_key = nullptr, *d_idx = nullptr, *d_key_s = nullptr, *d_idx_s = nullptr, *d_tile_of = nullptr, *d_utile = nullptr, *d_cnt = nullptr,
+             *d_start = nullptr, *d_nocc = nullptr;
     GB_TRY(tmp.alloc(&d_key, n * 4)); GB_TRY(tmp.alloc(&d_idx, n * 4)); GB_TRY(tmp.alloc(&d_key_s, n * 4)); GB_TRY(tmp.alloc(&d_idx_s, n * 4));
-    GB_TRY(tmp.alloc(&d_ukey, n * 4)); GB_TRY(tmp.alloc(&d_cnt, n * 4)); GB_TRY(tmp.alloc(&d_start, n * 4)); GB_TRY(tmp.alloc(&d_nocc, 4));
-    hipLaunchKernelGGL(cell_key_kernel, dim3(blocks_for(n)), dim3(kGB), 0, s, d_leaves, n, lo[0], lo[1], lo[2], inv, dims[0], dims[1], dims[2], d_key, d_idx);
+    GB_TRY(tmp.alloc(&d_tile_of, n * 4)); GB_TRY(tmp.alloc(&d_utile, n * 4)); GB_TRY(tmp.alloc(&d_cnt, n * 4)); GB_TRY(tmp.alloc(&d_start, n * 4));
+    GB_TRY(tmp.alloc(&d_nocc, 4));
+    hipLaunchKernelGGL(cell_key_kernel, dim3(blocks_for(n)), dim3(kGB), 0, s, d_leaves, n, lo[0], lo[1], lo[2], inv, dims[0], dims[1], dims[2], tdims[0],
+                       tdims[1], d_key, d_idx);
     size_t tb = sort_bytes;
     GB_TRY(hipcub::DeviceRadixSort::SortPairs(d_sort_tmp, tb, d_key, d_key_s, d_idx, d_idx_s, (int)n, 0, 32, s));  // stable: tree order inside a cell
     GB_TRY(hipMalloc((void**)&buf.pts, n * sizeof(float4)));
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for(n)), dim3(kGB), 0, s, d_leaves, d_idx_s, n, buf.pts);
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for(n)), dim3(kGB), 0, s, d_leaves, d_idx_s, d_key_s, n, buf.pts, d_tile_of);
     tb = sort_bytes;
-    GB_TRY(hipcub::DeviceRunLengthEncode::Encode(d_sort_tmp, tb, d_key_s, d_ukey, d_cnt, d_nocc, (int)n, s));
-    uint32_t n_occ = 0;
-    GB_TRY(hipMemcpyAsync(&n_occ, d_nocc, 4, hipMemcpyDeviceToHost, s));
+    GB_TRY(hipcub::DeviceRunLengthEncode::Encode(d_sort_tmp, tb, d_tile_of, d_utile, d_cnt, d_nocc, (int)n, s));
+    uint32_t n_tocc = 0;
+    GB_TRY(hipMemcpyAsync(&n_tocc, d_nocc, 4, hipMemcpyDeviceToHost, s));
     GB_TRY(hipStreamSynchronize(s));
     tb = sort_bytes;
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_sort_tmp, tb, d_cnt, d_start, (int)n_occ, s));
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_sort_tmp, tb, d_cnt, d_start, (int)n_tocc, s));
     uint32_t cap = 1024;
-    while (cap < 2u * n_occ) cap <<= 1;
-    GB_TRY(hipMalloc((void**)&buf.cells, (size_t)cap * sizeof(uint4)));
-    GB_TRY(hipMemsetAsync(buf.cells, 0xFF, (size_t)cap * sizeof(uint4), s));
-    hipLaunchKernelGGL(hash_insert_kernel, dim3(blocks_for(n_occ)), dim3(kGB), 0, s, d_ukey, d_start, d_cnt, n_occ, buf.cells, cap - 1);
+    while (cap < 2u * n_tocc) cap <<= 1;
+    GB_TRY(hipMalloc((void**)&buf.tile_hash, (size_t)cap * sizeof(uint2)));
+    GB_TRY(hipMemsetAsync(buf.tile_hash, 0xFF, (size_t)cap * sizeof(uint2), s));
+    GB_TRY(hipMalloc((void**)&buf.tiles, (size_t)n_tocc * sizeof(TileRec)));
+    GB_TRY(hipMemsetAsync(d_flag, 0, 2 * sizeof(unsigned int), s));
+    hipLaunchKernelGGL(tile_record_kernel, dim3(n_tocc), dim3(64), 0, s, d_key_s, d_utile, d_start, d_cnt, n_tocc, buf.tiles, buf.tile_hash, cap - 1, d_flag);
+    GB_TRY(hipMemcpyAsync(flag, d_flag, sizeof(flag), hipMemcpyDeviceToHost, s));
+    GB_TRY(hipStreamSynchronize(s));
+    if (flag[0] & 2u) { msg = "a tile holds more than 65535 leaves (degenerate point distribution)"; return hipErrorInvalidValue; }
+    const uint32_t n_occ = flag[1];
 
-    // ---- per-iteration binning scratch
-    const uint32_t n_tiles = (uint32_t)tdims[0] * (uint32_t)tdims[1] * (uint32_t)tdims[2];
-    GB_TRY(hipMalloc((void**)&buf.tile_count, ((size_t)n_tiles + 2) * sizeof(uint32_t)));
+    // ---- per-iteration binning scratch: one counter per occupied tile
+    GB_TRY(hipMalloc((void**)&buf.tile_count, ((size_t)n_tocc + 2) * sizeof(uint32_t)));
     size_t scan_bytes = 0;
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, buf.tile_count, buf.tile_count, (int)(n_tiles + 1), s));
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, buf.tile_count, buf.tile_count, (int)(n_tocc + 1), s));
     GB_TRY(hipMalloc(&buf.scan_temp, scan_bytes ? scan_bytes : 1));
     GB_TRY(hipGetLastError());
     GB_TRY(hipStreamSynchronize(s));
 
-    view.cells = buf.cells;
-    view.cell_mask = cap - 1;
+    view.tile_hash = buf.tile_hash;
+    view.tile_mask = cap - 1;
+    view.tiles = buf.tiles;
+    view.n_tocc = n_tocc;
     view.pts = buf.pts;
     float max_abs = 0.f;
     for (int a = 0; a < 3; ++a) {
@@ -276,11 +313,10 @@ hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, 
     view.slack = 1e-3f * cellf + 16.f * 1.2e-7f * max_abs;  // float32 rounding of the point→cell assignment and of the face positions
     view.num_points = n;
     view.num_cells = n_occ;
-    view.n_tiles = n_tiles;
     view.tile_count = buf.tile_count;
     view.scan_temp = buf.scan_temp;
     view.scan_temp_bytes = scan_bytes;
-    view.bytes = (size_t)cap * sizeof(uint4) + n * sizeof(float4) + ((size_t)n_tiles + 2) * sizeof(uint32_t);
+    view.bytes = (size_t)cap * sizeof(uint2) + (size_t)n_tocc * sizeof(TileRec) + n * sizeof(float4) + ((size_t)n_tocc + 2) * sizeof(uint32_t);
     return hipSuccess;
 }
 

@@ -1,4 +1,4 @@
-// loc_lib_amd/csrc/grid_kernels.hip — exact k-NN over the cell grid (LOCGPU_SEARCH_GRID_EXACT), gfx950.
+// loc_lib_amd/csrc/grid_kernels.hip — exact k-NN over the tile/cell grid (LOCGPU_SEARCH_GRID_EXACT), gfx950.
 //
 // Equals KdTree::GetClosestPoint with approximate_ = false (kdtree.cpp:147-167 with the exact NeedExpand branch :227-235): the
 // k leaves with the smallest float32 dist² (same Eigen reduction order, no FMA), ascending; a candidate replaces the current
@@ -7,15 +7,18 @@
 // exact tree kernel, as are queries whose neighbours lie many cells away.
 //
 // One Gauss–Newton iteration's search stage:
-//   1. bin     every query (transformed source point) → its tile (4×4×4 cells): per-tile counters, exclusive scan, scatter —
-//              a counting sort whose sizes live on the device (no host round trip; scans that have converged drop out).
-//   2. tiles   one-wave workgroups walk the tile-ordered query list in chunks of 64. For each distinct tile of a chunk the wave
-//              stages the tile's candidate block — its 6×6×6 cells (the tile and one ring): 216 hash look-ups, a wave prefix sum,
-//              then the cells' leaves streamed from the cell-sorted array (16-byte loads of consecutive addresses) into LDS —
-//              once, and every query of the tile takes its 3×3×3 cells from LDS (9 runs: consecutive cells along x are adjacent).
-//              Dense tiles fill whole chunks, so a staged block serves up to 64 queries.
-//   3. walk    queries the 3×3×3 block did not settle (k-th distance beyond the block's nearest open face), outside the grid, or in
-//              a block larger than the LDS stage: ring by ring through the hash, one thread per query, on the compacted list.
+//   1. bin     every query (transformed source point) → the occupied tile (4×4×4 cells) it falls in: a counting sort whose sizes
+//              live on the device (no host round trip; scans that have converged drop out). Each 256-thread block first merges its
+//              queries' tiles in an LDS hash, so the global counters see one atomic per distinct tile per block — hot tiles (thousands
+//              of queries) would otherwise serialise on same-address atomics.
+//   2. tiles   one-wave workgroups walk the tile-ordered query list in ranges of 256. For every run of queries of one tile the wave
+//              stages the tile's candidate block — its 6×6×6 cells (the tile and one ring): 27 tile look-ups (L2-resident hash),
+//              216 cell extents from the tile records, a wave prefix sum, then the cells' leaves streamed from the (tile, cell)-sorted
+//              array into LDS — once, and every query of the run takes its 3×3×3 cells from LDS (9 runs: consecutive cells along
+//              x are adjacent in the staged block).
+//   3. walk    queries the 3×3×3 block did not settle (k-th distance beyond the block's nearest open face), outside every occupied
+//              tile, or in a block larger than the LDS stage: ring by ring through the tile records, one thread per query, on the
+//              compacted list.
 //   4. tree    what is still open after `max_ring2` rings, and every tie: icp_search_redo_kernel with alpha = 1.
 #include "grid_kernels.hpp"
 #include "icp_kernels.hpp"
@@ -27,32 +30,49 @@
 namespace locgpu {
 
 struct GridDev {
-    const uint4* cells;
-    uint32_t mask;
+    const uint2* tile_hash;
+    uint32_t tile_mask;
+    const TileRec* tiles;
     const float4* pts;
     int nx, ny, nz, ntx, nty, ntz;
     float ox, oy, oz, cell, inv_cell, slack;
     int max_ring2;  // rings examined by the walk kernel
 };
 
-__device__ __forceinline__ uint32_t cell_hash(uint32_t k) {
+__device__ __forceinline__ uint32_t tile_hash_fn(uint32_t k) {
     k ^= k >> 16; k *= 0x7feb352du; k ^= k >> 15; k *= 0x846ca68bu; k ^= k >> 16;
     return k;
 }
 // the float32 expression grid_build.hip's cell_key_kernel evaluates
 __device__ __forceinline__ int cell_coord(float v, float o, float inv) { return (int)floorf((v - o) * inv); }
 
-// {first point, count} of a cell; {0, 0} outside the grid or when no leaf lies in it
+// record index of tile (tx,ty,tz), or -1 (outside the grid, or no leaf in the tile)
+__device__ __forceinline__ int tile_lookup(const GridDev& g, int tx, int ty, int tz) {
+    if ((unsigned)tx >= (unsigned)g.ntx || (unsigned)ty >= (unsigned)g.nty || (unsigned)tz >= (unsigned)g.ntz) return -1;
+    const uint32_t key = (uint32_t)((tz * g.nty + ty) * g.ntx + tx);
+    uint32_t h = tile_hash_fn(key) & g.tile_mask;
+    for (;;) {
+        const uint2 e = g.tile_hash[h];
+        if (e.x == key) return (int)e.y;
+        if (e.x == kEmptyCell) return -1;
+        h = (h + 1) & g.tile_mask;
+    }
+}
+
+// {first leaf, count} of cell (ix,iy,iz) of tile record t
+__device__ __forceinline__ uint2 cell_extent(const GridDev& g, int t, int ix, int iy, int iz) {
+    const TileRec* r = g.tiles + t;
+    const int c = (iz * kGridTile + iy) * kGridTile + ix;
+    const uint32_t a = r->cstart[c], b = r->cstart[c + 1];
+    return make_uint2(r->pt_start + a, b - a);
+}
+
+// {first leaf, count} of a cell given by global cell coordinates; {0, 0} when no leaf lies in it
 __device__ __forceinline__ uint2 cell_lookup(const GridDev& g, int cx, int cy, int cz) {
     if ((unsigned)cx >= (unsigned)g.nx || (unsigned)cy >= (unsigned)g.ny || (unsigned)cz >= (unsigned)g.nz) return make_uint2(0u, 0u);
-    const uint32_t key = (uint32_t)(((size_t)cz * g.ny + cy) * g.nx + cx);
-    uint32_t h = cell_hash(key) & g.mask;
-    for (;;) {
-        const uint4 e = g.cells[h];
-        if (e.x == key) return make_uint2(e.y, e.z);
-        if (e.x == kEmptyCell) return make_uint2(0u, 0u);
-        h = (h + 1) & g.mask;
-    }
+    const int t = tile_lookup(g, cx / kGridTile, cy / kGridTile, cz / kGridTile);
+    if (t < 0) return make_uint2(0u, 0u);
+    return cell_extent(g, t, cx % kGridTile, cy % kGridTile, cz % kGridTile);
 }
 
 // One candidate. Ties that could make the reference's answer depend on its visit order raise `tie`.
@@ -82,7 +102,7 @@ __device__ __forceinline__ int settle(const GridDev& g, const SortedSet<K>& set,
     return (set.n == K && safe > 0.f && set.top() <= safe * safe) ? 0 : 1;
 }
 
-// Ring walk through the hash, one thread per query. Returns true when the tree kernel must answer (tie, NaN, too far, < K leaves).
+// Ring walk through the tile records, one thread per query. Returns true when the tree kernel must answer (tie, NaN, too far, < K leaves).
 template <int K>
 __device__ __forceinline__ bool grid_knn_walk(const GridDev& g, float qx, float qy, float qz, SortedSet<K>& set, int max_ring) {
     set.init();
@@ -111,56 +131,89 @@ __device__ __forceinline__ bool grid_knn_walk(const GridDev& g, float qx, float 
 }
 
 // ------------------------------------------------------------------------------------------------ 1. binning
+constexpr int kBinSlots = 512;  // LDS hash slots per 256-thread block (≥ 2 × the block's queries)
+
+// Block-local merge of the block's tile keys. Every thread with `has` gets the slot of its key and its rank among the block's
+// queries of that key. After the call (it ends with a barrier) s_key/s_cnt hold the distinct keys and their counts.
+__device__ __forceinline__ void block_merge_keys(bool has, uint32_t key, uint32_t* s_key, uint32_t* s_cnt, int& slot, uint32_t& rank) {
+    for (int i = threadIdx.x; i < kBinSlots; i += kBlock) { s_key[i] = kEmptyCell; s_cnt[i] = 0u; }
+    __syncthreads();
+    slot = -1;
+    rank = 0;
+    if (has) {
+        uint32_t h = tile_hash_fn(key) & (kBinSlots - 1);
+        for (;;) {
+            const uint32_t prev = atomicCAS(&s_key[h], kEmptyCell, key);
+            if (prev == kEmptyCell || prev == key) break;
+            h = (h + 1) & (kBinSlots - 1);
+        }
+        slot = (int)h;
+        rank = atomicAdd(&s_cnt[h], 1u);
+    }
+    __syncthreads();
+}
+
 template <int K>
 __global__ __launch_bounds__(kBlock) void grid_bin_count_kernel(GridDev g, const float4* __restrict__ src, const int* __restrict__ counts,
                                                                 const PoseState* __restrict__ st, uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                 int skip_nonfinite, uint32_t* __restrict__ qkey, uint32_t* __restrict__ tile_count,
                                                                 uint32_t* __restrict__ walk_list, unsigned int* __restrict__ walk_count,
                                                                 unsigned long long* __restrict__ search_stats) {
+    __shared__ uint32_t s_key[kBinSlots], s_cnt[kBinSlots];
     const int scan = blockIdx.y;
-    if (st[scan].done) return;
+    if (st[scan].done) return;  // uniform per block
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= counts[scan]) return;
     const size_t gi = (size_t)scan * max_n + i;
-    const float4 p = src[gi];
-    if (skip_nonfinite && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {  // pcl::isFinite, icp cpp:64 (P2P only)
+    bool has = false;
+    uint32_t key = kEmptyCell;
+    if (i < counts[scan]) {
+        const float4 p = src[gi];
+        if (skip_nonfinite && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {  // pcl::isFinite, icp cpp:64 (P2P only)
 #pragma unroll
-        for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = kInvalidSlot;
-        qkey[gi] = kEmptyCell;
-        return;
+            for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = kInvalidSlot;
+        } else {
+            if (search_stats) atomicAdd(&search_stats[0], 1ull);
+            const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
+            const float qx = (float)qs.x, qy = (float)qs.y, qz = (float)qs.z;
+            const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
+            const bool inside = qx == qx && qy == qy && qz == qz && (unsigned)cx < (unsigned)g.nx && (unsigned)cy < (unsigned)g.ny && (unsigned)cz < (unsigned)g.nz;
+            const int t = inside ? tile_lookup(g, cx / kGridTile, cy / kGridTile, cz / kGridTile) : -1;
+            if (t >= 0) { has = true; key = (uint32_t)t; }
+            else walk_list[atomicAdd(walk_count, 1u)] = (uint32_t)gi;  // outside every occupied tile (or NaN): the walk kernel handles it
+        }
+        qkey[gi] = key;
     }
-    if (search_stats) atomicAdd(&search_stats[0], 1ull);
-    const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
-    const float qx = (float)qs.x, qy = (float)qs.y, qz = (float)qs.z;
-    const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
-    const bool inside = qx == qx && qy == qy && qz == qz && (unsigned)cx < (unsigned)g.nx && (unsigned)cy < (unsigned)g.ny && (unsigned)cz < (unsigned)g.nz;
-    if (!inside) {  // outside the leaves' bounding box (or NaN): the walk kernel handles it
-        qkey[gi] = kEmptyCell;
-        walk_list[atomicAdd(walk_count, 1u)] = (uint32_t)gi;
-        return;
-    }
-    const uint32_t tile = (uint32_t)(((cz / kGridTile) * g.nty + (cy / kGridTile)) * g.ntx + (cx / kGridTile));
-    qkey[gi] = tile;
-    atomicAdd(&tile_count[tile], 1u);
+    int slot;
+    uint32_t rank;
+    block_merge_keys(has, key, s_key, s_cnt, slot, rank);
+    for (int s = threadIdx.x; s < kBinSlots; s += kBlock)
+        if (s_key[s] != kEmptyCell) atomicAdd(&tile_count[s_key[s]], s_cnt[s]);
 }
 
 __global__ __launch_bounds__(kBlock) void grid_bin_scatter_kernel(const int* __restrict__ counts, const PoseState* __restrict__ st, int max_n,
                                                                   const uint32_t* __restrict__ qkey, uint32_t* __restrict__ tile_offset,
                                                                   uint2* __restrict__ sorted) {
+    __shared__ uint32_t s_key[kBinSlots], s_cnt[kBinSlots], s_base[kBinSlots];
     const int scan = blockIdx.y;
     if (st[scan].done) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= counts[scan]) return;
     const size_t gi = (size_t)scan * max_n + i;
-    const uint32_t key = qkey[gi];
-    if (key == kEmptyCell) return;
-    sorted[atomicAdd(&tile_offset[key], 1u)] = make_uint2((uint32_t)gi, key);
+    const uint32_t key = i < counts[scan] ? qkey[gi] : kEmptyCell;
+    const bool has = key != kEmptyCell;
+    int slot;
+    uint32_t rank;
+    block_merge_keys(has, key, s_key, s_cnt, slot, rank);
+    for (int s = threadIdx.x; s < kBinSlots; s += kBlock)
+        if (s_key[s] != kEmptyCell) s_base[s] = atomicAdd(&tile_offset[s_key[s]], s_cnt[s]);
+    __syncthreads();
+    if (has) sorted[s_base[slot] + rank] = make_uint2((uint32_t)gi, key);
 }
 
 // ------------------------------------------------------------------------------------------------ 2. tiles
-constexpr int kStageEdge = kGridTile + 2;                                  // 6 cells: the tile and one ring
+constexpr int kStageEdge = kGridTile + 2;                              // 6 cells: the tile and one ring
 constexpr int kStageCells = kStageEdge * kStageEdge * kStageEdge;      // 216
-constexpr int kStageCap = 1024;                                        // leaves a staged block may hold (16 KB of LDS)
+constexpr int kStageCap = 768;                                         // leaves a staged block may hold (12 KB of LDS)
+constexpr int kRangeQ = 256;                                           // sorted queries per work range
 
 template <int K>
 __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_binned_ptr,
@@ -171,49 +224,60 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
     __shared__ float4 s_pts[kStageCap];
     __shared__ uint32_t s_gstart[kStageCells + 8];
     __shared__ uint32_t s_lstart[kStageCells + 8];
+    __shared__ uint32_t s_keys[kRangeQ];
+    __shared__ int s_nt[27];
     const int lane = threadIdx.x;
     const uint32_t n_binned = *n_binned_ptr;
-    const uint32_t n_chunks = (n_binned + 63u) / 64u;
-    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const uint32_t si = c * 64u + (uint32_t)lane;
-        const bool valid = si < n_binned;
-        const uint2 e = valid ? sorted[si] : make_uint2(0u, kEmptyCell);
-        float qx = 0.f, qy = 0.f, qz = 0.f;
-        int cx = 0, cy = 0, cz = 0;
-        if (valid) {
-            const int scan = (int)(e.x / (uint32_t)max_n);
-            const float4 p = src[e.x];
-            const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
-            qx = (float)qs.x; qy = (float)qs.y; qz = (float)qs.z;
-            cx = cell_coord(qx, g.ox, g.inv_cell); cy = cell_coord(qy, g.oy, g.inv_cell); cz = cell_coord(qz, g.oz, g.inv_cell);
+    const uint32_t n_ranges = (n_binned + kRangeQ - 1) / kRangeQ;
+    for (uint32_t c = blockIdx.x; c < n_ranges; c += gridDim.x) {
+        const uint32_t base = c * kRangeQ;
+        const int n_in = (int)min((uint32_t)kRangeQ, n_binned - base);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kRangeQ / 64; ++k) {
+            const int idx = k * 64 + lane;
+            s_keys[idx] = idx < n_in ? sorted[base + idx].y : kEmptyCell;
         }
-        SortedSet<K> set;
-        set.init();
-        bool tie = false;
-        int outcome = 1;  // 0 settled, 1 needs the walk kernel, 2 needs the tree
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t cur = (uint32_t)__shfl((int)e.y, leader, 64);
-            const bool mine = valid && e.y == cur;
-            const int tz = (int)(cur / (uint32_t)(g.ntx * g.nty));
-            const int rem = (int)(cur - (uint32_t)tz * (uint32_t)(g.ntx * g.nty));
+        __syncthreads();
+        int pos = 0;
+        while (pos < n_in) {
+            const uint32_t cur = s_keys[pos];
+            int end = pos;
+            for (;;) {  // end of the run of `cur`
+                const int idx = end + lane;
+                const unsigned long long m = __ballot(idx < n_in && s_keys[idx] == cur);
+                const int nz = (~m) ? __ffsll((long long)~m) - 1 : 64;
+                end += nz;
+                if (nz < 64) break;
+            }
+            // ---- stage the candidate block of tile `cur`
+            const uint32_t lin = g.tiles[cur].tile_lin;
+            const int tz = (int)(lin / (uint32_t)(g.ntx * g.nty));
+            const int rem = (int)(lin - (uint32_t)tz * (uint32_t)(g.ntx * g.nty));
             const int ty = rem / g.ntx, tx = rem - ty * g.ntx;
-            const int bx = tx * kGridTile - 1, by = ty * kGridTile - 1, bz = tz * kGridTile - 1;
-            // ---- stage: look the block's 216 cells up (4 per lane), prefix-sum their sizes across the wave
+            if (lane < 27) {
+                const int ox = lane % 3 - 1, oy = (lane / 3) % 3 - 1, oz = lane / 9 - 1;
+                s_nt[lane] = lane == 13 ? (int)cur : tile_lookup(g, tx + ox, ty + oy, tz + oz);
+            }
+            __syncthreads();
             uint32_t cnt[4], gs[4], sum = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int id = lane * 4 + j;
                 uint2 r = make_uint2(0u, 0u);
-                if (id < kStageCells) r = cell_lookup(g, bx + id % kStageEdge, by + (id / kStageEdge) % kStageEdge, bz + id / (kStageEdge * kStageEdge));
+                if (id < kStageCells) {
+                    const int lx = id % kStageEdge, ly = (id / kStageEdge) % kStageEdge, lz = id / (kStageEdge * kStageEdge);  // 0..5 ↔ cell −1..4 of the tile
+                    const int nx_ = (lx + 3) / 4, ny_ = (ly + 3) / 4, nz_ = (lz + 3) / 4;                                       // neighbour tile 0..2
+                    const int t = s_nt[(nz_ * 3 + ny_) * 3 + nx_];
+                    if (t >= 0) r = cell_extent(g, t, (lx + 3) % 4, (ly + 3) % 4, (lz + 3) % 4);
+                }
                 gs[j] = r.x; cnt[j] = r.y; sum += r.y;
             }
             uint32_t incl = sum;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
-                if (lane >= off) incl += t;
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+                if (lane >= off) incl += v;
             }
             const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
             uint32_t run = incl - sum;
@@ -223,44 +287,47 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
                 if (id <= kStageCells) { s_lstart[id] = run; s_gstart[id] = gs[j]; }
                 run += cnt[j];
             }
+            const bool fits = total <= (uint32_t)kStageCap;
+            if (fits) {  // every lane copies the leaves of its own four cells (independent 16-byte loads)
+                uint32_t dst = incl - sum;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    for (uint32_t k = 0; k < cnt[j]; ++k) s_pts[dst + k] = g.pts[gs[j] + k];
+                    dst += cnt[j];
+                }
+            }
             __syncthreads();
-            if (total <= (uint32_t)kStageCap) {
-                // ---- copy the block's leaves into LDS: position p belongs to the cell `id` with lstart[id] <= p < lstart[id + 1]
-                for (uint32_t p = (uint32_t)lane; p < total; p += 64u) {
-                    int lo = 0, hi = kStageCells;
-#pragma unroll
-                    for (int it = 0; it < 8; ++it) {
-                        const int mid = (lo + hi) >> 1;
-                        const bool right = s_lstart[mid] <= p;
-                        lo = right ? mid : lo;
-                        hi = right ? hi : mid;
-                    }
-                    s_pts[p] = g.pts[s_gstart[lo] + (p - s_lstart[lo])];
-                }
-                __syncthreads();
-                if (mine) {
-                    const int lx = cx - bx, ly = cy - by, lz = cz - bz;  // 1..4
+            // ---- the run's queries, 64 at a time
+            for (int j = pos + lane; j < end; j += 64) {
+                const uint32_t gi = sorted[base + j].x;
+                if (!fits) { walk_list[atomicAdd(walk_count, 1u)] = gi; continue; }
+                const int scan = (int)(gi / (uint32_t)max_n);
+                const float4 p = src[gi];
+                const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
+                const float qx = (float)qs.x, qy = (float)qs.y, qz = (float)qs.z;
+                const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
+                const int lx = cx - tx * kGridTile + 1, ly = cy - ty * kGridTile + 1, lz = cz - tz * kGridTile + 1;  // 1..4
+                SortedSet<K> set;
+                set.init();
+                bool tie = false;
 #pragma unroll 1
-                    for (int r = 0; r < 9; ++r) {
-                        const int id0 = (lz + r / 3 - 1) * (kStageEdge * kStageEdge) + (ly + r % 3 - 1) * kStageEdge + (lx - 1);
-                        const uint32_t b = s_lstart[id0], en = s_lstart[id0 + 3];  // three consecutive cells along x are one run
-                        for (uint32_t pi = b; pi < en; ++pi) consider<K>(set, tie, qx, qy, qz, s_pts[pi]);
-                    }
-                    outcome = settle<K>(g, set, qx, qy, qz, cx, cy, cz, 1);
+                for (int r = 0; r < 9; ++r) {
+                    const int id0 = (lz + r / 3 - 1) * (kStageEdge * kStageEdge) + (ly + r % 3 - 1) * kStageEdge + (lx - 1);
+                    const uint32_t b = s_lstart[id0], en = s_lstart[id0 + 3];  // three consecutive cells along x are one run
+                    for (uint32_t pi = b; pi < en; ++pi) consider<K>(set, tie, qx, qy, qz, s_pts[pi]);
+                }
+                const int outcome = settle<K>(g, set, qx, qy, qz, cx, cy, cz, 1);
+                if (outcome == 0 && !tie) {
+#pragma unroll
+                    for (int jj = 0; jj < K; ++jj) nn[(size_t)jj * nn_pitch + gi] = set.id[jj];
+                } else if (outcome == 1 && !tie) {
+                    walk_list[atomicAdd(walk_count, 1u)] = gi;
+                } else {
+                    redo_list[atomicAdd(redo_count, 1u)] = gi;
                 }
             }
-            __syncthreads();  // the next tile's staging overwrites the block
-            todo &= ~__ballot(mine);
-        }
-        if (valid) {
-            if (outcome == 0 && !tie) {
-#pragma unroll
-                for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + e.x] = set.id[j];
-            } else if (outcome == 1 && !tie) {
-                walk_list[atomicAdd(walk_count, 1u)] = e.x;
-            } else {
-                redo_list[atomicAdd(redo_count, 1u)] = e.x;
-            }
+            __syncthreads();  // the next run's staging overwrites the block
+            pos = end;
         }
     }
 }
@@ -270,8 +337,9 @@ template <int K>
 __global__ __launch_bounds__(kBlock) void grid_walk_kernel(GridDev g, const float4* __restrict__ src, const PoseState* __restrict__ st,
                                                            uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, const uint32_t* __restrict__ list_in,
                                                            const unsigned int* __restrict__ n_in, uint32_t* __restrict__ list_out,
-                                                           unsigned int* __restrict__ n_out) {
+                                                           unsigned int* __restrict__ n_out, unsigned long long* __restrict__ search_stats) {
     const unsigned int n = *n_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && search_stats) atomicAdd(&search_stats[2], (unsigned long long)n);
     for (unsigned int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
         const size_t gi = list_in[r];
         const int scan = (int)(gi / (size_t)max_n);
@@ -306,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void knn_grid_query_kernel(GridDev g, const
 
 static GridDev to_dev(const GridView& v) {
     static const int max_ring2 = [] { const char* e = getenv("LOCGPU_GRID_RINGS2"); const int r = e ? atoi(e) : 6; return r < 1 ? 1 : (r > 32 ? 32 : r); }();
-    return GridDev{v.cells, v.cell_mask, v.pts, v.dims[0], v.dims[1], v.dims[2], v.tdims[0], v.tdims[1], v.tdims[2],
+    return GridDev{v.tile_hash, v.tile_mask, v.tiles, v.pts, v.dims[0], v.dims[1], v.dims[2], v.tdims[0], v.tdims[1], v.tdims[2],
                    v.origin[0], v.origin[1], v.origin[2], v.cell, v.inv_cell, v.slack, max_ring2};
 }
 
@@ -316,19 +384,19 @@ static bool search_grid_k(const GridView& grid, const GridDev& g, const SearchAr
     // work lists: redo_list2 = walk list (pass 3), redo_list = tree list (pass 4)
     (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);
     (void)hipMemsetAsync(a.redo_count2, 0, sizeof(unsigned int), s);
-    (void)hipMemsetAsync(grid.tile_count, 0, ((size_t)grid.n_tiles + 1) * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(grid.tile_count, 0, ((size_t)grid.n_tocc + 1) * sizeof(uint32_t), s);
     hipLaunchKernelGGL((grid_bin_count_kernel<K>), blocks, dim3(kBlock), 0, s, g, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.skip_nonfinite, sc.qkey,
                        grid.tile_count, a.redo_list2, a.redo_count2, a.search_stats);
     size_t tb = grid.scan_temp_bytes;
-    if (hipcub::DeviceScan::ExclusiveSum(grid.scan_temp, tb, grid.tile_count, grid.tile_count, (int)(grid.n_tiles + 1), s) != hipSuccess) return false;
+    if (hipcub::DeviceScan::ExclusiveSum(grid.scan_temp, tb, grid.tile_count, grid.tile_count, (int)(grid.n_tocc + 1), s) != hipSuccess) return false;
     hipLaunchKernelGGL(grid_bin_scatter_kernel, blocks, dim3(kBlock), 0, s, a.counts, a.st, a.max_n, sc.qkey, grid.tile_count, sc.sorted);
-    // after the scatter tile_count[t] = end of tile t; the last entry (never incremented) still holds the total
+    // after the scatter tile_count[t] = end of tile t's queries; the last entry (never incremented) still holds the total
     const size_t total_q = (size_t)a.max_n * a.n_scans;
-    const unsigned waves = (unsigned)std::min<size_t>((total_q + 63) / 64, 256u * 10u);
-    hipLaunchKernelGGL((grid_tile_search_kernel<K>), dim3(waves), dim3(64), 0, s, g, sc.sorted, grid.tile_count + grid.n_tiles, a.src, a.st, a.nn, a.nn_pitch,
+    const unsigned waves = (unsigned)std::min<size_t>((total_q + kRangeQ - 1) / kRangeQ, 256u * 10u);
+    hipLaunchKernelGGL((grid_tile_search_kernel<K>), dim3(waves), dim3(64), 0, s, g, sc.sorted, grid.tile_count + grid.n_tocc, a.src, a.st, a.nn, a.nn_pitch,
                        a.max_n, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count);
     hipLaunchKernelGGL((grid_walk_kernel<K>), dim3(1024), dim3(kBlock), 0, s, g, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.redo_list2, a.redo_count2,
-                       a.redo_list, a.redo_count);
+                       a.redo_list, a.redo_count, a.search_stats);
     return launch_icp_search_redo(a, s);  // exact tree traversal (alpha_eff = 1) for what is still open or tied
 }
 

@@ -1,10 +1,12 @@
 // loc_lib_amd/csrc/grid_kernels.hpp — the exact-search grid in HBM (LOCGPU_SEARCH_GRID_EXACT): device view, build, launchers.
 //
 // Layout (built on the device by grid_build.hip from the tree's leaves):
-//   pts    float4 {x, y, z, bits(tree leaf slot)} sorted by linear cell index (x fastest) — a cell's points are one run
-//   cells  open-addressing hash, 16 bytes per entry {cell key, start, count, -}: only occupied cells exist, so the cell edge is
-//          set by the data (≈4 leaves per occupied cell), not by the size of a dense offset array over the map's bounding box
-//   tiles  4×4×4 cells; the per-iteration query binning counts queries per tile in a dense array of n_tiles counters
+//   pts        float4 {x, y, z, bits(tree leaf slot)} sorted by (tile, cell inside the tile): a tile's leaves are one run, and so
+//              are each of its cells'
+//   tiles      one 140-byte record per OCCUPIED tile (4×4×4 cells): first leaf, and the 65 exclusive prefix sums of its cells'
+//              leaf counts — only occupied tiles exist, so the cell edge is set by the data (≈4 leaves per occupied cell), not by
+//              the size of a dense array over the map's bounding box
+//   tile_hash  open-addressing hash, tile (linear index, x fastest) → record; a few MB, L2-resident
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,26 +18,36 @@
 namespace locgpu {
 
 constexpr int kGridTile = 4;                    // cells per tile edge
+constexpr int kTileCells = kGridTile * kGridTile * kGridTile;
 constexpr uint32_t kEmptyCell = 0xFFFFFFFFu;
 
+struct TileRec {
+    uint32_t pt_start;               // first leaf of the tile in `pts`
+    uint32_t tile_lin;               // (tz·nty + ty)·ntx + tx
+    uint16_t cstart[kTileCells + 2]; // cstart[c] = leaves of the tile in cells < c (cell c = z·16 + y·4 + x); [64] = the tile's leaf count
+};
+static_assert(sizeof(TileRec) == 140, "TileRec layout");
+
 struct GridView {
-    const uint4* cells = nullptr;   // [cell_cap] hash table, key kEmptyCell = free
-    uint32_t cell_mask = 0;         // cell_cap - 1 (power of two)
-    const float4* pts = nullptr;    // leaves sorted by cell
-    int dims[3] = {0, 0, 0};        // cells per axis
-    int tdims[3] = {0, 0, 0};       // tiles per axis
+    const uint2* tile_hash = nullptr;  // [tile_mask + 1] {tile_lin, record index}; key kEmptyCell = free
+    uint32_t tile_mask = 0;
+    const TileRec* tiles = nullptr;    // [n_tocc]
+    uint32_t n_tocc = 0;               // occupied tiles
+    const float4* pts = nullptr;       // leaves sorted by (tile, cell)
+    int dims[3] = {0, 0, 0};           // cells per axis
+    int tdims[3] = {0, 0, 0};          // tiles per axis
     float origin[3] = {0, 0, 0};
     float cell = 1.f, inv_cell = 1.f, slack = 0.f;
     size_t num_points = 0, num_cells = 0, bytes = 0;
-    uint32_t n_tiles = 0;
     // per-iteration query binning (scratch owned by the context)
-    uint32_t* tile_count = nullptr;  // [n_tiles + 1]
+    uint32_t* tile_count = nullptr;  // [n_tocc + 1]
     void* scan_temp = nullptr;
     size_t scan_temp_bytes = 0;
 };
 
 struct GridBuffers {  // device allocations behind a GridView
-    uint4* cells = nullptr;
+    uint2* tile_hash = nullptr;
+    TileRec* tiles = nullptr;
     float4* pts = nullptr;
     uint32_t* tile_count = nullptr;
     void* scan_temp = nullptr;

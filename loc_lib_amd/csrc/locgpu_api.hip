@@ -893,7 +893,7 @@ int locgpu_profile_read(locgpu_ctx* ctx, double out[6], int reset) {
     return LOCGPU_OK;
 }
 
-int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[2], int reset) {
+int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset) {
     if (!ctx || !out) return LOCGPU_ERR_INVALID;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_search_stats) {
@@ -903,7 +903,7 @@ int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[2], int reset) {
     LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     unsigned long long h[16];
     LOCGPU_HIP(ctx, hipMemcpy(h, ctx->d_search_stats, sizeof(h), hipMemcpyDeviceToHost));
-    out[0] = h[0]; out[1] = h[1];
+    out[0] = h[0]; out[1] = h[1]; out[2] = getenv("LOCGPU_STAMP") ? 0 : h[2]; out[3] = 0;
     if (getenv("LOCGPU_STAMP") && h[12]) {  // diagnostic build only
         const double q = (double)h[0], w = (double)h[12];
         fprintf(stderr, "[locgpu stamp] per lane: descent %.0f cyc, total %.0f cyc, trips %.1f (visit %.1f, pop-only %.1f) | per wave (max over lanes): "
@@ -941,17 +941,21 @@ int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset) {
 }  // extern "C"
 
 // Test hook (not part of include/locgpu.h): the device-built exact-search grid of the current target, copied out so the test-suite
-// can check its invariants. info = {dims x,y,z, occupied cells, hash capacity, tiles}; params = {origin x,y,z, cell, inv_cell, slack};
-// pts: n × 4 floats (x, y, z, bits(leaf slot)) in cell order; cells: hash entries {key, start, count, -} × capacity. Returns the
-// number of grid points (0 on failure).
-extern "C" __attribute__((visibility("default"))) size_t locgpu_debug_grid_dump(locgpu_ctx* ctx, int64_t info[6], float params[6], float* pts, size_t pts_cap,
-                                                                                 uint32_t* cells, size_t cells_cap) {
+// can check its invariants. info = {dims x,y,z, occupied cells, occupied tiles, hash capacity, tile dims x,y,z};
+// params = {origin x,y,z, cell, inv_cell, slack}; pts: n × 4 floats (x, y, z, bits(leaf slot)) in (tile, cell) order; tiles: the raw
+// 140-byte TileRec records; hash: {tile_lin, record} × capacity. Returns the number of grid points (0 on failure).
+extern "C" __attribute__((visibility("default"))) size_t locgpu_debug_grid_dump(locgpu_ctx* ctx, int64_t info[9], float params[6], float* pts, size_t pts_cap,
+                                                                                 void* tiles, size_t tiles_cap_bytes, uint32_t* hash, size_t hash_cap) {
     if (!ctx || !ctx->d_tree || ensure_grid(ctx) != LOCGPU_OK) return 0;
     const locgpu::GridView& g = ctx->grid;
-    if (info) { for (int a = 0; a < 3; ++a) info[a] = g.dims[a]; info[3] = (int64_t)g.num_cells; info[4] = (int64_t)g.cell_mask + 1; info[5] = g.n_tiles; }
+    if (info) {
+        for (int a = 0; a < 3; ++a) { info[a] = g.dims[a]; info[6 + a] = g.tdims[a]; }
+        info[3] = (int64_t)g.num_cells; info[4] = g.n_tocc; info[5] = (int64_t)g.tile_mask + 1;
+    }
     if (params) { for (int a = 0; a < 3; ++a) params[a] = g.origin[a]; params[3] = g.cell; params[4] = g.inv_cell; params[5] = g.slack; }
     if (pts && hipMemcpy(pts, g.pts, std::min(pts_cap, g.num_points * 4) * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    if (cells && hipMemcpy(cells, g.cells, std::min(cells_cap, ((size_t)g.cell_mask + 1) * 4) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (tiles && hipMemcpy(tiles, g.tiles, std::min(tiles_cap_bytes, (size_t)g.n_tocc * sizeof(locgpu::TileRec)), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (hash && hipMemcpy(hash, g.tile_hash, std::min(hash_cap, ((size_t)g.tile_mask + 1) * 2) * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return g.num_points;
 }
 

@@ -285,8 +285,9 @@ def test_async_upload_double_buffer(gpu_ctx, api, small_world):
 # ----------------------------------------------------------------------------------------------- exact-search grid ingest (device)
 @pytest.mark.parametrize("case", ["city", "duplicates"])
 def test_device_grid_invariants(api, locref, synth, case):
-    """Grid ingest on the GPU (csrc/grid_build.hip): holds exactly the tree's leaves, sorted by linear cell index (x fastest), every
-    occupied cell in the hash table with the right start and count, the cell edge near the target occupancy."""
+    """Grid ingest on the GPU (csrc/grid_build.hip): holds exactly the tree's leaves, sorted by (tile, cell inside the tile); every
+    occupied tile has a record (first leaf, 65 prefix sums of its cells' counts) reachable through the tile hash; the cell edge
+    is near the target occupancy."""
     import ctypes
     rng = np.random.RandomState(11)
     if case == "city":
@@ -299,28 +300,41 @@ def test_device_grid_invariants(api, locref, synth, case):
         ctx.icp_set_target(pts)
         L = api.lib()
         L.locgpu_debug_grid_dump.restype = ctypes.c_size_t
-        L.locgpu_debug_grid_dump.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
-        info = np.zeros(6, np.int64)
+        L.locgpu_debug_grid_dump.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                             ctypes.c_void_p, ctypes.c_size_t]
+        info = np.zeros(9, np.int64)
         prm = np.zeros(6, np.float32)
-        n = L.locgpu_debug_grid_dump(ctx._h, info.ctypes.data, prm.ctypes.data, None, 0, None, 0)
+        n = L.locgpu_debug_grid_dump(ctx._h, info.ctypes.data, prm.ctypes.data, None, 0, None, 0, None, 0)
         tree = locref.KdTree(pts)
         assert n == tree.num_leaves
-        dims, n_occ, cap = info[:3], int(info[3]), int(info[4])
+        dims, n_occ, n_tocc, cap, tdims = info[:3], int(info[3]), int(info[4]), int(info[5]), info[6:9]
         gp = np.zeros((n, 4), np.float32)
-        cells = np.zeros((cap, 4), np.uint32)
-        L.locgpu_debug_grid_dump(ctx._h, info.ctypes.data, prm.ctypes.data, gp.ctypes.data, gp.size, cells.ctypes.data, cells.size)
+        rec = np.zeros(n_tocc, dtype=np.dtype([("pt_start", "<u4"), ("tile_lin", "<u4"), ("cstart", "<u2", (66,))]))
+        assert rec.dtype.itemsize == 140
+        hsh = np.zeros((cap, 2), np.uint32)
+        L.locgpu_debug_grid_dump(ctx._h, info.ctypes.data, prm.ctypes.data, gp.ctypes.data, gp.size, rec.ctypes.data, rec.nbytes, hsh.ctypes.data, hsh.size)
         c = np.floor((gp[:, :3] - prm[:3]) * prm[4]).astype(np.int64)
         assert np.all(c >= 0) and np.all(c < dims)
-        lin = (c[:, 2] * dims[1] + c[:, 1]) * dims[0] + c[:, 0]
-        assert np.all(np.diff(lin) >= 0)                                        # cell order
-        keys, starts, counts = np.unique(lin, return_index=True, return_counts=True)
-        assert len(keys) == n_occ and 1.5 <= counts.mean() <= 16.0              # the edge targets ≈4 leaves per occupied cell
-        used = cells[cells[:, 0] != 0xFFFFFFFF]
-        assert len(used) == n_occ and cap >= 2 * n_occ
+        t = c // 4
+        tile_lin = (t[:, 2] * tdims[1] + t[:, 1]) * tdims[0] + t[:, 0]
+        in_tile = ((c[:, 2] % 4) * 4 + (c[:, 1] % 4)) * 4 + (c[:, 0] % 4)
+        key = tile_lin * 64 + in_tile
+        assert np.all(np.diff(key) >= 0)                                        # (tile, cell) order
+        cells_per_pt = len(np.unique(key))
+        assert cells_per_pt == n_occ and 1.5 <= n / n_occ <= 16.0               # the edge targets ≈4 leaves per occupied cell
+        tiles, starts, counts = np.unique(tile_lin, return_index=True, return_counts=True)
+        assert len(tiles) == n_tocc and cap >= 2 * n_tocc
+        np.testing.assert_array_equal(rec["tile_lin"].astype(np.int64), tiles)
+        np.testing.assert_array_equal(rec["pt_start"].astype(np.int64), starts)
+        np.testing.assert_array_equal(rec["cstart"][:, 64].astype(np.int64), counts)
+        hist = np.zeros((n_tocc, 64), np.int64)
+        np.add.at(hist, (np.searchsorted(tiles, tile_lin), in_tile), 1)
+        want_cstart = np.concatenate([np.zeros((n_tocc, 1), np.int64), np.cumsum(hist, axis=1)], axis=1)
+        np.testing.assert_array_equal(rec["cstart"][:, :65].astype(np.int64), want_cstart)
+        used = hsh[hsh[:, 0] != 0xFFFFFFFF]
         order = np.argsort(used[:, 0])
-        np.testing.assert_array_equal(used[order, 0].astype(np.int64), keys)
-        np.testing.assert_array_equal(used[order, 1].astype(np.int64), starts)
-        np.testing.assert_array_equal(used[order, 2].astype(np.int64), counts)
+        np.testing.assert_array_equal(used[order, 0].astype(np.int64), tiles)
+        np.testing.assert_array_equal(used[order, 1].astype(np.int64), np.arange(n_tocc))
         # the points are exactly the tree's leaf points (multiset)
         _, _, pidx = tree.dump()
         xyz = np.ascontiguousarray(pts[:, :3], dtype=np.float32)
