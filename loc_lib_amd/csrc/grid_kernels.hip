@@ -12,14 +12,15 @@
 //              queries' tiles in an LDS hash, so the global counters see one atomic per distinct tile per block — hot tiles (thousands
 //              of queries) would otherwise serialise on same-address atomics.
 //   2. tiles   one-wave workgroups walk the tile-ordered query list in ranges of 256. For every run of queries of one tile the wave
-//              stages the tile's candidate block — its 6×6×6 cells (the tile and one ring): 27 tile look-ups (L2-resident hash),
-//              216 cell extents from the tile records, a wave prefix sum, then the cells' leaves streamed from the (tile, cell)-sorted
+//              stages the tile's candidate block — its 8×8×8 cells (the tile and two rings): 27 tile look-ups (L2-resident hash),
+//              512 cell extents from the tile records, a wave prefix sum, then the cells' leaves streamed from the (tile, cell)-sorted
 //              array into LDS — once, and every query of the run takes its 3×3×3 cells from LDS (9 runs: consecutive cells along
-//              x are adjacent in the staged block).
-//   3. walk    queries the 3×3×3 block did not settle (k-th distance beyond the block's nearest open face), outside every occupied
-//              tile, or in a block larger than the LDS stage: ring by ring through the tile records, one thread per query, on the
-//              compacted list.
-//   4. tree    what is still open after `max_ring2` rings, and every tie: icp_search_redo_kernel with alpha = 1.
+//              x are adjacent in the staged block) and, when the k-th distance reaches beyond that block's nearest open face, the
+//              5×5×5 shell around it.
+//   3. tree    what is still open after two rings (first-iteration queries far from every surface), outside every occupied tile,
+//              in a block larger than the LDS stage, and every tie: the fast tree traversal with alpha = 1 over the compacted list
+//              (icp_search_fast_list_kernel), then icp_search_redo_kernel for the few it hands on.
+// locgpu_knn's grid mode (plain queries, no poses) walks rings through the tile records, one thread per query.
 #include "grid_kernels.hpp"
 #include "icp_kernels.hpp"
 
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void grid_bin_count_kernel(GridDev g, const
     if (st[scan].done) return;  // uniform per block
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const size_t gi = (size_t)scan * max_n + i;
-    bool has = false;
+    bool has = false, to_tree = false, counted = false;
     uint32_t key = kEmptyCell;
     if (i < counts[scan]) {
         const float4 p = src[gi];
@@ -172,16 +173,21 @@ __global__ __launch_bounds__(kBlock) void grid_bin_count_kernel(GridDev g, const
 #pragma unroll
             for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = kInvalidSlot;
         } else {
-            if (search_stats) atomicAdd(&search_stats[0], 1ull);
+            counted = true;
             const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
             const float qx = (float)qs.x, qy = (float)qs.y, qz = (float)qs.z;
             const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
             const bool inside = qx == qx && qy == qy && qz == qz && (unsigned)cx < (unsigned)g.nx && (unsigned)cy < (unsigned)g.ny && (unsigned)cz < (unsigned)g.nz;
             const int t = inside ? tile_lookup(g, cx / kGridTile, cy / kGridTile, cz / kGridTile) : -1;
             if (t >= 0) { has = true; key = (uint32_t)t; }
-            else walk_list[atomicAdd(walk_count, 1u)] = (uint32_t)gi;  // outside every occupied tile (or NaN): the walk kernel handles it
+            else to_tree = true;  // outside every occupied tile (or NaN): the tree answers
         }
         qkey[gi] = key;
+    }
+    wave_append(walk_list, walk_count, to_tree, (uint32_t)gi);
+    if (search_stats) {  // one add per wave, only when stats were requested
+        const unsigned long long m = __ballot(counted);
+        if (m && (int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(&search_stats[0], (unsigned long long)__popcll(m));
     }
     int slot;
     uint32_t rank;
@@ -210,22 +216,23 @@ __global__ __launch_bounds__(kBlock) void grid_bin_scatter_kernel(const int* __r
 }
 
 // ------------------------------------------------------------------------------------------------ 2. tiles
-constexpr int kStageEdge = kGridTile + 2;                              // 6 cells: the tile and one ring
-constexpr int kStageCells = kStageEdge * kStageEdge * kStageEdge;      // 216
-constexpr int kStageCap = 768;                                         // leaves a staged block may hold (12 KB of LDS)
+constexpr int kStageRing = 2;                                          // rings of cells staged around the tile
+constexpr int kStageEdge = kGridTile + 2 * kStageRing;                 // 8 cells
+constexpr int kStageCells = kStageEdge * kStageEdge * kStageEdge;      // 512
+constexpr int kStageCap = 1024;                                        // leaves a staged block may hold (16 KB of LDS)
 constexpr int kRangeQ = 256;                                           // sorted queries per work range
+static_assert(kStageCells % 64 == 0 && kStageCap < 65536, "staging layout");
 
 template <int K>
 __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_binned_ptr,
                                                               const float4* __restrict__ src, const PoseState* __restrict__ st,
                                                               uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
-                                                              uint32_t* __restrict__ walk_list, unsigned int* __restrict__ walk_count,
-                                                              uint32_t* __restrict__ redo_list, unsigned int* __restrict__ redo_count) {
+                                                              uint32_t* __restrict__ tree_list, unsigned int* __restrict__ tree_count) {
     __shared__ float4 s_pts[kStageCap];
-    __shared__ uint32_t s_gstart[kStageCells + 8];
-    __shared__ uint32_t s_lstart[kStageCells + 8];
+    __shared__ uint16_t s_lstart[kStageCells + 8];
     __shared__ uint32_t s_keys[kRangeQ];
     __shared__ int s_nt[27];
+    constexpr int kPerLane = kStageCells / 64;  // 8 consecutive cells (one x-row of the block) per lane
     const int lane = threadIdx.x;
     const uint32_t n_binned = *n_binned_ptr;
     const uint32_t n_ranges = (n_binned + kRangeQ - 1) / kRangeQ;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
                 end += nz;
                 if (nz < 64) break;
             }
-            // ---- stage the candidate block of tile `cur`
+            // ---- stage the candidate block of tile `cur`: the tile's 4×4×4 cells and two rings around them
             const uint32_t lin = g.tiles[cur].tile_lin;
             const int tz = (int)(lin / (uint32_t)(g.ntx * g.nty));
             const int rem = (int)(lin - (uint32_t)tz * (uint32_t)(g.ntx * g.nty));
@@ -260,18 +267,18 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
                 s_nt[lane] = lane == 13 ? (int)cur : tile_lookup(g, tx + ox, ty + oy, tz + oz);
             }
             __syncthreads();
-            uint32_t cnt[4], gs[4], sum = 0;
+            uint32_t cnt[kPerLane], gs[kPerLane], sum = 0;
+            {
+                // lane = one x-row of the block: block cells lx = 0..7 ↔ cells −2..5 of the tile ↔ neighbour tile (lx + 2) / 4, cell (lx + 2) % 4
+                const int ly = lane % kStageEdge, lz = lane / kStageEdge;
+                const int ny_ = (ly + 2) / 4, nz_ = (lz + 2) / 4, iy = (ly + 2) % 4, iz = (lz + 2) % 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int id = lane * 4 + j;
-                uint2 r = make_uint2(0u, 0u);
-                if (id < kStageCells) {
-                    const int lx = id % kStageEdge, ly = (id / kStageEdge) % kStageEdge, lz = id / (kStageEdge * kStageEdge);  // 0..5 ↔ cell −1..4 of the tile
-                    const int nx_ = (lx + 3) / 4, ny_ = (ly + 3) / 4, nz_ = (lz + 3) / 4;                                       // neighbour tile 0..2
-                    const int t = s_nt[(nz_ * 3 + ny_) * 3 + nx_];
-                    if (t >= 0) r = cell_extent(g, t, (lx + 3) % 4, (ly + 3) % 4, (lz + 3) % 4);
+                for (int j = 0; j < kPerLane; ++j) {
+                    const int t = s_nt[(nz_ * 3 + ny_) * 3 + (j + 2) / 4];
+                    uint2 r = make_uint2(0u, 0u);
+                    if (t >= 0) r = cell_extent(g, t, (j + 2) % 4, iy, iz);
+                    gs[j] = r.x; cnt[j] = r.y; sum += r.y;
                 }
-                gs[j] = r.x; cnt[j] = r.y; sum += r.y;
             }
             uint32_t incl = sum;
 #pragma unroll
@@ -280,51 +287,69 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
                 if (lane >= off) incl += v;
             }
             const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-            uint32_t run = incl - sum;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int id = lane * 4 + j;
-                if (id <= kStageCells) { s_lstart[id] = run; s_gstart[id] = gs[j]; }
-                run += cnt[j];
-            }
             const bool fits = total <= (uint32_t)kStageCap;
-            if (fits) {  // every lane copies the leaves of its own four cells (independent 16-byte loads)
-                uint32_t dst = incl - sum;
+            if (fits) {
+                uint32_t run = incl - sum;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    for (uint32_t k = 0; k < cnt[j]; ++k) s_pts[dst + k] = g.pts[gs[j] + k];
-                    dst += cnt[j];
+                for (int j = 0; j < kPerLane; ++j) {  // every lane copies the leaves of its own eight cells (independent 16-byte loads)
+                    s_lstart[lane * kPerLane + j] = (uint16_t)run;
+                    for (uint32_t k = 0; k < cnt[j]; ++k) s_pts[run + k] = g.pts[gs[j] + k];
+                    run += cnt[j];
                 }
+                if (lane == 63) s_lstart[kStageCells] = (uint16_t)total;
             }
             __syncthreads();
             // ---- the run's queries, 64 at a time
-            for (int j = pos + lane; j < end; j += 64) {
-                const uint32_t gi = sorted[base + j].x;
-                if (!fits) { walk_list[atomicAdd(walk_count, 1u)] = gi; continue; }
-                const int scan = (int)(gi / (uint32_t)max_n);
-                const float4 p = src[gi];
-                const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
-                const float qx = (float)qs.x, qy = (float)qs.y, qz = (float)qs.z;
-                const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
-                const int lx = cx - tx * kGridTile + 1, ly = cy - ty * kGridTile + 1, lz = cz - tz * kGridTile + 1;  // 1..4
-                SortedSet<K> set;
-                set.init();
-                bool tie = false;
+            for (int j0 = pos; j0 < end; j0 += 64) {
+                const int j = j0 + lane;
+                bool to_tree = false;
+                uint32_t gi = 0;
+                if (j < end) {
+                    gi = sorted[base + j].x;
+                    to_tree = !fits;
+                }
+                if (j < end && fits) {
+                    const int scan = (int)(gi / (uint32_t)max_n);
+                    const float4 p = src[gi];
+                    const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
+                    const float qx = (float)qs.x, qy = (float)qs.y, qz = (float)qs.z;
+                    const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
+                    const int lx = cx - tx * kGridTile + kStageRing, ly = cy - ty * kGridTile + kStageRing, lz = cz - tz * kGridTile + kStageRing;  // 2..5
+                    SortedSet<K> set;
+                    set.init();
+                    bool tie = false;
 #pragma unroll 1
-                for (int r = 0; r < 9; ++r) {
-                    const int id0 = (lz + r / 3 - 1) * (kStageEdge * kStageEdge) + (ly + r % 3 - 1) * kStageEdge + (lx - 1);
-                    const uint32_t b = s_lstart[id0], en = s_lstart[id0 + 3];  // three consecutive cells along x are one run
-                    for (uint32_t pi = b; pi < en; ++pi) consider<K>(set, tie, qx, qy, qz, s_pts[pi]);
-                }
-                const int outcome = settle<K>(g, set, qx, qy, qz, cx, cy, cz, 1);
-                if (outcome == 0 && !tie) {
+                    for (int r = 0; r < 9; ++r) {  // ring 1: nine rows of three consecutive cells
+                        const int id0 = ((lz + r / 3 - 1) * kStageEdge + (ly + r % 3 - 1)) * kStageEdge + (lx - 1);
+                        const uint32_t b = s_lstart[id0], en = s_lstart[id0 + 3];
+                        for (uint32_t pi = b; pi < en; ++pi) consider<K>(set, tie, qx, qy, qz, s_pts[pi]);
+                    }
+                    int outcome = settle<K>(g, set, qx, qy, qz, cx, cy, cz, 1);
+                    if (outcome == 1) {  // ring 2: the shell of the 5×5×5 block — whole rows where |dy| or |dz| is 2, the two end cells elsewhere
+#pragma unroll 1
+                        for (int r = 0; r < 25; ++r) {
+                            const int dy = r % 5 - 2, dz = r / 5 - 2;
+                            const int row = ((lz + dz) * kStageEdge + (ly + dy)) * kStageEdge + lx;
+                            if (max(abs(dy), abs(dz)) == 2) {
+                                const uint32_t b = s_lstart[row - 2], en = s_lstart[row + 3];
+                                for (uint32_t pi = b; pi < en; ++pi) consider<K>(set, tie, qx, qy, qz, s_pts[pi]);
+                            } else {
+                                uint32_t b = s_lstart[row - 2], en = s_lstart[row - 1];
+                                for (uint32_t pi = b; pi < en; ++pi) consider<K>(set, tie, qx, qy, qz, s_pts[pi]);
+                                b = s_lstart[row + 2]; en = s_lstart[row + 3];
+                                for (uint32_t pi = b; pi < en; ++pi) consider<K>(set, tie, qx, qy, qz, s_pts[pi]);
+                            }
+                        }
+                        outcome = settle<K>(g, set, qx, qy, qz, cx, cy, cz, 2);
+                    }
+                    if (outcome == 0 && !tie) {
 #pragma unroll
-                    for (int jj = 0; jj < K; ++jj) nn[(size_t)jj * nn_pitch + gi] = set.id[jj];
-                } else if (outcome == 1 && !tie) {
-                    walk_list[atomicAdd(walk_count, 1u)] = gi;
-                } else {
-                    redo_list[atomicAdd(redo_count, 1u)] = gi;
+                        for (int jj = 0; jj < K; ++jj) nn[(size_t)jj * nn_pitch + gi] = set.id[jj];
+                    } else {
+                        to_tree = true;
+                    }
                 }
+                wave_append(tree_list, tree_count, to_tree, gi);
             }
             __syncthreads();  // the next run's staging overwrites the block
             pos = end;
@@ -332,29 +357,7 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
     }
 }
 
-// ------------------------------------------------------------------------------------------------ 3. walk
-template <int K>
-__global__ __launch_bounds__(kBlock) void grid_walk_kernel(GridDev g, const float4* __restrict__ src, const PoseState* __restrict__ st,
-                                                           uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, const uint32_t* __restrict__ list_in,
-                                                           const unsigned int* __restrict__ n_in, uint32_t* __restrict__ list_out,
-                                                           unsigned int* __restrict__ n_out, unsigned long long* __restrict__ search_stats) {
-    const unsigned int n = *n_in;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && search_stats) atomicAdd(&search_stats[2], (unsigned long long)n);
-    for (unsigned int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
-        const size_t gi = list_in[r];
-        const int scan = (int)(gi / (size_t)max_n);
-        const float4 p = src[gi];
-        const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
-        SortedSet<K> set;
-        if (grid_knn_walk<K>(g, (float)qs.x, (float)qs.y, (float)qs.z, set, g.max_ring2)) {
-            list_out[atomicAdd(n_out, 1u)] = (uint32_t)gi;
-        } else {
-#pragma unroll
-            for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = set.id[j];
-        }
-    }
-}
-
+// ------------------------------------------------------------------------------------------------ ring walk (locgpu_knn only)
 // Plain exact k-NN over given queries (locgpu_knn with LOCGPU_SEARCH_GRID_EXACT). out_idx[i*k] = -2 marks a query the caller
 // must answer with the tree kernel.
 template <int K>
@@ -381,7 +384,7 @@ static GridDev to_dev(const GridView& v) {
 template <int K>
 static bool search_grid_k(const GridView& grid, const GridDev& g, const SearchArgs& a, const GridSearchScratch& sc, hipStream_t s) {
     const dim3 blocks((a.max_n + kBlock - 1) / kBlock, a.n_scans);
-    // work lists: redo_list2 = walk list (pass 3), redo_list = tree list (pass 4)
+    // work lists: redo_list2 = queries for the fast tree traversal, redo_list = what that hands to the exact redo kernel
     (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);
     (void)hipMemsetAsync(a.redo_count2, 0, sizeof(unsigned int), s);
     (void)hipMemsetAsync(grid.tile_count, 0, ((size_t)grid.n_tocc + 1) * sizeof(uint32_t), s);
@@ -392,12 +395,10 @@ static bool search_grid_k(const GridView& grid, const GridDev& g, const SearchAr
     hipLaunchKernelGGL(grid_bin_scatter_kernel, blocks, dim3(kBlock), 0, s, a.counts, a.st, a.max_n, sc.qkey, grid.tile_count, sc.sorted);
     // after the scatter tile_count[t] = end of tile t's queries; the last entry (never incremented) still holds the total
     const size_t total_q = (size_t)a.max_n * a.n_scans;
-    const unsigned waves = (unsigned)std::min<size_t>((total_q + kRangeQ - 1) / kRangeQ, 256u * 10u);
+    const unsigned waves = (unsigned)std::min<size_t>((total_q + kRangeQ - 1) / kRangeQ, 256u * 8u);
     hipLaunchKernelGGL((grid_tile_search_kernel<K>), dim3(waves), dim3(64), 0, s, g, sc.sorted, grid.tile_count + grid.n_tocc, a.src, a.st, a.nn, a.nn_pitch,
-                       a.max_n, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count);
-    hipLaunchKernelGGL((grid_walk_kernel<K>), dim3(1024), dim3(kBlock), 0, s, g, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.redo_list2, a.redo_count2,
-                       a.redo_list, a.redo_count, a.search_stats);
-    return launch_icp_search_redo(a, s);  // exact tree traversal (alpha_eff = 1) for what is still open or tied
+                       a.max_n, a.redo_list2, a.redo_count2);
+    return launch_icp_search_list(a, a.redo_list2, a.redo_count2, s);  // a.alpha_eff = 1: exact pruning
 }
 
 bool launch_icp_search_grid(const GridView& grid, const SearchArgs& a, const GridSearchScratch& sc, hipStream_t s) {

@@ -97,6 +97,41 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
     }
 }
 
+// The fast traversal over a LIST of queries (grid mode: what the tile kernel could not settle, with alpha_eff = 1). One-wave
+// workgroups, grid-stride over the list whose length lives on the device. Queries it cannot finish go to redo_list as usual.
+template <int K, int DF>
+__global__ __launch_bounds__(64) void icp_search_fast_list_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+                                                                  const PoseState* __restrict__ st, uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
+                                                                  float alpha_eff, int T, unsigned int tree_bytes, const uint32_t* __restrict__ list,
+                                                                  const unsigned int* __restrict__ n_list, uint32_t* __restrict__ redo_list,
+                                                                  unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats) {
+    __shared__ uint2 s_stack[DF][64];
+    const unsigned int n = *n_list;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0 && search_stats) atomicAdd(&search_stats[2], (unsigned long long)n);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
+    for (unsigned int r0 = blockIdx.x * 64u; r0 < n; r0 += gridDim.x * 64u) {
+        const unsigned int r = r0 + (unsigned int)tid;
+        bool slow = false;
+        uint32_t gi = 0;
+        if (r < n) {
+            gi = list[r];
+            const int scan = (int)(gi / (uint32_t)max_n);
+            const float4 p = src[gi];
+            const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
+            const float fqx = (float)qs.x, fqy = (float)qs.y, fqz = (float)qs.z;
+            const bool sane = fabsf(fqx) < 1e18f && fabsf(fqy) < 1e18f && fabsf(fqz) < 1e18f;
+            SortedSet<K> set;
+            slow = !sane || tree_knn_fast<K, DF, 64>(rsrc, fqx, fqy, fqz, alpha_eff, T, s_stack, tid, set);
+            if (!slow) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = set.id[j];
+            }
+        }
+        wave_append(redo_list, redo_count, slow, gi);
+    }
+}
+
 // Exact recomputation of the queries the fast kernel could not finish (≈1e-6 of them on real maps: ≈30 per 256-scan launch).
 // One-wave workgroups over the list. A short list is dealt one query per WAVE (lane 0): 30 queries sharing a wave would each
 // pay the others' heap-emulation branches and the longest traversal; alone in its wave a query costs its own ≈40 dependent loads.
@@ -607,6 +642,23 @@ static bool launch_redo_k(const SearchArgs& a, hipStream_t s) {
 bool launch_icp_search_redo(const SearchArgs& a, hipStream_t s) {
     if (a.k == 1) return launch_redo_k<1>(a, s);
     if (a.k == 5) return launch_redo_k<5>(a, s);
+    return false;
+}
+
+// Fast traversal over `list` (length *n_list on the device), then the exact redo kernel for what it hands on. a.redo_count must
+// have been zeroed on the stream; a.alpha_eff is the pruning factor (1 = exact).
+template <int K>
+static bool launch_fast_list_k(const SearchArgs& a, const uint32_t* list, const unsigned int* n_list, hipStream_t s) {
+    constexpr int DF = 20;
+    const int T = a.depth > DF ? a.depth - DF : 0;
+    hipLaunchKernelGGL((icp_search_fast_list_kernel<K, DF>), dim3(4096), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.alpha_eff, T,
+                       (unsigned int)a.tree_bytes, list, n_list, a.redo_list, a.redo_count, a.search_stats);
+    return launch_redo_k<K>(a, s);
+}
+bool launch_icp_search_list(const SearchArgs& a, const uint32_t* list, const unsigned int* n_list, hipStream_t s) {
+    if (a.depth > 64) return false;
+    if (a.k == 1) return launch_fast_list_k<1>(a, list, n_list, s);
+    if (a.k == 5) return launch_fast_list_k<5>(a, list, n_list, s);
     return false;
 }
 

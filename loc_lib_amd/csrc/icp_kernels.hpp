@@ -38,6 +38,19 @@ struct GnParams {
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __uint_as_float(u); }
 
+// list[(*count)++] = value for every lane with `pred`, one atomic per wave (same-address atomics cost ≈10 ns each on gfx950: a
+// per-lane append from millions of queries serialises for milliseconds). Every active lane of the wave must reach the call.
+__device__ __forceinline__ void wave_append(uint32_t* __restrict__ list, unsigned int* __restrict__ count, bool pred, uint32_t value) {
+    const unsigned long long mask = __ballot(pred);
+    if (!mask) return;
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned int)__popcll(mask));
+    base = (unsigned int)__shfl((int)base, leader, 64);
+    if (pred) list[base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Result set: std::priority_queue<NodeAndDistance> (kdtree.h:33-39, kdtree.cpp:156-165,197-212)
 // restated as libstdc++'s __push_heap / __adjust_heap on a register-resident array. Dynamic

@@ -44,6 +44,8 @@ struct AccumArgs {
 bool launch_icp_search(const SearchArgs& a, hipStream_t s);
 // exact tree traversal over a.redo_list only (the list is filled by a preceding fast / grid kernel)
 bool launch_icp_search_redo(const SearchArgs& a, hipStream_t s);
+// fast tree traversal (a.alpha_eff) over the queries in `list`, then the exact redo kernel for what it could not finish
+bool launch_icp_search_list(const SearchArgs& a, const uint32_t* list, const unsigned int* n_list, hipStream_t s);
 bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, int k, float alpha_eff, int32_t* out, uint32_t* visits,
                       hipStream_t s);
 // returns the number of partial blocks per scan the kernel wrote (what gn_solve must sum)

@@ -504,11 +504,11 @@ bool IterLauncher::launch(int do_update) {
         SearchArgs sa{ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ctx->depth, b->d_src, b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, k, alpha_eff,
                       prm.method == LOCGPU_P2P ? 1 : 0, ctx->count_visits ? ctx->d_visits : nullptr, b->d_redo_list, b->d_redo_count,
                       b->d_redo_list2, b->d_redo_count + 1, ctx->d_search_stats};
-        const bool grid_mode = alpha_eff < 0.f;
-        if (!grid_mode && !ctx->tree_bounded) sa.redo_list = nullptr;  // huge / non-finite map coordinates: exact kernel only
+        const bool grid_mode = alpha_eff < 0.f && ctx->tree_bounded;
+        if (alpha_eff < 0.f) sa.alpha_eff = 1.0f;                       // grid mode is exact by construction (`approximate` is ignored)
+        if (!ctx->tree_bounded) sa.redo_list = nullptr;                 // huge / non-finite map coordinates: exact tree kernel only
         if (grid_mode && !b->d_redo_list2) { fail(ctx, LOCGPU_ERR_INVALID, "grid search: work list missing (ensure_grid_lists was not called)"); return false; }
         sa.redo_list2 = b->d_redo_list2;
-        if (grid_mode) sa.alpha_eff = 1.0f;  // the tree kernel that settles the grid's leftovers runs the exact pruning rule
         const GridSearchScratch gsc{b->d_grid_qkey, b->d_grid_sorted};
         const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, gsc, s) : launch_icp_search(sa, s);
         if (!ok_search) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }

@@ -41,14 +41,16 @@ def main():
     ctx.visit_count_enable(False)
     hb = ctx.icp_hb_batch(b, inits, opts)  # warm-up + correctness of the variant vs the instrumented default path
     same = bool(np.array_equal(hb, hb_ref))
-    ctx.search_stats_read(reset=True)
-    ctx.icp_hb_batch(b, inits, opts)
-    ss = ctx.search_stats_read(reset=True)
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)
     for _ in range(args.reps):
         ctx.icp_hb_batch(b, inits, opts)
     p = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+    # bookkeeping counters LAST: once requested they stay on, and their atomics distort the timing above
+    ctx.search_stats_read(reset=True)
+    ctx.icp_hb_batch(b, inits, opts)
+    ss = ctx.search_stats_read(reset=True)
     q = vc["queries"]
     k = 1 if args.method == 0 else 5
     sbytes = q * 16 + vc["nodes"] * 16 + q * 4 * k
