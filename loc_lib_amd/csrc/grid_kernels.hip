@@ -86,6 +86,53 @@ __device__ __forceinline__ void consider(SortedSet<K>& set, bool& tie, float qx,
     else if (dis2 == top && top < __builtin_inff()) tie = true;
 }
 
+// The tile kernel's result set: ascending distances in registers, updated by a branch-free insertion network — every lane of
+// a wave is at a different candidate of a different query, so a conditional insert would execute for all of them anyway and
+// pay the branch on top. Two cheap tests catch every case in which the reference's answer depends on its visit order:
+// a candidate equal to the current k-th distance, and an eviction while the two largest distances are equal; equal
+// distances that survive to the end are found by finish().
+template <int K>
+struct TopK {
+    float d[K];
+    uint32_t id[K];
+    bool tie;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < K; ++j) { d[j] = __builtin_inff(); id[j] = kInvalidSlot; }
+        tie = false;
+    }
+    __device__ __forceinline__ float top() const { return d[K - 1]; }
+    __device__ __forceinline__ void offer(float x, uint32_t w) {
+        const float t = d[K - 1];
+        tie |= (x == t) | ((x < t) & (K > 1 ? d[K > 1 ? K - 2 : 0] == t : false) & (t < __builtin_inff()));
+        float c = x;
+        uint32_t cw = w;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool sm = c < d[j];
+            const float nd = sm ? c : d[j], nc = sm ? d[j] : c;
+            const uint32_t nw = sm ? cw : id[j], ncw = sm ? id[j] : cw;
+            d[j] = nd; id[j] = nw; c = nc; cw = ncw;
+        }
+    }
+    __device__ __forceinline__ bool full() const { return d[K - 1] < __builtin_inff(); }
+    __device__ __forceinline__ bool finish() {  // true when the tree must answer
+#pragma unroll
+        for (int j = 0; j + 1 < K; ++j) tie |= (d[j] == d[j + 1]) & (d[j] < __builtin_inff());
+        return tie;
+    }
+};
+
+template <int K>
+__device__ __forceinline__ void offer_point(TopK<K>& set, float qx, float qy, float qz, const float4 p) {
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    set.offer(dx * dx + (dy * dy + dz * dz), __float_as_uint(p.w));  // Eigen squaredNorm order, no FMA (-ffp-contract=off)
+}
+
+// settle() for a TopK set: see below
+template <int K>
+__device__ __forceinline__ int settle_top(const struct GridDev& g, const TopK<K>& set, float qx, float qy, float qz, int cx, int cy, int cz, int R);
+
 // After the cells within Chebyshev distance R of (cx,cy,cz) were examined: 0 = the set is final, 1 = more rings needed,
 // 2 = every leaf was examined and fewer than K exist (the tree kernel answers like the reference does).
 template <int K>
@@ -101,6 +148,21 @@ __device__ __forceinline__ int settle(const GridDev& g, const SortedSet<K>& set,
     if (!open_face) return set.n < K ? 2 : 0;
     const float safe = dmin - g.slack;
     return (set.n == K && safe > 0.f && set.top() <= safe * safe) ? 0 : 1;
+}
+
+template <int K>
+__device__ __forceinline__ int settle_top(const GridDev& g, const TopK<K>& set, float qx, float qy, float qz, int cx, int cy, int cz, int R) {
+    float dmin = __builtin_inff();
+    bool open_face = false;
+    if (cx - R > 0) { dmin = fminf(dmin, qx - (g.ox + (float)(cx - R) * g.cell)); open_face = true; }
+    if (cx + R < g.nx - 1) { dmin = fminf(dmin, (g.ox + (float)(cx + R + 1) * g.cell) - qx); open_face = true; }
+    if (cy - R > 0) { dmin = fminf(dmin, qy - (g.oy + (float)(cy - R) * g.cell)); open_face = true; }
+    if (cy + R < g.ny - 1) { dmin = fminf(dmin, (g.oy + (float)(cy + R + 1) * g.cell) - qy); open_face = true; }
+    if (cz - R > 0) { dmin = fminf(dmin, qz - (g.oz + (float)(cz - R) * g.cell)); open_face = true; }
+    if (cz + R < g.nz - 1) { dmin = fminf(dmin, (g.oz + (float)(cz + R + 1) * g.cell) - qz); open_face = true; }
+    if (!open_face) return set.full() ? 0 : 2;
+    const float safe = dmin - g.slack;
+    return (set.full() && safe > 0.f && set.top() <= safe * safe) ? 0 : 1;
 }
 
 // Ring walk through the tile records, one thread per query. Returns true when the tree kernel must answer (tie, NaN, too far, < K leaves).
@@ -315,16 +377,24 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
                     const float qx = (float)qs.x, qy = (float)qs.y, qz = (float)qs.z;
                     const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
                     const int lx = cx - tx * kGridTile + kStageRing, ly = cy - ty * kGridTile + kStageRing, lz = cz - tz * kGridTile + kStageRing;  // 2..5
-                    SortedSet<K> set;
+                    TopK<K> set;
                     set.init();
-                    bool tie = false;
-#pragma unroll 1
-                    for (int r = 0; r < 9; ++r) {  // ring 1: nine rows of three consecutive cells
-                        const int id0 = ((lz + r / 3 - 1) * kStageEdge + (ly + r % 3 - 1)) * kStageEdge + (lx - 1);
-                        const uint32_t b = s_lstart[id0], en = s_lstart[id0 + 3];
-                        for (uint32_t pi = b; pi < en; ++pi) consider<K>(set, tie, qx, qy, qz, s_pts[pi]);
+                    {   // ring 1: nine rows of three consecutive cells, walked as ONE loop (a lane switches rows when its run ends)
+                        int r = 0;
+                        const int id00 = ((lz - 1) * kStageEdge + (ly - 1)) * kStageEdge + (lx - 1);
+                        uint32_t pi = s_lstart[id00], en = s_lstart[id00 + 3];
+                        for (;;) {
+                            while (pi == en && r < 8) {
+                                ++r;
+                                const int id0 = id00 + (r / 3) * (kStageEdge * kStageEdge) + (r % 3) * kStageEdge;
+                                pi = s_lstart[id0]; en = s_lstart[id0 + 3];
+                            }
+                            if (pi == en) break;
+                            offer_point<K>(set, qx, qy, qz, s_pts[pi]);
+                            ++pi;
+                        }
                     }
-                    int outcome = settle<K>(g, set, qx, qy, qz, cx, cy, cz, 1);
+                    int outcome = settle_top<K>(g, set, qx, qy, qz, cx, cy, cz, 1);
                     if (outcome == 1) {  // ring 2: the shell of the 5×5×5 block — whole rows where |dy| or |dz| is 2, the two end cells elsewhere
 #pragma unroll 1
                         for (int r = 0; r < 25; ++r) {
@@ -332,16 +402,17 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
                             const int row = ((lz + dz) * kStageEdge + (ly + dy)) * kStageEdge + lx;
                             if (max(abs(dy), abs(dz)) == 2) {
                                 const uint32_t b = s_lstart[row - 2], en = s_lstart[row + 3];
-                                for (uint32_t pi = b; pi < en; ++pi) consider<K>(set, tie, qx, qy, qz, s_pts[pi]);
+                                for (uint32_t pi = b; pi < en; ++pi) offer_point<K>(set, qx, qy, qz, s_pts[pi]);
                             } else {
                                 uint32_t b = s_lstart[row - 2], en = s_lstart[row - 1];
-                                for (uint32_t pi = b; pi < en; ++pi) consider<K>(set, tie, qx, qy, qz, s_pts[pi]);
+                                for (uint32_t pi = b; pi < en; ++pi) offer_point<K>(set, qx, qy, qz, s_pts[pi]);
                                 b = s_lstart[row + 2]; en = s_lstart[row + 3];
-                                for (uint32_t pi = b; pi < en; ++pi) consider<K>(set, tie, qx, qy, qz, s_pts[pi]);
+                                for (uint32_t pi = b; pi < en; ++pi) offer_point<K>(set, qx, qy, qz, s_pts[pi]);
                             }
                         }
-                        outcome = settle<K>(g, set, qx, qy, qz, cx, cy, cz, 2);
+                        outcome = settle_top<K>(g, set, qx, qy, qz, cx, cy, cz, 2);
                     }
+                    const bool tie = set.finish();
                     if (outcome == 0 && !tie) {
 #pragma unroll
                         for (int jj = 0; jj < K; ++jj) nn[(size_t)jj * nn_pitch + gi] = set.id[jj];
