@@ -289,7 +289,7 @@ template <int K>
 __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const uint2* __restrict__ sorted, const uint32_t* __restrict__ n_binned_ptr,
                                                               const float4* __restrict__ src, const PoseState* __restrict__ st,
                                                               uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
-                                                              uint32_t* __restrict__ tree_list, unsigned int* __restrict__ tree_count) {
+                                                              uint32_t* __restrict__ tree_list, unsigned int* __restrict__ tree_count, int exp_flags) {
     __shared__ float4 s_pts[kStageCap];
     __shared__ uint16_t s_lstart[kStageCells + 8];
     __shared__ uint32_t s_keys[kRangeQ];
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
 #pragma unroll
                 for (int j = 0; j < kPerLane; ++j) {  // every lane copies the leaves of its own eight cells (independent 16-byte loads)
                     s_lstart[lane * kPerLane + j] = (uint16_t)run;
-                    for (uint32_t k = 0; k < cnt[j]; ++k) s_pts[run + k] = g.pts[gs[j] + k];
+                    if (!(exp_flags & 2)) for (uint32_t k = 0; k < cnt[j]; ++k) s_pts[run + k] = g.pts[gs[j] + k];
                     run += cnt[j];
                 }
                 if (lane == 63) s_lstart[kStageCells] = (uint16_t)total;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
                     gi = sorted[base + j].x;
                     to_tree = !fits;
                 }
-                if (j < end && fits) {
+                if (j < end && fits && !(exp_flags & 1)) {
                     const int scan = (int)(gi / (uint32_t)max_n);
                     const float4 p = src[gi];
                     const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
@@ -467,8 +467,9 @@ static bool search_grid_k(const GridView& grid, const GridDev& g, const SearchAr
     // after the scatter tile_count[t] = end of tile t's queries; the last entry (never incremented) still holds the total
     const size_t total_q = (size_t)a.max_n * a.n_scans;
     const unsigned waves = (unsigned)std::min<size_t>((total_q + kRangeQ - 1) / kRangeQ, 256u * 8u);
+    static const int exp_flags = [] { const char* e = getenv("LOCGPU_GRID_EXP"); return e ? atoi(e) : 0; }();  // timing experiments only (results wrong)
     hipLaunchKernelGGL((grid_tile_search_kernel<K>), dim3(waves), dim3(64), 0, s, g, sc.sorted, grid.tile_count + grid.n_tocc, a.src, a.st, a.nn, a.nn_pitch,
-                       a.max_n, a.redo_list2, a.redo_count2);
+                       a.max_n, a.redo_list2, a.redo_count2, exp_flags);
     return launch_icp_search_list(a, a.redo_list2, a.redo_count2, s);  // a.alpha_eff = 1: exact pruning
 }
 
