@@ -113,6 +113,13 @@ LOCGPU_API int locgpu_icp_target_info(const locgpu_ctx* ctx, int64_t out[4]);
 LOCGPU_API int locgpu_knn(locgpu_ctx* ctx, const float* queries, size_t nq, int k, int approximate, float alpha, int search_mode,
                           int32_t* out_idx, uint32_t* visits);
 
+/* ---- BfnnRegistration (LocUtils/include/LocUtils/model/search_point/bfnn/bfnn.h:11-37, bfnn.cpp:14-50): the brute-force
+ * implementation of SearchPointInterface. set_target = SetTargetCloud (deep copy; false/-1 for an empty cloud); knn = FindNearstPoints
+ * for nq queries at once: out_idx nq × k original point indices in ascending float32 distance. Equal distances — an order the
+ * reference's std::sort leaves open — are ordered by index. k > cloud size is an error here (the reference reads past the end). */
+LOCGPU_API int locgpu_bfnn_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes);
+LOCGPU_API int locgpu_bfnn_knn(locgpu_ctx* ctx, const float* queries, size_t nq, int k, int32_t* out_idx);
+
 /* ---- MatchingInterface::CaculateMatrixHAndB (matching_interface.h:18-24; icp_registration.cpp:31-55): one
  * evaluation of H (6×6 row-major) and B at `pose`. *ok receives the reference's bool (false: too few effective
  * points or det(H)==0). Used by LoamRegistration (loam_registration.cpp:56,66). */

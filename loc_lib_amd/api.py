@@ -36,6 +36,7 @@ ABI_SYMBOLS = [
     "locgpu_submap_create", "locgpu_submap_destroy", "locgpu_submap_add_keyframe", "locgpu_submap_cloud", "locgpu_submap_last_keyframe",
     "locgpu_submap_info", "locgpu_cloud_loam_extract", "locgpu_loam_extract",
     "locgpu_batch_create_empty", "locgpu_batch_upload_async", "locgpu_batch_upload_wait",
+    "locgpu_bfnn_set_target", "locgpu_bfnn_knn",
     "locgpu_comm_unique_id", "locgpu_comm_init", "locgpu_comm_info", "locgpu_batch_create_sharded", "locgpu_icp_set_target_bcast",
 ]
 COMM_ID_BYTES = 128
@@ -124,6 +125,7 @@ def lib():
             "locgpu_comm_unique_id": (i32, [vp]), "locgpu_comm_init": (i32, [vp, i32, i32, vp]), "locgpu_comm_info": (i32, [vp, vp, vp]),
             "locgpu_batch_create_sharded": (i32, [vp, vp, vp, sz, i32, i32, i32, vp]),
             "locgpu_icp_set_target_bcast": (i32, [vp, vp, sz, sz, i32]),
+            "locgpu_bfnn_set_target": (i32, [vp, vp, sz, sz]), "locgpu_bfnn_knn": (i32, [vp, vp, sz, i32, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -225,6 +227,17 @@ class Context:
         self._check(lib().locgpu_knn(self._h, q.ctypes.data, q.shape[0], k, int(approximate), alpha, search_mode, out.ctypes.data,
                                      vis.ctypes.data if with_visits else None))
         return (out, vis) if with_visits else out
+
+    # ---- BfnnRegistration (brute-force SearchPointInterface)
+    def bfnn_set_target(self, cloud):
+        c = _cloud(cloud)
+        self._check(lib().locgpu_bfnn_set_target(self._h, c.ctypes.data, c.shape[0], c.strides[0]))
+
+    def bfnn_knn(self, queries, k=5):
+        q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32)[:, :3])
+        out = np.empty((q.shape[0], k), dtype=np.int32)
+        self._check(lib().locgpu_bfnn_knn(self._h, q.ctypes.data, q.shape[0], k, out.ctypes.data))
+        return out
 
     # ---- MatchingInterface::CaculateMatrixHAndB
     def icp_hb(self, src, pose, opts):

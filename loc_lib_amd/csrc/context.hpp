@@ -21,6 +21,7 @@ struct locgpu_ctx {
     // ICP target: packed KD-tree in HBM (kdtree_build.cpp layout)
     uint2* d_tree = nullptr;
     size_t tree_slots = 0, num_leaves = 0, num_nodes = 0, num_points = 0;
+    size_t tree_cap_slots = 0, leaf_cap = 0;  // capacities of d_tree / d_leaf_slots (grow-only)
     int depth = 0;
     bool tree_bounded = true;  // PackedKdTree::bounded: the fast search kernel may be used
     unsigned long long target_epoch = 0;  // bumped by every set_target: captured graphs of older targets are never replayed
@@ -30,6 +31,10 @@ struct locgpu_ctx {
     // exact-search grid over the tree's leaves (built on the device on first use of LOCGPU_SEARCH_GRID_EXACT)
     locgpu::GridView grid;
     locgpu::GridBuffers grid_buf;
+
+    // BfnnRegistration target (bfnn.hip)
+    float4* d_bfnn = nullptr;
+    size_t bfnn_n = 0;
 
     // NDT target
     NdtTable* ndt = nullptr;

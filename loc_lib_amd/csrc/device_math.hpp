@@ -281,8 +281,11 @@ __device__ __forceinline__ D3 line_direction(const D3 (&dl)[5]) {
 
 // 6×6 partial-pivot LU: determinant and (if non-zero) solution of H x = b. What Eigen's fixed-size
 // 6×6 determinant()/inverse() do (icp_registration.cpp:210,364). Runs in one thread.
-__device__ __host__ inline double lu6_det_solve(const double* H, const double* b, double* x) {
-    double a[36];
+// `work` (optional, 42 doubles): where the factorisation lives — on the device pass LDS (a local array indexed by the pivot search
+// lives in scratch memory, ≈10× the latency).
+__device__ __host__ inline double lu6_det_solve(const double* H, const double* b, double* x, double* work = nullptr) {
+    double a_local[36];
+    double* a = work ? work : a_local;
     for (int i = 0; i < 36; ++i) a[i] = H[i];
     int perm[6];
     for (int i = 0; i < 6; ++i) perm[i] = i;

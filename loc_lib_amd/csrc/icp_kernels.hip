@@ -54,13 +54,15 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
                                                                  uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, float alpha_eff, int T,
                                                                  unsigned int tree_bytes, int skip_nonfinite, uint32_t* __restrict__ redo_list,
                                                                  unsigned int* __restrict__ redo_count,
-                                                                 unsigned long long* __restrict__ search_stats) {
+                                                                 unsigned long long* __restrict__ search_stats, int lanes) {
     __shared__ uint2 s_stack[DF][BLK];
     const int scan = blockIdx.y;
     if (st[scan].done) return;
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * BLK + tid;
-    if (i >= counts[scan]) return;
+    // `lanes` < BLK: a small launch (one scan) spread over twice as many, half-filled waves — it cannot fill the chip anyway, and
+    // a wave's time is the longest traversal among its lanes
+    const int i = blockIdx.x * lanes + tid;
+    if (tid >= lanes || i >= counts[scan]) return;
     const size_t gi = (size_t)scan * max_n + i;
     const float4 p = src[gi];
     if (skip_nonfinite && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {  // pcl::isFinite, icp cpp:64 (P2P only)
@@ -420,9 +422,13 @@ __global__ __launch_bounds__(kBlock) void icp_line_accum_kernel(const uint2* __r
 // reference's checks and update (icp_registration.cpp:204-211 + 362-375; ndt_registration.cpp:435-459).
 // hb_out (optional): per scan 44 doubles = H (36, row-major), B (6), effective_num, ok.
 __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restrict__ partials, int blocks_per_scan, PoseState* __restrict__ st,
-                                                          GnParams prm, int do_update, double* __restrict__ hb_out) {
+                                                          GnParams prm, int do_update, double* __restrict__ hb_out, unsigned int* __restrict__ list_counts) {
     __shared__ double s_sum[kBlock / kAccW][kAccW];
+    __shared__ double s_lu[36 + 6];
     const int scan = blockIdx.x;
+    // The search stage's work-list counters (fast kernel → redo kernel) are consumed by now: zero them for the next iteration's
+    // search instead of paying two fill launches per iteration (a single-scan alignment is launch-latency bound).
+    if (list_counts && scan == 0 && threadIdx.x < 2) list_counts[threadIdx.x] = 0u;
     if (st[scan].done) return;
     const int col = threadIdx.x & (kAccW - 1), chunk = threadIdx.x / kAccW;
     constexpr int kChunks = kBlock / kAccW;
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restri
     const long long eff = (long long)tot[27];
     PoseState& ps = st[scan];
     bool ok;
-    const double det = lu6_det_solve(H, B, dx);
+    const double det = lu6_det_solve(H, B, dx, s_lu);  // LU workspace in LDS: its pivoting indexes rows dynamically
     if (prm.method == 3) {
         // direct NDT: det(H)==0 is tested FIRST and aborts the whole alignment (ndt cpp:435-436)
         if (det == 0.0) {
@@ -580,34 +586,36 @@ static int fast_stack_depth() {
 template <int K, int D, int DF>
 static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
     const int T = a.depth > DF ? a.depth - DF : 0;  // leading stack positions the fast kernel does not store
-    (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);
+    // a.redo_count is zero here: the caller clears it before an alignment's first iteration, gn_solve_kernel after every search
     static const bool stamp = [] { const char* e = getenv("LOCGPU_STAMP"); return e && atoi(e) != 0; }();
     if (stamp) {  // diagnostic build of the default shape; results unchanged, timing meaningless
         dim3 g2((a.max_n + 63) / 64, a.n_scans);
         hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 64, true>), g2, dim3(64), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
+                           a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats, 64);
         hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                            a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
         return;
     }
     static const int blk = [] { const char* e = getenv("LOCGPU_FAST_BLOCK"); const int v = e ? atoi(e) : 64; return (v == 256 || v == 128) ? v : 64; }();
-    (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);
     if (blk != 256) {
-        dim3 g2((a.max_n + blk - 1) / blk, a.n_scans);
         static const int lds_pad = [] { const char* e = getenv("LOCGPU_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiment: extra dynamic LDS lowers occupancy
+        static const int small_lanes = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); const int v = e ? atoi(e) : 32; return (v == 16 || v == 32) ? v : 64; }();
+        // fewer than 2048 full waves (one or two scans): half-filled waves, see the kernel
+        const int lanes = (blk == 64 && (size_t)((a.max_n + 63) / 64) * a.n_scans <= 2048) ? small_lanes : blk;
+        dim3 g2((a.max_n + lanes - 1) / lanes, a.n_scans);
         if (blk == 64)
             hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 64>), g2, dim3(64), lds_pad, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                               a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
+                               a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats, lanes);
         else
             hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 128>), g2, dim3(128), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                               a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
+                               a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats, 128);
         hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                            a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
         return;
     }
     dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
     hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, kBlock>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                       a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
+                       a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats, kBlock);
     hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                        a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
 }
@@ -711,8 +719,8 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
 }
 
 void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
-                     hipStream_t s) {
-    hipLaunchKernelGGL(gn_solve_kernel, dim3(n_scans), dim3(kBlock), 0, s, partials, blocks_per_scan, st, prm, do_update, hb_out);
+                     unsigned int* list_counts, hipStream_t s) {
+    hipLaunchKernelGGL(gn_solve_kernel, dim3(n_scans), dim3(kBlock), 0, s, partials, blocks_per_scan, st, prm, do_update, hb_out, list_counts);
 }
 
 void launch_sum_partials(const double* partials, int blocks_per_scan, const PoseState* st_all, int first, int n_local, int n_total, double* acc,

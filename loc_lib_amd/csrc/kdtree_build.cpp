@@ -20,15 +20,28 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 namespace locgpu {
 namespace {
 
+struct Local {  // per-task counters (shared atomics on every leaf cost more than the build itself on small maps)
+    int64_t leaves = 0;
+    int depth = 0;
+};
+
 struct Builder {
     const float* pts;  // packed xyz, 3 floats per point
     std::atomic<int64_t> leaves{0};
     std::atomic<int> depth{0};
+    void merge(const Local& l) {
+        leaves.fetch_add(l.leaves, std::memory_order_relaxed);
+        int d = depth.load(std::memory_order_relaxed);
+        while (l.depth > d && !depth.compare_exchange_weak(d, l.depth, std::memory_order_relaxed)) {}
+    }
 
     // Split [idx, idx+len) the way FindSplitAxisAndThresh does. Returns false for the degenerate case.
     bool split(int32_t* idx, int32_t* tmp, size_t len, int& axis, float& th, size_t& n_left) const {
@@ -63,13 +76,13 @@ struct Builder {
         return !(nl == 0 || nr == 0);
     }
 
-    void emit_leaf(std::vector<uint64_t>& out, int32_t id) {
+    void emit_leaf(std::vector<uint64_t>& out, int32_t id, Local& loc) {
         const float* p = pts + 3 * (size_t)id;
         uint32_t xb, yb, zb;
         std::memcpy(&xb, p, 4); std::memcpy(&yb, p + 1, 4); std::memcpy(&zb, p + 2, 4);
         out.push_back((uint64_t)xb | ((uint64_t)((3u << 30) | (uint32_t)id) << 32));
         out.push_back((uint64_t)yb | ((uint64_t)zb << 32));
-        leaves.fetch_add(1, std::memory_order_relaxed);
+        loc.leaves++;
     }
 
     void note_depth(int level) {
@@ -78,33 +91,117 @@ struct Builder {
     }
 
     // Recursive build of one sub-tree into `out` (slot indices relative to out's start).
-    void build(int32_t* idx, int32_t* tmp, size_t len, int level, std::vector<uint64_t>& out) {
-        note_depth(level);
-        if (len == 1) { emit_leaf(out, idx[0]); return; }
+    void build(int32_t* idx, int32_t* tmp, size_t len, int level, std::vector<uint64_t>& out, Local& loc) {
+        if (level > loc.depth) loc.depth = level;
+        if (len == 1) { emit_leaf(out, idx[0], loc); return; }
         const int32_t first = idx[0];  // points[0] before the partition reorders nothing: stable ⇒ idx[0] stays first of its side
         int axis; float th; size_t nl;
-        if (!split(idx, tmp, len, axis, th, nl)) { emit_leaf(out, first); return; }
+        if (!split(idx, tmp, len, axis, th, nl)) { emit_leaf(out, first, loc); return; }
         const size_t pos = out.size();
         out.push_back(0);
-        build(idx, tmp, nl, level + 1, out);
+        build(idx, tmp, nl, level + 1, out, loc);
         const size_t right = out.size();
         uint32_t tb; std::memcpy(&tb, &th, 4);
         out[pos] = (uint64_t)tb | ((uint64_t)(((uint32_t)axis << 30) | (uint32_t)right) << 32);
-        build(idx + nl, tmp + nl, len - nl, level + 1, out);
+        build(idx + nl, tmp + nl, len - nl, level + 1, out, loc);
     }
 };
 
-struct Piece {  // a node of the serially built top of the tree, or a deferred sub-tree task
+struct Piece {  // a node of the level-parallel top of the tree, or a deferred sub-tree task
     bool is_task = false;
     bool is_leaf = false;
     int32_t leaf_id = 0;
     int axis = 0;
     float th = 0.f;
     int left = -1, right = -1;  // piece indices
-    size_t off = 0, len = 0;    // task: range in idx
+    size_t off = 0, len = 0;    // range in idx
     int level = 0;
     std::vector<uint64_t> slots;  // task output
+    size_t n_slots = 0, n_leaves = 0;  // size of this piece's sub-tree output (filled bottom-up)
+    size_t pos = 0, leaf_pos = 0;      // where it starts in the packed tree / in the leaf list
+    bool bounded = true;
 };
+
+// A small persistent pool: target ingest is called once per keyframe by the streaming front-end (≈35 k points), where spawning
+// threads per call would cost more than the build. run(n, fn) calls fn(i) for i in [0, n) on the pool and the caller's thread.
+class Pool {
+public:
+    static Pool& get() { static Pool p; return p; }
+    unsigned size() const { return (unsigned)workers_.size() + 1; }
+    template <class F> void run(size_t n, F&& fn) {
+        if (n == 0) return;
+        if (n == 1 || workers_.empty()) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+        std::lock_guard<std::mutex> serial(run_mu_);  // one parallel region at a time (several contexts may ingest concurrently)
+        std::function<void(size_t)> f = fn;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &f; n_ = n; next_.store(0); pending_ = workers_.size(); ++gen_;
+        }
+        cv_.notify_all();
+        for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) f(i);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    Pool() {
+        unsigned nt = std::thread::hardware_concurrency();
+        if (nt == 0) nt = 4;
+        if (nt > 48) nt = 48;
+        for (unsigned t = 1; t < nt; ++t) workers_.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::function<void(size_t)>* f;
+            size_t n;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                f = fn_; n = n_;
+            }
+            for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*f)(i);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_cv_;
+    std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_ = 0, pending_ = 0;
+    std::atomic<size_t> next_{0};
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
+
+inline bool slot_floats_bounded(const uint64_t* s, size_t n) {
+    for (size_t i = 0; i < n;) {
+        const uint32_t meta = (uint32_t)(s[i] >> 32);
+        const bool leaf = (meta >> 30) == 3u;
+        float f[3];
+        const uint32_t w0 = (uint32_t)s[i];
+        std::memcpy(&f[0], &w0, 4);
+        int nf = 1;
+        if (leaf) {
+            const uint32_t w1 = (uint32_t)s[i + 1], w2 = (uint32_t)(s[i + 1] >> 32);
+            std::memcpy(&f[1], &w1, 4); std::memcpy(&f[2], &w2, 4);
+            nf = 3;
+        }
+        for (int k = 0; k < nf; ++k)
+            if (!(std::fabs(f[k]) < 1e18f)) return false;
+        i += leaf ? 2 : 1;
+    }
+    return true;
+}
 
 }  // namespace
 
@@ -118,131 +215,127 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
     std::vector<int32_t> idx(n), tmp(n);
     for (size_t i = 0; i < n; ++i) idx[i] = (int32_t)i;
 
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 4;
-    if (nt > 64) nt = 64;
-    const size_t task_len = std::max<size_t>(n / (8 * (size_t)nt), 4096);
+    Pool& pool = Pool::get();
+    const unsigned nt = pool.size();
+    const size_t task_len = std::max<size_t>(n / (4 * (size_t)nt), 2048);
 
-    // Top of the tree, serially (each node still sums in index order); sub-trees below task_len become tasks.
-    std::vector<Piece> pieces;
-    pieces.reserve(64 * nt + 64);
-    struct Frame { int piece; size_t off, len; int level; };
-    std::vector<Frame> todo;
-    pieces.emplace_back();
-    todo.push_back({0, 0, n, 1});
-    while (!todo.empty()) {
-        const Frame f = todo.back();
-        todo.pop_back();
-        Piece& p = pieces[f.piece];
-        p.level = f.level;
-        if (f.len <= task_len) { p.is_task = true; p.off = f.off; p.len = f.len; continue; }
-        b.note_depth(f.level);
-        const int32_t first = idx[f.off];
-        int axis; float th; size_t nl;
-        if (!b.split(idx.data() + f.off, tmp.data() + f.off, f.len, axis, th, nl)) {
-            p.is_leaf = true; p.leaf_id = first;
-            continue;
+    // Top of the tree, level by level: the nodes of one level are independent, so they are split in parallel (each node still
+    // sums its points sequentially in index order — math_utils.h:40-45); sub-trees of at most task_len points become tasks.
+    std::vector<Piece> pieces(1);
+    pieces.reserve(16 * (n / task_len + 2));
+    pieces[0].off = 0; pieces[0].len = n; pieces[0].level = 1;
+    std::vector<int> frontier{0}, tasks;
+    while (!frontier.empty()) {
+        std::vector<int> split_now;
+        for (int pi : frontier) {
+            if (pieces[pi].len <= task_len) { pieces[pi].is_task = true; tasks.push_back(pi); }
+            else split_now.push_back(pi);
         }
-        p.axis = axis; p.th = th;
-        const int li = (int)pieces.size();
-        pieces.emplace_back();
-        pieces.emplace_back();
-        pieces[f.piece].left = li;  // (re-index: emplace_back may have moved `p`)
-        pieces[f.piece].right = li + 1;
-        todo.push_back({li + 1, f.off + nl, f.len - nl, f.level + 1});
-        todo.push_back({li, f.off, nl, f.level + 1});
+        const size_t base = pieces.size();
+        pieces.resize(base + 2 * split_now.size());  // two child slots per node, reserved before the parallel region
+        pool.run(split_now.size(), [&](size_t k) {
+            Piece& p = pieces[split_now[k]];
+            b.note_depth(p.level);
+            const int32_t first = idx[p.off];
+            int axis; float th; size_t nl;
+            if (!b.split(idx.data() + p.off, tmp.data() + p.off, p.len, axis, th, nl)) {
+                p.is_leaf = true; p.leaf_id = first;
+                return;
+            }
+            p.axis = axis; p.th = th;
+            p.left = (int)(base + 2 * k); p.right = p.left + 1;
+            Piece& l = pieces[p.left];
+            Piece& r = pieces[p.right];
+            l.off = p.off; l.len = nl; l.level = p.level + 1;
+            r.off = p.off + nl; r.len = p.len - nl; r.level = p.level + 1;
+        });
+        frontier.clear();
+        for (int pi : split_now)
+            if (!pieces[pi].is_leaf) { frontier.push_back(pieces[pi].left); frontier.push_back(pieces[pi].right); }
     }
 
-    // Run the tasks.
-    std::vector<int> tasks;
-    for (size_t i = 0; i < pieces.size(); ++i) if (pieces[i].is_task) tasks.push_back((int)i);
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-        for (;;) {
-            const size_t t = next.fetch_add(1);
-            if (t >= tasks.size()) break;
-            Piece& p = pieces[tasks[t]];
-            p.slots.reserve(3 * p.len);
-            b.build(idx.data() + p.off, tmp.data() + p.off, p.len, p.level, p.slots);
-        }
-    };
-    std::vector<std::thread> th;
-    const unsigned nthreads = (unsigned)std::min<size_t>(nt, tasks.size());
-    for (unsigned t = 1; t < nthreads; ++t) th.emplace_back(worker);
-    worker();
-    for (auto& t : th) t.join();
+    // The tasks, largest first.
+    std::sort(tasks.begin(), tasks.end(), [&](int a, int c) { return pieces[a].len > pieces[c].len; });
+    pool.run(tasks.size(), [&](size_t t) {
+        Piece& p = pieces[tasks[t]];
+        p.slots.reserve(3 * p.len);
+        Local loc;
+        b.build(idx.data() + p.off, tmp.data() + p.off, p.len, p.level, p.slots, loc);
+        b.merge(loc);
+        p.n_slots = p.slots.size();
+        p.n_leaves = (size_t)loc.leaves;
+        p.bounded = slot_floats_bounded(p.slots.data(), p.slots.size());
+    });
 
-    // Assemble in preorder; right-child indices inside task outputs are rebased by the task's base slot.
-    size_t total = 0;
-    for (const Piece& p : pieces) total += p.is_task ? p.slots.size() : (p.is_leaf ? 2 : 1);
-    out.slots.resize(total);
-    struct AFrame { int piece; };
-    std::vector<int> stack{0};
-    size_t pos = 0;
-    std::vector<std::pair<size_t, int>> pending_right;  // (slot position of internal node, right piece) resolved when reached
-    std::vector<size_t> piece_pos(pieces.size(), 0);
-    while (!stack.empty()) {
-        const int pi = stack.back();
-        stack.pop_back();
-        Piece& p = pieces[pi];
-        piece_pos[pi] = pos;
-        if (p.is_task) {
-            const size_t base = pos;
-            for (size_t i = 0; i < p.slots.size(); ++i) {
-                uint64_t s = p.slots[i];
-                const uint32_t meta = (uint32_t)(s >> 32);
-                if ((meta >> 30) != 3u) {
-                    const uint32_t rebased = (meta & 0x3FFFFFFFu) + (uint32_t)base;
-                    s = (s & 0xFFFFFFFFull) | ((uint64_t)((meta & 0xC0000000u) | rebased) << 32);
-                    out.slots[pos++] = s;
-                } else {
-                    out.slots[pos++] = s;
-                    out.slots[pos++] = p.slots[++i];  // second leaf slot {y,z}: raw floats, never rebased
-                }
-            }
-            std::vector<uint64_t>().swap(p.slots);
-        } else if (p.is_leaf) {
-            std::vector<uint64_t> two;
-            b.emit_leaf(two, p.leaf_id);
-            out.slots[pos++] = two[0];
-            out.slots[pos++] = two[1];
-        } else {
-            pos++;  // patched once the right child's position is known
+    // Sizes bottom-up (children have larger indices than their parent), then positions in preorder.
+    for (size_t i = pieces.size(); i-- > 0;) {
+        Piece& p = pieces[i];
+        if (p.is_task) continue;
+        if (p.is_leaf) { p.n_slots = 2; p.n_leaves = 1; }
+        else if (p.left >= 0) { p.n_slots = 1 + pieces[p.left].n_slots + pieces[p.right].n_slots; p.n_leaves = pieces[p.left].n_leaves + pieces[p.right].n_leaves; }
+    }
+    {
+        std::vector<int> stack{0};
+        pieces[0].pos = 0; pieces[0].leaf_pos = 0;
+        while (!stack.empty()) {
+            const Piece& p = pieces[stack.back()];
+            stack.pop_back();
+            if (p.is_task || p.is_leaf) continue;
+            Piece& l = pieces[p.left];
+            Piece& r = pieces[p.right];
+            l.pos = p.pos + 1; l.leaf_pos = p.leaf_pos;
+            r.pos = l.pos + l.n_slots; r.leaf_pos = l.leaf_pos + l.n_leaves;
             stack.push_back(p.right);
             stack.push_back(p.left);
         }
     }
-    for (size_t i = 0; i < pieces.size(); ++i) {
-        const Piece& p = pieces[i];
-        if (p.is_task || p.is_leaf) continue;
-        uint32_t tb; std::memcpy(&tb, &p.th, 4);
-        out.slots[piece_pos[i]] = (uint64_t)tb | ((uint64_t)(((uint32_t)p.axis << 30) | (uint32_t)piece_pos[p.right]) << 32);
-    }
+    const size_t total = pieces[0].n_slots;
+    out.slots.resize(total);
+    out.leaf_slots.resize(pieces[0].n_leaves);
+    std::atomic<bool> bounded{true};
+    // Assemble: task outputs are copied (right-child indices rebased by the task's position) in parallel; top nodes are single slots.
+    pool.run(pieces.size(), [&](size_t i) {
+        Piece& p = pieces[i];
+        if (p.is_task) {
+            const size_t base = p.pos;
+            size_t lp = p.leaf_pos;
+            for (size_t k = 0; k < p.slots.size(); ++k) {
+                uint64_t sl = p.slots[k];
+                const uint32_t meta = (uint32_t)(sl >> 32);
+                if ((meta >> 30) != 3u) {
+                    const uint32_t rebased = (meta & 0x3FFFFFFFu) + (uint32_t)base;
+                    out.slots[base + k] = (sl & 0xFFFFFFFFull) | ((uint64_t)((meta & 0xC0000000u) | rebased) << 32);
+                } else {
+                    out.slots[base + k] = sl;
+                    out.leaf_slots[lp++] = (uint32_t)(base + k);
+                    out.slots[base + k + 1] = p.slots[k + 1];  // second leaf slot {y,z}: raw floats, never rebased
+                    ++k;
+                }
+            }
+            if (!p.bounded) bounded.store(false);
+            std::vector<uint64_t>().swap(p.slots);
+        } else if (p.is_leaf) {
+            std::vector<uint64_t> two;
+            Local loc;
+            b.emit_leaf(two, p.leaf_id, loc);
+            b.merge(loc);
+            out.slots[p.pos] = two[0];
+            out.slots[p.pos + 1] = two[1];
+            out.leaf_slots[p.leaf_pos] = (uint32_t)p.pos;
+            if (!slot_floats_bounded(two.data(), 2)) bounded.store(false);
+        } else if (p.left >= 0) {
+            uint32_t tb; std::memcpy(&tb, &p.th, 4);
+            out.slots[p.pos] = (uint64_t)tb | ((uint64_t)(((uint32_t)p.axis << 30) | (uint32_t)pieces[p.right].pos) << 32);
+            if (!(std::fabs(p.th) < 1e18f)) bounded.store(false);
+        }
+    });
     out.num_leaves = (size_t)b.leaves.load();
     out.num_nodes = total - out.num_leaves;  // internal (1 slot) + leaves (2 slots) ⇒ nodes = slots − leaves
     out.depth = b.depth.load();
     out.num_points = n;
     // The fast search kernel assumes squared distances cannot overflow or be NaN: true when every float in the tree (leaf
     // coordinates and split thresholds) is finite and small enough. Otherwise searches use the exact kernel only.
-    out.bounded = true;
-    out.leaf_slots.reserve(out.num_leaves);
-    for (size_t i = 0; i < out.slots.size();) {
-        const uint32_t meta = (uint32_t)(out.slots[i] >> 32);
-        const bool leaf = (meta >> 30) == 3u;
-        if (leaf) out.leaf_slots.push_back((uint32_t)i);
-        float f[3];
-        const uint32_t w0 = (uint32_t)out.slots[i];
-        std::memcpy(&f[0], &w0, 4);
-        int nf = 1;
-        if (leaf) {
-            const uint32_t w1 = (uint32_t)out.slots[i + 1], w2 = (uint32_t)(out.slots[i + 1] >> 32);
-            std::memcpy(&f[1], &w1, 4); std::memcpy(&f[2], &w2, 4);
-            nf = 3;
-        }
-        for (int k = 0; k < nf; ++k)
-            if (!(std::fabs(f[k]) < 1e18f)) out.bounded = false;
-        i += leaf ? 2 : 1;
-    }
+    out.bounded = bounded.load();
     return true;
 }
 

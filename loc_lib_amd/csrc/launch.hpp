@@ -50,8 +50,9 @@ bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, i
                       hipStream_t s);
 // returns the number of partial blocks per scan the kernel wrote (what gn_solve must sum)
 int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s);
+// list_counts (optional): the two search work-list counters, zeroed for the next iteration
 void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
-                     hipStream_t s);
+                     unsigned int* list_counts, hipStream_t s);
 // Sharded batches: acc[g][0..28) = sum of the block partials of global scan g when this rank holds it (local index g - first),
 // zeros otherwise — in exactly the order gn_solve_kernel sums them, so that all-reduce(acc) followed by gn_solve on acc
 // (blocks_per_scan = 1) gives bit for bit the single-GPU result.

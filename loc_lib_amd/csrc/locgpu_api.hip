@@ -148,6 +148,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     if (ctx->comm) { (void)ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
     if (ctx->d_tree) (void)hipFree(ctx->d_tree);
     if (ctx->d_leaf_slots) (void)hipFree(ctx->d_leaf_slots);
+    if (ctx->d_bfnn) (void)hipFree(ctx->d_bfnn);
     free_grid(ctx);
     if (ctx->d_visits) (void)hipFree(ctx->d_visits);
     if (ctx->d_search_stats) (void)hipFree(ctx->d_search_stats);
@@ -175,15 +176,25 @@ static int build_host_tree(locgpu_ctx* ctx, const void* pts, size_t n, size_t st
     return LOCGPU_OK;
 }
 
-// meta = {slots, leaves, nodes, points, depth, bounded}; (re)allocates the device tree.
+// meta = {slots, leaves, nodes, points, depth, bounded}. The device buffers only ever grow: a streaming front-end re-ingests its
+// local map every keyframe (lio.cpp:296-305) and must not pay a hipMalloc/hipFree pair (≈100 µs each) per ingest.
 static int install_tree_meta(locgpu_ctx* ctx, const long long meta[6]) {
-    if (ctx->d_tree) { LOCGPU_HIP(ctx, hipFree(ctx->d_tree)); ctx->d_tree = nullptr; }
-    if (ctx->d_leaf_slots) { LOCGPU_HIP(ctx, hipFree(ctx->d_leaf_slots)); ctx->d_leaf_slots = nullptr; }
     free_grid(ctx);
-    LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_tree, (size_t)meta[0] * sizeof(uint64_t)));
-    LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_leaf_slots, (size_t)meta[1] * sizeof(uint32_t)));
-    ctx->tree_slots = (size_t)meta[0];
-    ctx->num_leaves = (size_t)meta[1];
+    const size_t slots = (size_t)meta[0], leaves = (size_t)meta[1];
+    if (slots > ctx->tree_cap_slots) {
+        if (ctx->d_tree) { LOCGPU_HIP(ctx, hipFree(ctx->d_tree)); ctx->d_tree = nullptr; ctx->tree_cap_slots = 0; }
+        const size_t cap = slots + slots / 4 + 1024;
+        LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_tree, cap * sizeof(uint64_t)));
+        ctx->tree_cap_slots = cap;
+    }
+    if (leaves > ctx->leaf_cap) {
+        if (ctx->d_leaf_slots) { LOCGPU_HIP(ctx, hipFree(ctx->d_leaf_slots)); ctx->d_leaf_slots = nullptr; ctx->leaf_cap = 0; }
+        const size_t cap = leaves + leaves / 4 + 1024;
+        LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_leaf_slots, cap * sizeof(uint32_t)));
+        ctx->leaf_cap = cap;
+    }
+    ctx->tree_slots = slots;
+    ctx->num_leaves = leaves;
     ctx->num_nodes = (size_t)meta[2];
     ctx->num_points = (size_t)meta[3];
     ctx->depth = (int)meta[4];
@@ -350,7 +361,8 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, 2 * sizeof(unsigned int)), "hipMalloc redo") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_total * sizeof(PoseState)), "hipHostMalloc state") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_total * 44 * sizeof(double)), "hipHostMalloc hb") &&
-              hip_ok(ctx, hipMemset(b->d_counts, 0, n_scans * sizeof(int)), "hipMemset counts");
+              hip_ok(ctx, hipMemset(b->d_counts, 0, n_scans * sizeof(int)), "hipMemset counts") &&
+              hip_ok(ctx, hipMemset(b->d_redo_count, 0, 2 * sizeof(unsigned int)), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
     if (!ok) { free_batch(b); return LOCGPU_ERR_OOM; }
     *out = b;
     return LOCGPU_OK;
@@ -534,9 +546,9 @@ bool IterLauncher::launch(int do_update) {
             const ncclResult_t nr = ncclAllReduce(b->d_acc, b->d_acc, (size_t)b->n_total * kAccW, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
             if (nr != ncclSuccess) { fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(nr)); return false; }
         }
-        launch_gn_solve(b->d_acc, 1, b->d_state, b->n_total, prm, do_update, b->d_hb, s);
+        launch_gn_solve(b->d_acc, 1, b->d_state, b->n_total, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s);
     } else {
-        launch_gn_solve(b->d_partials, n_partial_blocks, b->d_state, b->n_scans, prm, do_update, b->d_hb, s);
+        launch_gn_solve(b->d_partials, n_partial_blocks, b->d_state, b->n_scans, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s);
     }
     mark();
     return hip_ok(ctx, hipGetLastError(), "kernel launch");

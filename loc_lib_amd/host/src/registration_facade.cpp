@@ -15,6 +15,7 @@
 #include "LocUtils/model/matching/3d/loam/loam_registration.hpp"
 #include "LocUtils/model/matching/3d/ndt/ndt_registration.hpp"
 #include "LocUtils/model/search_point/kdtree/kdtree.h"
+#include "LocUtils/model/search_point/bfnn/bfnn.h"
 
 namespace LocUtils {
 
@@ -216,5 +217,29 @@ std::vector<int> KdtreeRegistration::FindNearstPoints(const Vec3f& point, int k)
 
 void KdtreeRegistration::FindCloud(const CloudPtr&, std::vector<std::pair<size_t, size_t>>&) {}
 void KdtreeRegistration::SetEnableANN(bool use_ann, float alpha) { approximate_ = use_ann; alpha_ = alpha; }
+
+// ------------------------------------------------------------------------------------------------ BfnnRegistration (bfnn.cpp:7-50)
+BfnnRegistration::BfnnRegistration(bool) {}
+BfnnRegistration::~BfnnRegistration() { locgpu_destroy(ctx_); }
+
+bool BfnnRegistration::SetTargetCloud(const CloudPtr& cloud) {
+    if (!cloud || cloud->points.empty()) return false;  // bfnn.cpp:16-19
+    if (!ctx_ && locgpu_create(0, &ctx_) != LOCGPU_OK) return false;
+    return locgpu_bfnn_set_target(ctx_, cloud->points.data(), cloud->points.size(), sizeof(PointType)) == LOCGPU_OK;
+}
+
+bool BfnnRegistration::FindNearstPointsBatch(const float* xyz, size_t n, int k, std::vector<int>& out) {
+    out.assign(n * (size_t)k, -1);
+    return ctx_ && locgpu_bfnn_knn(ctx_, xyz, n, k, out.data()) == LOCGPU_OK;
+}
+
+std::vector<int> BfnnRegistration::FindNearstPoints(const Vec3f& point, int k) {
+    const float q[3] = {point[0], point[1], point[2]};
+    std::vector<int> out;
+    if (!FindNearstPointsBatch(q, 1, k, out)) out.clear();
+    return out;
+}
+
+void BfnnRegistration::FindCloud(const CloudPtr&, std::vector<std::pair<size_t, size_t>>&) {}
 
 }  // namespace LocUtils

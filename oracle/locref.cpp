@@ -23,11 +23,14 @@
 #include <cstdio>
 #include <cstring>
 #include <list>
+#include <thread>
+#include <atomic>
 #include <set>
 #include <unordered_map>
 #include <vector>
 
 #include "locref_filters.hpp"
+#include "locref_flat.hpp"
 #include "locref_kdtree.hpp"
 #include "locref_loam.hpp"
 #include "locref_math.hpp"
@@ -113,6 +116,19 @@ static bool FitPlane(const std::vector<V3>& data, double n[4], double eps = 1e-2
     return true;
 }
 
+// FitPlane for exactly five points on fixed arrays — the operations of the five-point branch above, no std::vector (R2).
+static bool FitPlane5(const V3 data[5], double n[4], double eps = 1e-2) {
+    double a[4][5], v[4][4];
+    for (int i = 0; i < 5; ++i) { a[0][i] = data[i].x; a[1][i] = data[i].y; a[2][i] = data[i].z; a[3][i] = 1.0; }
+    jacobi_svd_onesided<5, 4>(a, v);
+    PlaneVectorFromSvd<5>(a, v, n);
+    for (int i = 0; i < 5; ++i) {
+        const double err = dot(V3{n[0], n[1], n[2]}, data[i]) + n[3];
+        if (err * err > eps) return false;
+    }
+    return true;
+}
+
 // math_utils.h:138-163  FitLine<double>: origin = mean, dir = dominant right singular vector of the centred 5×3.
 static bool FitLine(const std::vector<V3>& data, V3& origin, V3& dir, double eps) {
     if (data.size() != 5) return false;
@@ -163,11 +179,74 @@ public:
     IcpOptions opt;
     KnnStats stats;
     bool count_stats = false;
+    FlatKdTree flat;       // R2: the same tree as one flat array (locref_flat.hpp), built on request
+    bool use_flat = false;
+    bool approximate = true;
+    float alpha = 0.1f;
 
     void SetInputTarget(const float* xyz, size_t n, size_t stride_floats) {
         target.resize(n);
         for (size_t i = 0; i < n; ++i) target[i] = {xyz[i * stride_floats], xyz[i * stride_floats + 1], xyz[i * stride_floats + 2]};
         tree.Build(xyz, n, stride_floats);
+        if (use_flat) flat.FromTree(tree);
+    }
+    void EnableFlat(bool on) {
+        use_flat = on;
+        if (on && flat.size() != tree.size() && tree.size() > 0) flat.FromTree(tree);
+    }
+
+    // icp cpp:161-213 on the flat tree with fixed arrays (R2). Read-only on the object: safe to call from several threads.
+    bool HB_P2Plane_flat(const std::vector<F3>& src, const SE3& pose, double H[36], double B[6], double* eff_out) const {
+        size_t effective_num = 0;
+        const M3 R = rotation_matrix(pose);
+        for (size_t i = 0; i < src.size(); ++i) {
+            const V3 q = ToVec3d(src[i]);
+            const V3 qs = transform(pose, q);
+            int nn[FlatKdTree::kMaxK];
+            const int cnt = flat.Knn(CastF(qs), 5, approximate, alpha, nn);
+            if (cnt > 3) {
+                V3 nb[5];
+                for (int j = 0; j < 5; ++j) nb[j] = ToVec3d(target[nn[j]]);
+                double n[4];
+                if (!FitPlane5(nb, n)) continue;
+                effective_num++;
+                const V3 n3{n[0], n[1], n[2]};
+                const double dis = dot(n3, qs) + n[3];
+                if (std::fabs(dis) > opt.max_plane_distance) continue;
+                const M3 hq = hat(q);
+                double nR[3];
+                for (int c = 0; c < 3; ++c) nR[c] = (-n3.x * R(0, c) + -n3.y * R(1, c)) + -n3.z * R(2, c);
+                double J[1][6];
+                for (int c = 0; c < 3; ++c) J[0][c] = (nR[0] * hq(0, c) + nR[1] * hq(1, c)) + nR[2] * hq(2, c);
+                J[0][3] = n3.x; J[0][4] = n3.y; J[0][5] = n3.z;
+                AddJtJ(H, B, J, 1, &dis);
+            }
+        }
+        if (eff_out) *eff_out = (double)effective_num;
+        if (effective_num < (size_t)opt.min_effective_pts) return false;
+        double x[6];
+        if (lu6_det_solve(H, B, x) == 0) return false;
+        return true;
+    }
+
+    // AlignP2Plane (icp cpp:345-381) over HB_P2Plane_flat; const ⇒ callable concurrently for different scans (R3)
+    int AlignFlat(const std::vector<F3>& src, const SE3& init, SE3& result) const {
+        SE3 pose = init;
+        int iters = 0;
+        for (int iter = 0; iter < opt.max_iteration; ++iter) {
+            double H[36] = {0}, err[6] = {0}, dx[6] = {0}, eff = 0;
+            const bool ok = HB_P2Plane_flat(src, pose, H, err, &eff);
+            ++iters;
+            if (ok) {
+                lu6_det_solve(H, err, dx);
+                apply_update(pose, dx);
+                double n2 = 0;
+                for (int i = 0; i < 6; ++i) n2 += dx[i] * dx[i];
+                if (std::sqrt(n2) < opt.eps) break;
+            }
+        }
+        result = pose;
+        return iters;
     }
 
     // KdtreeRegistration::FindNearstPoints (kdtree.cpp:272-283)
@@ -727,7 +806,30 @@ void* locref_icp_create(int method, const double* opts, int use_ann, float alpha
         m->opt.max_line_distance = opts[3]; m->opt.min_effective_pts = (int)opts[4]; m->opt.eps = opts[5];
     }
     m->tree.SetEnableANN(use_ann != 0, alpha);
+    m->approximate = use_ann != 0;
+    m->alpha = alpha;
     return m;
+}
+// R2 / R3: point-to-plane alignment of n_scans scans through the flat-array port, `threads` native threads taking
+// whole scans (1 = R2). Bit-identical poses to locref_icp_align. iters (optional): GN iterations per scan.
+void locref_icp_align_flat(void* mp, const float* const* srcs, const size_t* counts, size_t stride_floats, int n_scans, const double* inits,
+                           double* out_poses, int* iters, int threads) {
+    auto* m = (Icp*)mp;
+    m->EnableFlat(true);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (int s = next.fetch_add(1); s < n_scans; s = next.fetch_add(1)) {
+            std::vector<F3> cloud = LoadCloud(srcs[s], counts[s], stride_floats);
+            SE3 res;
+            const int it = m->AlignFlat(cloud, se3_from_array(inits + 7 * s), res);
+            se3_to_array(res, out_poses + 7 * s);
+            if (iters) iters[s] = it;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
 }
 void locref_icp_destroy(void* m) { delete (Icp*)m; }
 void locref_icp_set_target(void* mp, const float* xyz, size_t n, size_t stride_floats) { ((Icp*)mp)->SetInputTarget(xyz, n, stride_floats); }

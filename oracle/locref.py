@@ -19,7 +19,7 @@ TRACE_W = 50  # H36 B6 dx6 eff ok
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("locref.cpp", "locref_math.hpp", "locref_kdtree.hpp", "locref_filters.hpp", "locref_loam.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("locref.cpp", "locref_math.hpp", "locref_kdtree.hpp", "locref_flat.hpp", "locref_filters.hpp", "locref_loam.hpp")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liblocref.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -52,6 +52,7 @@ def lib():
             "locref_icp_tree_info": (None, [_vp, _vp]),
             "locref_icp_hb": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
             "locref_icp_align": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _i, _vp]),
+            "locref_icp_align_flat": (None, [_vp, _vp, _vp, _sz, _i, _vp, _vp, _vp, _i]),
             "locref_ndt_create": (_vp, [_vp]),
             "locref_ndt_destroy": (None, [_vp]),
             "locref_ndt_set_target": (None, [_vp, _vp, _sz, _sz]),
@@ -222,6 +223,22 @@ class Icp:
         return res
 
 
+    def align_flat(self, scans, init_poses, threads=1):
+        """BASELINE.md R2 (threads=1) / R3 (threads>1): the point-to-plane path through the flat-array port (locref_flat.hpp),
+        whole scans dealt to native threads. Returns (poses [n, 7], iterations [n]); bit-identical to align()."""
+        scans = [_f32(s) for s in scans]
+        width = scans[0].shape[1]
+        assert all(s.shape[1] == width for s in scans)
+        n = len(scans)
+        ptrs = (ctypes.c_void_p * n)(*[s.ctypes.data for s in scans])
+        cnts = (ctypes.c_size_t * n)(*[s.shape[0] for s in scans])
+        inits = np.ascontiguousarray(np.asarray(init_poses, dtype=np.float64).reshape(n, 7))
+        out = np.zeros((n, 7))
+        iters = np.zeros(n, dtype=np.int32)
+        lib().locref_icp_align_flat(self._h, ptrs, cnts, width, n, inits.ctypes.data, out.ctypes.data, iters.ctypes.data, int(threads))
+        return out, iters
+
+
 class Ndt:
     """NdtRegistration restated (ndt_registration.cpp). ``opts`` keys follow NdtOptions (hpp:27-42)."""
 
@@ -357,3 +374,17 @@ def loam_extract(cloud, ring, num_scan=16, order=SORT_STD):
     lib().locref_loam_extract(cloud.ctypes.data, ring.ctypes.data, len(cloud), int(num_scan), int(order), edge.ctypes.data, ctypes.byref(ne),
                               surf.ctypes.data, ctypes.byref(ns))
     return edge[:ne.value].copy(), surf[:ns.value].copy()
+
+
+def bfnn_knn(cloud, queries, k):
+    """BfnnRegistration::FindNearstPoints (LocUtils/src/model/search_point/bfnn/bfnn.cpp:24-50) for many queries: float32 squared
+    distances in Eigen's x0 + (x1 + x2) order, sorted ascending, first k indices. std::sort's order among equal distances is
+    unspecified; this restatement (and the product) order them by index (numpy's stable sort)."""
+    c = np.ascontiguousarray(np.asarray(cloud, dtype=np.float32)[:, :3])
+    q = np.ascontiguousarray(np.asarray(queries, dtype=np.float32)[:, :3])
+    out = np.empty((len(q), k), np.int32)
+    for i in range(len(q)):
+        d = c - q[i]
+        d2 = (d[:, 0] * d[:, 0]) + ((d[:, 1] * d[:, 1]) + (d[:, 2] * d[:, 2]))
+        out[i] = np.argsort(d2, kind="stable")[:k]
+    return out

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Fills BASELINE.md's table (configs 1-5 of BASELINE.json) on the GPU box: runs bench.py / the microbenches per config and
 collects CPU R1 (the oracle is written in the reference's style: per-query std::vector + std::priority_queue, pointer nodes —
-1 thread), CPU R3 (same, scan-parallel over all host cores), GPU scans/s, ms per GN iteration, roofline fraction, pose delta.
+1 thread), CPU R2 (the flat-array port, 1 thread), CPU R3 (R2 scan-parallel over native threads on all host cores), GPU scans/s
+(scan H2D inside the timed region), ms per GN iteration, roofline fractions, pose delta.
 
     python3 tests/perf/baseline_table.py --out gpurun_out/baseline_table.json
 """
@@ -30,8 +31,10 @@ def run_bench(*extra):
 def row_from_bench(name, j):
     cb = j.get("cpu_baseline") or {}
     cfg = j.get("config", {})
-    return dict(config=name, workload=cfg.get("workload"), cpu_r1_scans_s=cb.get("value"), cpu_r3_scans_s=(cb.get("all_cores") or {}).get("value"),
-                cpu_cores=(cb.get("all_cores") or {}).get("cores"), gpu_scans_s=j["value"], ms_per_step=j["ms_per_step"],
+    r2, r3 = cb.get("r2_flat_port") or {}, cb.get("r3_flat_port_all_cores") or {}
+    return dict(config=name, workload=cfg.get("workload"), cpu_r1_scans_s=cb.get("value"), cpu_r2_scans_s=r2.get("value"), cpu_r3_scans_s=r3.get("value"),
+                cpu_cores=r3.get("cores"), gpu_scans_s=j["value"], ms_per_step=j["ms_per_step"], scan_h2d_in_timed_region=cfg.get("scan_h2d_in_timed_region"),
+                search_hbm_frac=(j.get("roofline") or {}).get("hbm_frac"),
                 gpu_iter_ms_per_scan=j.get("icp_iter_ms_per_scan"), gn_iterations_per_scan=j.get("gn_iterations_per_scan"),
                 search_roofline_frac=(j.get("roofline") or {}).get("frac"), traffic_bytes=(j.get("roofline") or {}).get("traffic"),
                 pose_delta_m=cb.get("max_pose_delta_gpu_vs_cpu_m"), gpu_over_cpu=cb.get("gpu_over_cpu"))
@@ -75,9 +78,9 @@ def main():
     a = ap.parse_args()
     steps = ["--steps", "3", "--warmup", "1"] if a.quick else ["--steps", "10", "--warmup", "2"]
     rows = [config1()]
-    rows.append(row_from_bench("2: 115200-pt scans vs 1M-pt map, P2Plane (64 resident scans)", run_bench("--map-points", "1000000", "--scans-per-gpu", "64", *steps)))
-    rows.append(row_from_bench("3a: vs 10M-pt map, P2Plane (64 resident scans)", run_bench("--scans-per-gpu", "64", *steps)))
-    rows.append(row_from_bench("3b: vs 10M-pt map, direct NDT (64 resident scans)", run_bench("--scans-per-gpu", "64", "--method", "ndt", *steps)))
+    rows.append(row_from_bench("2: 115200-pt scans vs 1M-pt map, P2Plane (64 scans per step)", run_bench("--map-points", "1000000", "--scans-per-gpu", "64", "--traffic", "none", *steps)))
+    rows.append(row_from_bench("3a: vs 10M-pt map, P2Plane (64 scans per step)", run_bench("--scans-per-gpu", "64", "--traffic", "none", *steps)))
+    rows.append(row_from_bench("3b: vs 10M-pt map, direct NDT (64 scans per step)", run_bench("--scans-per-gpu", "64", "--method", "ndt", "--traffic", "none", *steps)))
     rows.append(row_from_bench("4: 256 scans vs 10M-pt map, P2Plane, 1 GPU of the 8 (scan-sharded, no data-path collective)", run_bench(*steps)))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "perf", "pipeline_microbench.py"), "--only", "stream"], capture_output=True, text=True, timeout=900)
     st = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])["stream"]
@@ -85,13 +88,13 @@ def main():
                      gpu_scans_s=st["scans_per_s"], ms_per_scan=st["ms_per_scan"], pose_delta_m=st["max_pose_abs_diff"], local_map_points=st["local_map_points"]))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(dict(rows=rows, host_cores=os.cpu_count()), open(a.out, "w"), indent=1)
-    print("| config | CPU R1 scans/s (1 thread) | CPU R3 scans/s (cores) | GPU×1 scans/s | GPU ms per scan-iteration | search roofline frac | pose Δ vs oracle [m] |")
-    print("|---|---|---|---|---|---|---|")
+    print("| config | CPU R1 scans/s (1 thread) | CPU R2 scans/s (1 thread) | CPU R3 scans/s (cores) | GPU×1 scans/s | GPU ms per scan-iteration | search roofline frac (algorithmic / HBM traffic) | pose Δ vs oracle [m] |")
+    print("|---|---|---|---|---|---|---|---|")
     f = lambda v, p="%.3g": "—" if v is None else p % v
     for r in rows:
-        print("| %s | %s | %s | %s | %s | %s | %s |" % (r["config"], f(r.get("cpu_r1_scans_s")),
+        print("| %s | %s | %s | %s | %s | %s | %s / %s | %s |" % (r["config"], f(r.get("cpu_r1_scans_s")), f(r.get("cpu_r2_scans_s")),
               ("%s (%s)" % (f(r.get("cpu_r3_scans_s")), r.get("cpu_cores"))) if r.get("cpu_r3_scans_s") else "—", f(r.get("gpu_scans_s"), "%.4g"),
-              f(r.get("gpu_iter_ms_per_scan")), f(r.get("search_roofline_frac")), f(r.get("pose_delta_m"), "%.1e")))
+              f(r.get("gpu_iter_ms_per_scan")), f(r.get("search_roofline_frac")), f(r.get("search_hbm_frac")), f(r.get("pose_delta_m"), "%.1e")))
 
 
 if __name__ == "__main__":

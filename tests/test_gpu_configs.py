@@ -344,3 +344,24 @@ def test_device_grid_invariants(api, locref, synth, case):
         assert np.array_equal(a, b)
     finally:
         ctx.close()
+
+
+# ----------------------------------------------------------------------------------------------- BfnnRegistration
+@pytest.mark.parametrize("k", [1, 5, 8])
+def test_bfnn_matches_brute_force(gpu_ctx, api, locref, small_world, k):
+    """BfnnRegistration::FindNearstPoints (bfnn.cpp:24-50): indices of the k smallest float32 distances, ascending, ties by index;
+    lattice points give many exact ties. k larger than the cloud is an error (the reference reads past the end of its array)."""
+    m = small_world["map"][:50000]
+    rng = np.random.RandomState(7 + k)
+    q = (m[rng.choice(len(m), 64, replace=False), :3] + rng.randn(64, 3).astype(np.float32) * 0.1).astype(np.float32)
+    gpu_ctx.bfnn_set_target(m)
+    np.testing.assert_array_equal(gpu_ctx.bfnn_knn(q, k=k), locref.bfnn_knn(m, q, k))
+    g = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(5), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    ql = (g[::11] + 0.5).astype(np.float32)
+    gpu_ctx.bfnn_set_target(g)
+    np.testing.assert_array_equal(gpu_ctx.bfnn_knn(ql, k=k), locref.bfnn_knn(g, ql, k))
+    gpu_ctx.bfnn_set_target(g[:3])
+    if k > 3:
+        with pytest.raises(api.LocGpuError) as e:
+            gpu_ctx.bfnn_knn(ql, k=k)
+        assert e.value.code == -4

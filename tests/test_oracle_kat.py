@@ -233,3 +233,21 @@ def test_p2p_sixteenth_quirk(locref):
     hat = lambda v: np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
     Hrr = sum((hat(v) / 16).T @ (hat(v) / 16) for v in q)
     np.testing.assert_allclose(H[:3, :3], Hrr, rtol=1e-9)
+
+
+def test_flat_port_equals_reference_style(locref, synth, small_world):
+    """the flat-array port of the point-to-plane path (oracle/locref_flat.hpp) and its threaded driver give the
+    poses and iteration counts of the reference-style restatement (R1) bit for bit — approximate and exact pruning."""
+    m, init = small_world["map"], small_world["init_pose"]
+    scans = [small_world["scan2k"], small_world["scan10k"][::4], small_world["scan2k"][::2]]
+    inits = np.stack([init, init, init])
+    inits[1, 4:] += [0.05, -0.02, 0.01]
+    for use_ann in (True, False):
+        icp = locref.Icp(method=locref.P2PLANE, use_ann=use_ann)
+        icp.set_target(m)
+        want = [icp.align(s, p) for s, p in zip(scans, inits)]
+        for threads in (1, 3):
+            poses, iters = icp.align_flat(scans, inits, threads=threads)
+            for i, w in enumerate(want):
+                np.testing.assert_array_equal(poses[i], w["pose"])
+                assert iters[i] == w["iters"]
