@@ -128,16 +128,19 @@ class Pool {
 public:
     static Pool& get() { static Pool p; return p; }
     unsigned size() const { return (unsigned)workers_.size() + 1; }
-    template <class F> void run(size_t n, F&& fn) {
+    // fn(i) for i in [0, n) on the caller's thread and at most max_threads − 1 pool threads. Only as many workers as can be useful
+    // are woken: waking (and waiting for) every thread of a 256-thread host costs more than a 35 k-point build.
+    template <class F> void run(size_t n, unsigned max_threads, F&& fn) {
         if (n == 0) return;
-        if (n == 1 || workers_.empty()) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+        const size_t helpers = std::min<size_t>({workers_.size(), n - 1, max_threads > 0 ? (size_t)max_threads - 1 : 0});
+        if (helpers == 0) { for (size_t i = 0; i < n; ++i) fn(i); return; }
         std::lock_guard<std::mutex> serial(run_mu_);  // one parallel region at a time (several contexts may ingest concurrently)
         std::function<void(size_t)> f = fn;
         {
             std::lock_guard<std::mutex> lk(mu_);
-            fn_ = &f; n_ = n; next_.store(0); pending_ = workers_.size(); ++gen_;
+            fn_ = &f; n_ = n; next_.store(0); pending_ = helpers; tickets_ = helpers;
         }
-        cv_.notify_all();
+        for (size_t h = 0; h < helpers; ++h) cv_.notify_one();
         for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) f(i);
         std::unique_lock<std::mutex> lk(mu_);
         done_cv_.wait(lk, [&] { return pending_ == 0; });
@@ -152,20 +155,19 @@ private:
         for (unsigned t = 1; t < nt; ++t) workers_.emplace_back([this] { loop(); });
     }
     ~Pool() {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
         cv_.notify_all();
         for (auto& t : workers_) t.join();
     }
     void loop() {
-        unsigned long long seen = 0;
         for (;;) {
             std::function<void(size_t)>* f;
             size_t n;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
+                cv_.wait(lk, [&] { return tickets_ > 0 || stop_; });
                 if (stop_) return;
+                --tickets_;
                 f = fn_; n = n_;
             }
             for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) (*f)(i);
@@ -177,9 +179,8 @@ private:
     std::mutex mu_, run_mu_;
     std::condition_variable cv_, done_cv_;
     std::function<void(size_t)>* fn_ = nullptr;
-    size_t n_ = 0, pending_ = 0;
+    size_t n_ = 0, pending_ = 0, tickets_ = 0;
     std::atomic<size_t> next_{0};
-    unsigned long long gen_ = 0;
     bool stop_ = false;
 };
 
@@ -216,7 +217,7 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
     for (size_t i = 0; i < n; ++i) idx[i] = (int32_t)i;
 
     Pool& pool = Pool::get();
-    const unsigned nt = pool.size();
+    const unsigned nt = (unsigned)std::min<size_t>(pool.size(), std::max<size_t>(1, n / 4096));  // threads worth waking for this map
     const size_t task_len = std::max<size_t>(n / (4 * (size_t)nt), 2048);
 
     // Top of the tree, level by level: the nodes of one level are independent, so they are split in parallel (each node still
@@ -233,7 +234,7 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
         }
         const size_t base = pieces.size();
         pieces.resize(base + 2 * split_now.size());  // two child slots per node, reserved before the parallel region
-        pool.run(split_now.size(), [&](size_t k) {
+        pool.run(split_now.size(), nt, [&](size_t k) {
             Piece& p = pieces[split_now[k]];
             b.note_depth(p.level);
             const int32_t first = idx[p.off];
@@ -256,7 +257,7 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
 
     // The tasks, largest first.
     std::sort(tasks.begin(), tasks.end(), [&](int a, int c) { return pieces[a].len > pieces[c].len; });
-    pool.run(tasks.size(), [&](size_t t) {
+    pool.run(tasks.size(), nt, [&](size_t t) {
         Piece& p = pieces[tasks[t]];
         p.slots.reserve(3 * p.len);
         Local loc;
@@ -294,7 +295,7 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
     out.leaf_slots.resize(pieces[0].n_leaves);
     std::atomic<bool> bounded{true};
     // Assemble: task outputs are copied (right-child indices rebased by the task's position) in parallel; top nodes are single slots.
-    pool.run(pieces.size(), [&](size_t i) {
+    pool.run(pieces.size(), nt, [&](size_t i) {
         Piece& p = pieces[i];
         if (p.is_task) {
             const size_t base = p.pos;

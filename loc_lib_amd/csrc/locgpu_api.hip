@@ -6,6 +6,7 @@
 // reads back the small per-scan state every `kChunk` iterations.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <cmath>
 #include <cstdio>
@@ -206,14 +207,26 @@ static int install_tree_meta(locgpu_ctx* ctx, const long long meta[6]) {
 int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes) {
     if (!ctx) return LOCGPU_ERR_INVALID;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    static const bool times = getenv("LOCGPU_INGEST_TIMES") != nullptr;  // diagnostic: phase times on stderr
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!times) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[locgpu ingest] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     PackedKdTree t;
     int rc = build_host_tree(ctx, pts, n, stride_bytes, t);
     if (rc != LOCGPU_OK) return rc;
+    lap("host build");
     const long long meta[6] = {(long long)t.slots.size(), (long long)t.num_leaves, (long long)t.num_nodes, (long long)t.num_points, t.depth, t.bounded ? 1 : 0};
     rc = install_tree_meta(ctx, meta);
     if (rc != LOCGPU_OK) return rc;
-    LOCGPU_HIP(ctx, hipMemcpy(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    LOCGPU_HIP(ctx, hipMemcpy(ctx->d_leaf_slots, t.leaf_slots.data(), t.leaf_slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    lap("device buffers");
+    LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_leaf_slots, t.leaf_slots.data(), t.leaf_slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    lap("H2D");
     return LOCGPU_OK;
 }
 
