@@ -20,9 +20,43 @@
 #include "kdtree_build.hpp"
 #include "launch.hpp"
 
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 using namespace locgpu;
+
+// RCCL is bound at the first locgpu_comm_* call (dlopen), not at load time: a single-GPU process — the slam_demo front-end, the
+// tests — never maps librccl and its dependencies (rocm_smi, roctx, rocprofiler-register). The entry points used:
+namespace {
+struct Rccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    std::string err;
+};
+Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);  // a copy already mapped by the host process (e.g. PyTorch's) is reused
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { x.err = std::string("cannot load librccl: ") + dlerror(); return x; }
+        x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        x.CommInitRank = (decltype(x.CommInitRank))dlsym(h, "ncclCommInitRank");
+        x.CommDestroy = (decltype(x.CommDestroy))dlsym(h, "ncclCommDestroy");
+        x.AllReduce = (decltype(x.AllReduce))dlsym(h, "ncclAllReduce");
+        x.Broadcast = (decltype(x.Broadcast))dlsym(h, "ncclBroadcast");
+        x.GetErrorString = (decltype(x.GetErrorString))dlsym(h, "ncclGetErrorString");
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllReduce && x.Broadcast && x.GetErrorString;
+        if (!x.ok) x.err = "librccl lacks an expected entry point";
+        return x;
+    }();
+    return r;
+}
+}  // namespace
 
 namespace {
 std::string g_create_err;
@@ -146,7 +180,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_batch(ctx->single);
-    if (ctx->comm) { (void)ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
+    if (ctx->comm) { (void)rccl().CommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
     if (ctx->d_tree) (void)hipFree(ctx->d_tree);
     if (ctx->d_leaf_slots) (void)hipFree(ctx->d_leaf_slots);
     if (ctx->d_bfnn) (void)hipFree(ctx->d_bfnn);
@@ -250,7 +284,7 @@ int locgpu_icp_set_target_bcast(locgpu_ctx* ctx, const void* pts, size_t n, size
     long long* d_meta = nullptr;
     LOCGPU_HIP(ctx, hipMalloc((void**)&d_meta, sizeof(meta)));
     bool ok = hip_ok(ctx, hipMemcpyAsync(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, s), "bcast meta H2D");
-    ok = ok && ncclBroadcast(d_meta, d_meta, sizeof(meta), ncclChar, root, comm, s) == ncclSuccess;
+    ok = ok && rccl().Broadcast(d_meta, d_meta, sizeof(meta), ncclChar, root, comm, s) == ncclSuccess;
     ok = ok && hip_ok(ctx, hipMemcpyAsync(meta, d_meta, sizeof(meta), hipMemcpyDeviceToHost, s), "bcast meta D2H") && hip_ok(ctx, hipStreamSynchronize(s), "sync");
     (void)hipFree(d_meta);
     if (!ok) return fail(ctx, LOCGPU_ERR_NO_DEVICE, "icp_set_target_bcast: broadcast of the tree header failed");
@@ -261,8 +295,8 @@ int locgpu_icp_set_target_bcast(locgpu_ctx* ctx, const void* pts, size_t n, size
         LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_leaf_slots, t.leaf_slots.data(), t.leaf_slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     }
-    if (ncclBroadcast(ctx->d_tree, ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ncclChar, root, comm, s) != ncclSuccess ||
-        ncclBroadcast(ctx->d_leaf_slots, ctx->d_leaf_slots, ctx->num_leaves * sizeof(uint32_t), ncclChar, root, comm, s) != ncclSuccess)
+    if (rccl().Broadcast(ctx->d_tree, ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ncclChar, root, comm, s) != ncclSuccess ||
+        rccl().Broadcast(ctx->d_leaf_slots, ctx->d_leaf_slots, ctx->num_leaves * sizeof(uint32_t), ncclChar, root, comm, s) != ncclSuccess)
         return fail(ctx, LOCGPU_ERR_NO_DEVICE, "icp_set_target_bcast: broadcast of the tree failed");
     LOCGPU_HIP(ctx, hipStreamSynchronize(s));
     return LOCGPU_OK;
@@ -433,7 +467,7 @@ int locgpu_comm_unique_id(void* id_out) {
     if (!id_out) return LOCGPU_ERR_INVALID;
     static_assert(LOCGPU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "locgpu.h and rccl.h disagree on the id size");
     ncclUniqueId id;
-    if (ncclGetUniqueId(&id) != ncclSuccess) return LOCGPU_ERR_NO_DEVICE;
+    if (!rccl().ok || rccl().GetUniqueId(&id) != ncclSuccess) return LOCGPU_ERR_NO_DEVICE;
     std::memcpy(id_out, &id, sizeof(id));
     return LOCGPU_OK;
 }
@@ -442,12 +476,13 @@ int locgpu_comm_init(locgpu_ctx* ctx, int rank, int world, const void* id) {
     if (!ctx) return LOCGPU_ERR_INVALID;
     if (!id || world < 1 || rank < 0 || rank >= world) return fail(ctx, LOCGPU_ERR_INVALID, "comm_init: bad arguments");
     if (ctx->comm) return fail(ctx, LOCGPU_ERR_INVALID, "comm_init: this context already has a communicator");
+    if (!rccl().ok) return fail(ctx, LOCGPU_ERR_NO_DEVICE, "comm_init: " + rccl().err);
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof(uid));
     ncclComm_t comm = nullptr;
-    const ncclResult_t nr = ncclCommInitRank(&comm, world, uid, rank);
-    if (nr != ncclSuccess) return fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(nr));
+    const ncclResult_t nr = rccl().CommInitRank(&comm, world, uid, rank);
+    if (nr != ncclSuccess) return fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclCommInitRank: ") + rccl().GetErrorString(nr));
     ctx->comm = comm;
     ctx->comm_rank = rank;
     ctx->comm_world = world;
@@ -556,8 +591,8 @@ bool IterLauncher::launch(int do_update) {
         // same convergence flags and stay in lock-step.
         launch_sum_partials(b->d_partials, n_partial_blocks, b->d_state, b->first, b->n_scans, b->n_total, b->d_acc, s);
         if (ctx->comm) {
-            const ncclResult_t nr = ncclAllReduce(b->d_acc, b->d_acc, (size_t)b->n_total * kAccW, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
-            if (nr != ncclSuccess) { fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(nr)); return false; }
+            const ncclResult_t nr = rccl().AllReduce(b->d_acc, b->d_acc, (size_t)b->n_total * kAccW, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
+            if (nr != ncclSuccess) { fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr)); return false; }
         }
         launch_gn_solve(b->d_acc, 1, b->d_state, b->n_total, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s);
     } else {
