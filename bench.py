@@ -176,9 +176,12 @@ def main():
 
     strong = args.scaling == "strong"
     ctx = api.Context(local_rank)  # fails loudly without a GPU / without liblocgpu.so
-    use_comm = dist is not None or strong
+    # The native RCCL communicator (inside liblocgpu.so) is only needed where the path has an exchange step: the strong-scaling
+    # mode's per-iteration all-reduce (and its one tree build per node, broadcast over xGMI). Weak scaling has no collective on
+    # the data path: every rank ingests the map itself (0.4 s with the level-parallel host build).
+    use_comm = strong
     if use_comm:
-        multi_gpu.init_comm(ctx, dist)  # RCCL communicator inside liblocgpu.so (one rank when not launched by torchrun)
+        multi_gpu.init_comm(ctx, dist)  # one rank when not launched by torchrun
 
     # ---- inputs (untimed): map, tree ingest — resident in HBM before the timed region
     t0 = time.time()
