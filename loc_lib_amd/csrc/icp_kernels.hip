@@ -599,7 +599,7 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
     static const int blk = [] { const char* e = getenv("LOCGPU_FAST_BLOCK"); const int v = e ? atoi(e) : 64; return (v == 256 || v == 128) ? v : 64; }();
     if (blk != 256) {
         static const int lds_pad = [] { const char* e = getenv("LOCGPU_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiment: extra dynamic LDS lowers occupancy
-        static const int small_lanes = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); const int v = e ? atoi(e) : 32; return (v == 16 || v == 32) ? v : 64; }();
+        static const int small_lanes = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); const int v = e ? atoi(e) : 16; return (v == 16 || v == 32) ? v : 64; }();
         // fewer than 2048 full waves (one or two scans): half-filled waves, see the kernel
         const int lanes = (blk == 64 && (size_t)((a.max_n + 63) / 64) * a.n_scans <= 2048) ? small_lanes : blk;
         dim3 g2((a.max_n + lanes - 1) / lanes, a.n_scans);
