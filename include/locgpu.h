@@ -195,11 +195,12 @@ LOCGPU_API int locgpu_ndt_dump(locgpu_ctx* ctx, int32_t* keys, double* mu, doubl
 LOCGPU_API int locgpu_ndt_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7],
                                 double out_pose[7], locgpu_align_stats* stats);
 
-/* ---- hipGraph mode (BASELINE config 5, streaming loop). When on, an align call captures ALL max_iteration Gauss–Newton
- * iterations of the batch once (kernels early-out per scan on a device-side flag, so the fixed node sequence equals the
- * reference's data-dependent loop, icp_registration.cpp:358-376) and replays the instantiated graph on later calls with the
- * same batch, options and target: one graph launch and one host synchronisation per call. Results are bit-identical to the
- * eager mode. */
+/* ---- hipGraph mode (BASELINE config 5, streaming loop). When on, an align call replays instantiated graphs of Gauss–Newton
+ * iterations instead of launching kernel by kernel: one graph of the first eight iterations (with the state upload and
+ * read-back) — the typical alignment ends inside it: one graph launch, one host synchronisation — and a four-iteration graph
+ * replayed while scans are still open. Kernels early-out per scan on a device-side flag, so the fixed node sequence equals the
+ * reference's data-dependent loop (icp_registration.cpp:358-376). Graphs are captured once per batch, options and target and
+ * re-captured when any of them changes. Results are bit-identical to the eager mode. */
 LOCGPU_API int locgpu_graph_enable(locgpu_ctx* ctx, int on);
 
 /* ---- Measurement hooks (bench.py / tests; no reference counterpart). */

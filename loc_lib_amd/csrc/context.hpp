@@ -85,7 +85,8 @@ struct locgpu_batch {
     uint32_t* d_grid_qkey = nullptr;       // [pitch] grid search: tile of each query
     uint2* d_grid_sorted = nullptr;        // [pitch] grid search: {query, tile} in tile order
     // hipGraph of {H2D state, max_iteration × (search, fit+accumulate, solve), D2H state}, keyed by the launch parameters
-    hipGraphExec_t graph_exec = nullptr;
+    hipGraphExec_t graph_exec = nullptr;       // {H2D state, first chunk of iterations, D2H state}
+    hipGraphExec_t graph_exec_next = nullptr;  // {further chunk, D2H state}
     locgpu::GnParams graph_prm{};
     int graph_k = -1;
     float graph_alpha = 0.f;

@@ -114,6 +114,7 @@ static void free_batch(locgpu_batch* b) {
     if (b->d_grid_qkey) (void)hipFree(b->d_grid_qkey);
     if (b->d_grid_sorted) (void)hipFree(b->d_grid_sorted);
     if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
+    if (b->graph_exec_next) (void)hipGraphExecDestroy(b->graph_exec_next);
     if (b->h_src) (void)hipHostFree(b->h_src);
     if (b->h_state) (void)hipHostFree(b->h_state);
     if (b->h_hb) (void)hipHostFree(b->h_hb);
@@ -639,9 +640,30 @@ static int ensure_grid_lists(locgpu_ctx* ctx, locgpu_batch* b, float alpha_eff) 
     return LOCGPU_OK;
 }
 
-// hipGraph path (BASELINE config 5): every GN iteration of the batch is captured once — the kernels early-out per scan on
-// the device-side `done` flag, so a fixed node sequence gives the same result as the data-dependent eager loop — and
-// replayed per call with a single host synchronisation at the end.
+// hipGraph path (BASELINE config 5): the Gauss–Newton iterations are captured once — the kernels early-out per scan on the
+// device-side `done` flag, so a fixed node sequence gives the same result as the data-dependent eager loop — and replayed per call.
+// Two graphs mirror the eager loop's chunks: graph 0 = {H2D state, kFirstChunk iterations, D2H state} covers the typical alignment
+// with one launch and one host synchronisation; graph 1 = {kNextChunk iterations, D2H state} is replayed while scans are still
+// open (capturing all max_iteration iterations in one graph made every call pay a dozen empty iterations).
+static int capture_chunk(locgpu_ctx* ctx, locgpu_batch* b, const GnParams& prm, int k, float alpha_eff, bool ndt, int iters, bool with_h2d,
+                         hipGraphExec_t* out) {
+    hipStream_t s = ctx->stream;
+    hipGraph_t graph = nullptr;
+    LOCGPU_HIP(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    bool ok = !with_h2d || hip_ok(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, s), "capture H2D");
+    IterLauncher it{ctx, b, prm, k, alpha_eff};
+    it.ndt = ndt;
+    it.capturing = true;
+    for (int i = 0; ok && i < iters; ++i) ok = it.launch(1);
+    ok = ok && hip_ok(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_total * sizeof(PoseState), hipMemcpyDeviceToHost, s), "capture D2H");
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (!ok || !hip_ok(ctx, e, "hipStreamEndCapture")) { if (graph) (void)hipGraphDestroy(graph); return LOCGPU_ERR_NO_DEVICE; }
+    const bool inst = hip_ok(ctx, hipGraphInstantiate(out, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+    (void)hipGraphDestroy(graph);
+    if (!inst) { *out = nullptr; return LOCGPU_ERR_NO_DEVICE; }
+    return LOCGPU_OK;
+}
+
 static int run_align_graph(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt,
                            double* out_poses, locgpu_align_stats* stats) {
     hipStream_t s = ctx->stream;
@@ -650,26 +672,29 @@ static int run_align_graph(locgpu_ctx* ctx, locgpu_batch* b, const double* init_
     const bool same = b->graph_exec && b->graph_k == k && b->graph_alpha == alpha_eff && b->graph_ndt == ndt && b->graph_target == target &&
                       b->graph_epoch == ctx->target_epoch &&
                       b->graph_prm == prm;
+    const int first = std::min(kFirstChunk, prm.max_iteration);
     if (!same) {
         if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
-        hipGraph_t graph = nullptr;
-        LOCGPU_HIP(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        bool ok = hip_ok(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, s), "capture H2D");
-        IterLauncher it{ctx, b, prm, k, alpha_eff};
-        it.ndt = ndt;
-        it.capturing = true;
-        for (int i = 0; ok && i < prm.max_iteration; ++i) ok = it.launch(1);
-        ok = ok && hip_ok(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_total * sizeof(PoseState), hipMemcpyDeviceToHost, s), "capture D2H");
-        const hipError_t e = hipStreamEndCapture(s, &graph);
-        if (!ok || !hip_ok(ctx, e, "hipStreamEndCapture")) { if (graph) (void)hipGraphDestroy(graph); return LOCGPU_ERR_NO_DEVICE; }
-        const bool inst = hip_ok(ctx, hipGraphInstantiate(&b->graph_exec, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
-        (void)hipGraphDestroy(graph);
-        if (!inst) { b->graph_exec = nullptr; return LOCGPU_ERR_NO_DEVICE; }
+        if (b->graph_exec_next) { (void)hipGraphExecDestroy(b->graph_exec_next); b->graph_exec_next = nullptr; }
+        int rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, first, true, &b->graph_exec);
+        if (rc == LOCGPU_OK && prm.max_iteration > first) rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, kNextChunk, false, &b->graph_exec_next);
+        if (rc != LOCGPU_OK) return rc;
         b->graph_prm = prm; b->graph_k = k; b->graph_alpha = alpha_eff; b->graph_ndt = ndt; b->graph_target = target;
         b->graph_epoch = ctx->target_epoch;
     }
     LOCGPU_HIP(ctx, hipGraphLaunch(b->graph_exec, s));
     LOCGPU_HIP(ctx, hipStreamSynchronize(s));
+    int launched = first;
+    for (;;) {
+        bool all_done = true;
+        for (int i = 0; i < b->n_total; ++i)
+            if (!b->h_state[i].done) { all_done = false; break; }
+        if (all_done || launched >= prm.max_iteration) break;
+        // kernels of a finished scan return at once and the solve kernel stops at max_iteration, so a whole chunk is always safe
+        LOCGPU_HIP(ctx, hipGraphLaunch(b->graph_exec_next, s));
+        LOCGPU_HIP(ctx, hipStreamSynchronize(s));
+        launched += kNextChunk;
+    }
     write_results(b, init_poses, out_poses, stats);
     return LOCGPU_OK;
 }
