@@ -288,11 +288,10 @@ hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, 
     if (flag[0] & 2u) { msg = "a tile holds more than 65535 leaves (degenerate point distribution)"; return hipErrorInvalidValue; }
     const uint32_t n_occ = flag[1];
 
-    // ---- per-iteration binning scratch: one counter per (occupied tile, y-z row of its cells)
-    const size_t n_keys = (size_t)n_tocc * kTileRows;
-    GB_TRY(hipMalloc((void**)&buf.tile_count, (n_keys + 2) * sizeof(uint32_t)));
+    // ---- per-iteration binning scratch: one counter per occupied tile
+    GB_TRY(hipMalloc((void**)&buf.tile_count, ((size_t)n_tocc + 2) * sizeof(uint32_t)));
     size_t scan_bytes = 0;
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, buf.tile_count, buf.tile_count, (int)(n_keys + 1), s));
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, buf.tile_count, buf.tile_count, (int)(n_tocc + 1), s));
     GB_TRY(hipMalloc(&buf.scan_temp, scan_bytes ? scan_bytes : 1));
     GB_TRY(hipGetLastError());
     GB_TRY(hipStreamSynchronize(s));
@@ -301,7 +300,6 @@ hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, 
     view.tile_mask = cap - 1;
     view.tiles = buf.tiles;
     view.n_tocc = n_tocc;
-    view.n_keys = (uint32_t)n_keys;
     view.pts = buf.pts;
     float max_abs = 0.f;
     for (int a = 0; a < 3; ++a) {
@@ -318,7 +316,7 @@ hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, 
     view.tile_count = buf.tile_count;
     view.scan_temp = buf.scan_temp;
     view.scan_temp_bytes = scan_bytes;
-    view.bytes = (size_t)cap * sizeof(uint2) + (size_t)n_tocc * sizeof(TileRec) + n * sizeof(float4) + (n_keys + 2) * sizeof(uint32_t);
+    view.bytes = (size_t)cap * sizeof(uint2) + (size_t)n_tocc * sizeof(TileRec) + n * sizeof(float4) + ((size_t)n_tocc + 2) * sizeof(uint32_t);
     return hipSuccess;
 }
 

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void grid_bin_count_kernel(GridDev g, const
             const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
             const bool inside = qx == qx && qy == qy && qz == qz && (unsigned)cx < (unsigned)g.nx && (unsigned)cy < (unsigned)g.ny && (unsigned)cz < (unsigned)g.nz;
             const int t = inside ? tile_lookup(g, cx / kGridTile, cy / kGridTile, cz / kGridTile) : -1;
-            if (t >= 0) { has = true; key = (uint32_t)t * kTileRows + (uint32_t)((cz % kGridTile) * kGridTile + (cy % kGridTile)); }
+            if (t >= 0) { has = true; key = (uint32_t)t; }
             else to_tree = true;  // outside every occupied tile (or NaN): the tree answers
         }
         qkey[gi] = key;
@@ -283,7 +283,6 @@ constexpr int kStageEdge = kGridTile + 2 * kStageRing;                 // 8 cell
 constexpr int kStageCells = kStageEdge * kStageEdge * kStageEdge;      // 512
 constexpr int kStageCap = 1024;                                        // leaves a staged block may hold (16 KB of LDS)
 constexpr int kRangeQ = 256;                                           // sorted queries per work range
-constexpr int kDenseRow = 24;                                          // queries of one (tile, y, z) row from which the uniform loop pays
 static_assert(kStageCells % 64 == 0 && kStageCap < 65536, "staging layout");
 
 template <int K>
@@ -311,11 +310,11 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
         __syncthreads();
         int pos = 0;
         while (pos < n_in) {
-            const uint32_t cur = s_keys[pos] / (uint32_t)kTileRows;  // tile record
+            const uint32_t cur = s_keys[pos];
             int end = pos;
-            for (;;) {  // end of the run of queries of tile `cur`
+            for (;;) {  // end of the run of `cur`
                 const int idx = end + lane;
-                const unsigned long long m = __ballot(idx < n_in && s_keys[idx] / (uint32_t)kTileRows == cur);
+                const unsigned long long m = __ballot(idx < n_in && s_keys[idx] == cur);
                 const int nz = (~m) ? __ffsll((long long)~m) - 1 : 64;
                 end += nz;
                 if (nz < 64) break;
@@ -362,126 +361,64 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
                 if (lane == 63) s_lstart[kStageCells] = (uint16_t)total;
             }
             __syncthreads();
-
-            // One query against the staged block. `have_union`: ring 1 was already examined by the row's uniform loop (the cells
-            // x = 1..6 of the rows |dy|,|dz| ≤ 1); otherwise ring 1 is walked here, per lane. Then ring 2 if ring 1 did not settle.
-            auto finish_query = [&](uint32_t gi, TopK<K>& set, float qx, float qy, float qz, int cx, int cy, int cz, bool have_union) -> bool {
-                const int lx = cx - tx * kGridTile + kStageRing, ly = cy - ty * kGridTile + kStageRing, lz = cz - tz * kGridTile + kStageRing;  // 2..5
-                if (!have_union) {  // ring 1: nine rows of three consecutive cells, walked as ONE loop (a lane switches rows when its run ends)
-                    int r = 0;
-                    const int id00 = ((lz - 1) * kStageEdge + (ly - 1)) * kStageEdge + (lx - 1);
-                    uint32_t pi = s_lstart[id00], en = s_lstart[id00 + 3];
-                    for (;;) {
-                        while (pi == en && r < 8) {
-                            ++r;
-                            const int id0 = id00 + (r / 3) * (kStageEdge * kStageEdge) + (r % 3) * kStageEdge;
-                            pi = s_lstart[id0]; en = s_lstart[id0 + 3];
-                        }
-                        if (pi == en) break;
-                        offer_point<K>(set, qx, qy, qz, s_pts[pi]);
-                        ++pi;
-                    }
-                }
-                int outcome = settle_top<K>(g, set, qx, qy, qz, cx, cy, cz, 1);
-                if (outcome == 1) {  // ring 2: the shell of the 5×5×5 block — whole rows where |dy| or |dz| is 2, the two end cells elsewhere
-#pragma unroll 1
-                    for (int r = 0; r < 25; ++r) {
-                        const int dy = r % 5 - 2, dz = r / 5 - 2;
-                        const int row = ((lz + dz) * kStageEdge + (ly + dy)) * kStageEdge + lx;
-                        if (max(abs(dy), abs(dz)) == 2) {
-                            const uint32_t b = s_lstart[row - 2], en = s_lstart[row + 3];
-                            for (uint32_t pi = b; pi < en; ++pi) offer_point<K>(set, qx, qy, qz, s_pts[pi]);
-                        } else {
-                            // end cells x = lx − 2 and lx + 2; the row's uniform loop already offered the cells 1..6
-                            if (!(have_union && lx - 2 >= 1)) {
-                                const uint32_t b = s_lstart[row - 2], en = s_lstart[row - 1];
-                                for (uint32_t pi = b; pi < en; ++pi) offer_point<K>(set, qx, qy, qz, s_pts[pi]);
-                            }
-                            if (!(have_union && lx + 2 <= 6)) {
-                                const uint32_t b = s_lstart[row + 2], en = s_lstart[row + 3];
-                                for (uint32_t pi = b; pi < en; ++pi) offer_point<K>(set, qx, qy, qz, s_pts[pi]);
-                            }
-                        }
-                    }
-                    outcome = settle_top<K>(g, set, qx, qy, qz, cx, cy, cz, 2);
-                }
-                const bool tie = set.finish();
-                if (outcome == 0 && !tie) {
-#pragma unroll
-                    for (int jj = 0; jj < K; ++jj) nn[(size_t)jj * nn_pitch + gi] = set.id[jj];
-                    return false;
-                }
-                return true;  // the tree answers
-            };
-            auto load_query = [&](uint32_t gi, float& qx, float& qy, float& qz, int& cx, int& cy, int& cz) {
-                const int scan = (int)(gi / (uint32_t)max_n);
-                const float4 p = src[gi];
-                const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
-                qx = (float)qs.x; qy = (float)qs.y; qz = (float)qs.z;
-                cx = cell_coord(qx, g.ox, g.inv_cell); cy = cell_coord(qy, g.oy, g.inv_cell); cz = cell_coord(qz, g.oz, g.inv_cell);
-            };
-
-            // ---- dense rows: the queries of one (y, z) row of the tile share their candidates — the 6×3×3 cells around the row — so a
-            // wave walks them in a UNIFORM loop (one broadcast LDS read per leaf, no per-lane run bookkeeping, no longest-lane tax)
-            uint32_t dense_mask = 0;
-            if (fits && !(exp_flags & 1)) {
-                int rpos = pos;
-                while (rpos < end) {
-                    const uint32_t rkey = s_keys[rpos];
-                    int rend = rpos;
-                    for (;;) {
-                        const int idx = rend + lane;
-                        const unsigned long long m = __ballot(idx < end && s_keys[idx] == rkey);
-                        const int nz = (~m) ? __ffsll((long long)~m) - 1 : 64;
-                        rend += nz;
-                        if (nz < 64) break;
-                    }
-                    if (rend - rpos >= kDenseRow) {
-                        const int row = (int)(rkey % (uint32_t)kTileRows);
-                        dense_mask |= 1u << row;
-                        const int ly = (row % kGridTile) + kStageRing, lz = (row / kGridTile) + kStageRing;
-                        for (int j0 = rpos; j0 < rend; j0 += 64) {
-                            const int j = j0 + lane;
-                            const bool act = j < rend;
-                            uint32_t gi = 0;
-                            float qx = 0.f, qy = 0.f, qz = 0.f;
-                            int cx = 0, cy = 0, cz = 0;
-                            if (act) { gi = sorted[base + j].x; load_query(gi, qx, qy, qz, cx, cy, cz); }
-                            TopK<K> set;
-                            set.init();
-#pragma unroll 1
-                            for (int r = 0; r < 9; ++r) {
-                                const int id0 = ((lz + r / 3 - 1) * kStageEdge + (ly + r % 3 - 1)) * kStageEdge + 1;
-                                const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_lstart[id0]);
-                                const uint32_t en = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_lstart[id0 + 6]);
-                                for (uint32_t pi = b; pi < en; ++pi) offer_point<K>(set, qx, qy, qz, s_pts[pi]);
-                            }
-                            const bool to_tree = act && finish_query(gi, set, qx, qy, qz, cx, cy, cz, true);
-                            wave_append(tree_list, tree_count, to_tree, gi);
-                        }
-                    }
-                    rpos = rend;
-                }
-            }
-            // ---- the queries of sparse rows (and of blocks too large for the stage), 64 at a time, each lane walking its own cells
+            // ---- the run's queries, 64 at a time
             for (int j0 = pos; j0 < end; j0 += 64) {
                 const int j = j0 + lane;
-                bool mine = j < end;
-                if (mine && ((dense_mask >> (s_keys[j] % (uint32_t)kTileRows)) & 1u)) mine = false;
-                if (!__ballot(mine)) continue;
                 bool to_tree = false;
                 uint32_t gi = 0;
-                if (mine) {
+                if (j < end) {
                     gi = sorted[base + j].x;
                     to_tree = !fits;
                 }
-                if (mine && fits && !(exp_flags & 1)) {
-                    float qx, qy, qz;
-                    int cx, cy, cz;
-                    load_query(gi, qx, qy, qz, cx, cy, cz);
+                if (j < end && fits && !(exp_flags & 1)) {
+                    const int scan = (int)(gi / (uint32_t)max_n);
+                    const float4 p = src[gi];
+                    const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
+                    const float qx = (float)qs.x, qy = (float)qs.y, qz = (float)qs.z;
+                    const int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
+                    const int lx = cx - tx * kGridTile + kStageRing, ly = cy - ty * kGridTile + kStageRing, lz = cz - tz * kGridTile + kStageRing;  // 2..5
                     TopK<K> set;
                     set.init();
-                    to_tree = finish_query(gi, set, qx, qy, qz, cx, cy, cz, false);
+                    {   // ring 1: nine rows of three consecutive cells, walked as ONE loop (a lane switches rows when its run ends)
+                        int r = 0;
+                        const int id00 = ((lz - 1) * kStageEdge + (ly - 1)) * kStageEdge + (lx - 1);
+                        uint32_t pi = s_lstart[id00], en = s_lstart[id00 + 3];
+                        for (;;) {
+                            while (pi == en && r < 8) {
+                                ++r;
+                                const int id0 = id00 + (r / 3) * (kStageEdge * kStageEdge) + (r % 3) * kStageEdge;
+                                pi = s_lstart[id0]; en = s_lstart[id0 + 3];
+                            }
+                            if (pi == en) break;
+                            offer_point<K>(set, qx, qy, qz, s_pts[pi]);
+                            ++pi;
+                        }
+                    }
+                    int outcome = settle_top<K>(g, set, qx, qy, qz, cx, cy, cz, 1);
+                    if (outcome == 1) {  // ring 2: the shell of the 5×5×5 block — whole rows where |dy| or |dz| is 2, the two end cells elsewhere
+#pragma unroll 1
+                        for (int r = 0; r < 25; ++r) {
+                            const int dy = r % 5 - 2, dz = r / 5 - 2;
+                            const int row = ((lz + dz) * kStageEdge + (ly + dy)) * kStageEdge + lx;
+                            if (max(abs(dy), abs(dz)) == 2) {
+                                const uint32_t b = s_lstart[row - 2], en = s_lstart[row + 3];
+                                for (uint32_t pi = b; pi < en; ++pi) offer_point<K>(set, qx, qy, qz, s_pts[pi]);
+                            } else {
+                                uint32_t b = s_lstart[row - 2], en = s_lstart[row - 1];
+                                for (uint32_t pi = b; pi < en; ++pi) offer_point<K>(set, qx, qy, qz, s_pts[pi]);
+                                b = s_lstart[row + 2]; en = s_lstart[row + 3];
+                                for (uint32_t pi = b; pi < en; ++pi) offer_point<K>(set, qx, qy, qz, s_pts[pi]);
+                            }
+                        }
+                        outcome = settle_top<K>(g, set, qx, qy, qz, cx, cy, cz, 2);
+                    }
+                    const bool tie = set.finish();
+                    if (outcome == 0 && !tie) {
+#pragma unroll
+                        for (int jj = 0; jj < K; ++jj) nn[(size_t)jj * nn_pitch + gi] = set.id[jj];
+                    } else {
+                        to_tree = true;
+                    }
                 }
                 wave_append(tree_list, tree_count, to_tree, gi);
             }
@@ -521,17 +458,17 @@ static bool search_grid_k(const GridView& grid, const GridDev& g, const SearchAr
     // work lists: redo_list2 = queries for the fast tree traversal, redo_list = what that hands to the exact redo kernel
     (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);
     (void)hipMemsetAsync(a.redo_count2, 0, sizeof(unsigned int), s);
-    (void)hipMemsetAsync(grid.tile_count, 0, ((size_t)grid.n_keys + 1) * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(grid.tile_count, 0, ((size_t)grid.n_tocc + 1) * sizeof(uint32_t), s);
     hipLaunchKernelGGL((grid_bin_count_kernel<K>), blocks, dim3(kBlock), 0, s, g, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.skip_nonfinite, sc.qkey,
                        grid.tile_count, a.redo_list2, a.redo_count2, a.search_stats);
     size_t tb = grid.scan_temp_bytes;
-    if (hipcub::DeviceScan::ExclusiveSum(grid.scan_temp, tb, grid.tile_count, grid.tile_count, (int)(grid.n_keys + 1), s) != hipSuccess) return false;
+    if (hipcub::DeviceScan::ExclusiveSum(grid.scan_temp, tb, grid.tile_count, grid.tile_count, (int)(grid.n_tocc + 1), s) != hipSuccess) return false;
     hipLaunchKernelGGL(grid_bin_scatter_kernel, blocks, dim3(kBlock), 0, s, a.counts, a.st, a.max_n, sc.qkey, grid.tile_count, sc.sorted);
     // after the scatter tile_count[t] = end of tile t's queries; the last entry (never incremented) still holds the total
     const size_t total_q = (size_t)a.max_n * a.n_scans;
     const unsigned waves = (unsigned)std::min<size_t>((total_q + kRangeQ - 1) / kRangeQ, 256u * 8u);
     static const int exp_flags = [] { const char* e = getenv("LOCGPU_GRID_EXP"); return e ? atoi(e) : 0; }();  // timing experiments only (results wrong)
-    hipLaunchKernelGGL((grid_tile_search_kernel<K>), dim3(waves), dim3(64), 0, s, g, sc.sorted, grid.tile_count + grid.n_keys, a.src, a.st, a.nn, a.nn_pitch,
+    hipLaunchKernelGGL((grid_tile_search_kernel<K>), dim3(waves), dim3(64), 0, s, g, sc.sorted, grid.tile_count + grid.n_tocc, a.src, a.st, a.nn, a.nn_pitch,
                        a.max_n, a.redo_list2, a.redo_count2, exp_flags);
     return launch_icp_search_list(a, a.redo_list2, a.redo_count2, s);  // a.alpha_eff = 1: exact pruning
 }

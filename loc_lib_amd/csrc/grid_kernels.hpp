@@ -19,7 +19,6 @@ namespace locgpu {
 
 constexpr int kGridTile = 4;                    // cells per tile edge
 constexpr int kTileCells = kGridTile * kGridTile * kGridTile;
-constexpr int kTileRows = kGridTile * kGridTile;  // (y, z) rows of cells in a tile: the queries of one iteration are binned by (tile, row)
 constexpr uint32_t kEmptyCell = 0xFFFFFFFFu;
 
 struct TileRec {
@@ -34,7 +33,6 @@ struct GridView {
     uint32_t tile_mask = 0;
     const TileRec* tiles = nullptr;    // [n_tocc]
     uint32_t n_tocc = 0;               // occupied tiles
-    uint32_t n_keys = 0;               // binning keys = n_tocc · kTileRows
     const float4* pts = nullptr;       // leaves sorted by (tile, cell)
     int dims[3] = {0, 0, 0};           // cells per axis
     int tdims[3] = {0, 0, 0};          // tiles per axis
@@ -42,7 +40,7 @@ struct GridView {
     float cell = 1.f, inv_cell = 1.f, slack = 0.f;
     size_t num_points = 0, num_cells = 0, bytes = 0;
     // per-iteration query binning (scratch owned by the context)
-    uint32_t* tile_count = nullptr;  // [n_keys + 1]
+    uint32_t* tile_count = nullptr;  // [n_tocc + 1]
     void* scan_temp = nullptr;
     size_t scan_temp_bytes = 0;
 };
@@ -62,8 +60,8 @@ hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, 
 void grid_free(GridBuffers& buf);
 
 struct GridSearchScratch {  // per batch: the queries of one iteration, binned by tile
-    uint32_t* qkey;     // [pitch] key of query gi: tile record · 16 + row (kEmptyCell: not binned)
-    uint2* sorted;      // [pitch] {gi, key} in key order
+    uint32_t* qkey;     // [pitch] tile key of query gi (kEmptyCell: not binned)
+    uint2* sorted;      // [pitch] {gi, tile key} in tile order
 };
 
 // Search stage of one GN iteration in grid mode: bin by tile → tile kernel (LDS-staged candidate blocks) → ring walk for the
