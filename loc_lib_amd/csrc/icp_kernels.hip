@@ -417,6 +417,37 @@ __global__ __launch_bounds__(kBlock) void icp_line_accum_kernel(const uint2* __r
     block_reduce_store<28>(acc, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
 }
 
+// Sum of the block partials of one scan, per column, in a fixed order (chunk c takes rows c, c + 8, …; the chunks are then added in
+// order). Eight loads are in flight per thread: a single-scan alignment has 450 rows, and a row-by-row load → add chain made this the
+// longest part of the solve kernel. Returns the column total in threads 0..kAccW-1 (0 elsewhere). Ends with the block synchronised.
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ rows, int blocks_per_scan, bool mine, double (*s_sum)[kAccW]) {
+    const int col = threadIdx.x & (kAccW - 1), chunk = threadIdx.x / kAccW;
+    constexpr int kChunks = kBlock / kAccW;
+    double s = 0.0;
+    if (mine && col < 28) {
+        for (int b = chunk; b < blocks_per_scan; b += kChunks * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = b + u * kChunks;
+                v[u] = idx < blocks_per_scan ? rows[(size_t)idx * kAccW + col] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    }
+    s_sum[chunk][col] = s;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x < kAccW) {
+        t = s_sum[0][threadIdx.x];
+#pragma unroll
+        for (int c = 1; c < kChunks; ++c) t += s_sum[c][threadIdx.x];
+    }
+    __syncthreads();
+    return t;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K3: one 256-thread block per scan. Sums the block partials in a fixed order, then thread 0 runs the
 // reference's checks and update (icp_registration.cpp:204-211 + 362-375; ndt_registration.cpp:435-459).
@@ -430,20 +461,12 @@ __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restri
     // search instead of paying two fill launches per iteration (a single-scan alignment is launch-latency bound).
     if (list_counts && scan == 0 && threadIdx.x < 2) list_counts[threadIdx.x] = 0u;
     if (st[scan].done) return;
-    const int col = threadIdx.x & (kAccW - 1), chunk = threadIdx.x / kAccW;
-    constexpr int kChunks = kBlock / kAccW;
-    double s = 0.0;
-    if (col < 28)
-        for (int b = chunk; b < blocks_per_scan; b += kChunks) s += partials[((size_t)scan * blocks_per_scan + b) * kAccW + col];
-    s_sum[chunk][col] = s;
+    const double col_total = reduce_partials(partials + (size_t)scan * blocks_per_scan * kAccW, blocks_per_scan, true, s_sum);
+    if (threadIdx.x < kAccW) s_sum[0][threadIdx.x] = col_total;
     __syncthreads();
     if (threadIdx.x != 0) return;
     double tot[28];
-    for (int v = 0; v < 28; ++v) {
-        double t = s_sum[0][v];
-        for (int c = 1; c < kChunks; ++c) t += s_sum[c][v];
-        tot[v] = t;
-    }
+    for (int v = 0; v < 28; ++v) tot[v] = s_sum[0][v];
     double H[36], B[6], dx[6] = {0, 0, 0, 0, 0, 0};
     int o = 0;
     for (int i = 0; i < 6; ++i)
@@ -500,20 +523,10 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* __re
                                                               int first, int n_local, double* __restrict__ acc) {
     __shared__ double s_sum[kBlock / kAccW][kAccW];
     const int g = blockIdx.x;
-    const int col = threadIdx.x & (kAccW - 1), chunk = threadIdx.x / kAccW;
-    constexpr int kChunks = kBlock / kAccW;
     const int scan = g - first;
     const bool mine = scan >= 0 && scan < n_local && !st_all[g].done;  // a finished scan's partials are stale: contribute zeros (nobody reads them)
-    double s = 0.0;
-    if (mine && col < 28)
-        for (int b = chunk; b < blocks_per_scan; b += kChunks) s += partials[((size_t)scan * blocks_per_scan + b) * kAccW + col];
-    s_sum[chunk][col] = s;
-    __syncthreads();
-    if (threadIdx.x < kAccW) {
-        double t = s_sum[0][threadIdx.x];
-        for (int c = 1; c < kChunks; ++c) t += s_sum[c][threadIdx.x];
-        acc[(size_t)g * kAccW + threadIdx.x] = threadIdx.x < 28 ? t : 0.0;
-    }
+    const double t = reduce_partials(partials + (size_t)(mine ? scan : 0) * blocks_per_scan * kAccW, blocks_per_scan, mine, s_sum);
+    if (threadIdx.x < kAccW) acc[(size_t)g * kAccW + threadIdx.x] = threadIdx.x < 28 ? t : 0.0;
 }
 
 // pcl::transformPointCloud with the float32 4×4 (icp_registration.cpp:241): ((m0·x + m1·y) + m2·z) + m3 per row.
