@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--method", default="p2plane")
     ap.add_argument("--workdir", default=os.path.join(ROOT, "gpurun_out", "traffic"))
     a = ap.parse_args()
-    bench_args = ["--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--scans-per-gpu", str(a.scans_per_gpu), "--map-points",
+    bench_args = ["--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--traffic", "none", "--scans-per-gpu", str(a.scans_per_gpu), "--map-points",
                   str(a.map_points), "--method", a.method]
     fetch = run_pass("FETCH_SIZE", os.path.join(a.workdir, "fetch"), bench_args)
     write = run_pass("WRITE_SIZE", os.path.join(a.workdir, "write"), bench_args)
