@@ -39,6 +39,7 @@ bool ensure_resources(locgpu_batch* b) {
     const int n_slots = u.n_threads * BatchUploader::kSlotsPerThread;
     u.h_slots.assign(n_slots, nullptr);
     u.slot_ev.assign(n_slots, nullptr);
+    u.slot_busy.assign(n_slots, 0);
     for (int i = 0; i < n_slots; ++i)
         if (!hip_ok(ctx, hipHostMalloc((void**)&u.h_slots[i], BatchUploader::kSlotPoints * sizeof(float4)), "upload: hipHostMalloc slot") ||
             !hip_ok(ctx, hipEventCreateWithFlags(&u.slot_ev[i], hipEventDisableTiming), "upload: hipEventCreate"))
@@ -57,16 +58,16 @@ void run_upload(locgpu_batch* b) {
     std::atomic<int> failed{0};
     auto packer = [&](int t) {
         (void)hipSetDevice(b->ctx->device);
-        int used[BatchUploader::kSlotsPerThread] = {0, 0};
         int turn = 0;
         for (size_t i = next.fetch_add(1); i < units.size() && !failed.load(); i = next.fetch_add(1)) {
             const Unit& w = units[i];
             const int slot = t * BatchUploader::kSlotsPerThread + turn;
-            if (used[turn] && hipEventSynchronize(u.slot_ev[slot]) != hipSuccess) { failed = 1; break; }  // the slot's previous copy has left it
+            // the slot's previous copy — of this upload or of the one before — has left it
+            if (u.slot_busy[slot] && hipEventSynchronize(u.slot_ev[slot]) != hipSuccess) { failed = 1; break; }
             pack_points((const char*)u.srcs[w.scan] + w.off * u.stride, u.stride, w.len, u.h_slots[slot]);
             if (hipMemcpyAsync(b->d_src + (size_t)w.scan * b->max_n + w.off, u.h_slots[slot], w.len * sizeof(float4), hipMemcpyHostToDevice, u.stream) != hipSuccess ||
                 hipEventRecord(u.slot_ev[slot], u.stream) != hipSuccess) { failed = 1; break; }
-            used[turn] = 1;
+            u.slot_busy[slot] = 1;
             turn = (turn + 1) % BatchUploader::kSlotsPerThread;
         }
     };

@@ -24,6 +24,7 @@ struct BatchUploader {
     int n_threads = 0;
     std::vector<float4*> h_slots;  // n_threads × kSlotsPerThread pinned slots
     std::vector<hipEvent_t> slot_ev;
+    std::vector<char> slot_busy;   // the slot's event has been recorded: its last copy may still be reading it (kept across uploads)
     int* h_counts = nullptr;       // pinned copy of the per-scan point counts
     std::thread worker;
     bool worker_active = false;
