@@ -97,6 +97,8 @@ int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts,
     if (!b->up) b->up = new BatchUploader();
     if (!ensure_resources(b)) return LOCGPU_ERR_OOM;
     BatchUploader& u = *b->up;
+    // One upload of a batch at a time, end to end: the previous one's copies (same destination, same pinned counts) have landed.
+    if (u.done_valid && !hip_ok(ctx, hipEventSynchronize(u.done), "batch upload: previous upload")) return LOCGPU_ERR_NO_DEVICE;
     // The previous contents of the source array may still be read by kernels enqueued on the compute stream (an align call
     // always synchronises before it returns, so in practice the stream is idle): order the copies behind them.
     hipEvent_t ev = nullptr;
