@@ -99,60 +99,6 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
     }
 }
 
-// K1 fast path, two queries per lane (tree_knn_fast2): workgroup = one wave = 128 consecutive points of one scan.
-template <int K, int DF>
-__global__ __launch_bounds__(64) void icp_search_fast2_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
-                                                              const int* __restrict__ counts, const PoseState* __restrict__ st,
-                                                              uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, float alpha_eff, int T,
-                                                              unsigned int tree_bytes, int skip_nonfinite, uint32_t* __restrict__ redo_list,
-                                                              unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats) {
-    __shared__ uint2 s_stackA[DF][64];
-    __shared__ uint2 s_stackB[DF][64];
-    const int scan = blockIdx.y;
-    if (st[scan].done) return;
-    const int tid = threadIdx.x;
-    const int n = counts[scan];
-    const int iA = blockIdx.x * 128 + tid, iB = iA + 64;
-    if (iA >= n) return;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
-    FastQ<K> q[2];
-    size_t gi[2] = {(size_t)scan * max_n + iA, (size_t)scan * max_n + iB};
-    bool valid[2] = {true, iB < n};
-    bool presl[2] = {false, false};  // straight to the exact kernel (query not finite / astronomically far)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        q[h].qx = q[h].qy = q[h].qz = 0.f;
-        if (!valid[h]) continue;
-        const float4 p = src[gi[h]];
-        if (skip_nonfinite && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {  // pcl::isFinite, icp cpp:64 (P2P only)
-#pragma unroll
-            for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi[h]] = kInvalidSlot;
-            valid[h] = false;
-            continue;
-        }
-        const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
-        q[h].qx = (float)qs.x; q[h].qy = (float)qs.y; q[h].qz = (float)qs.z;
-        presl[h] = !(fabsf(q[h].qx) < 1e18f && fabsf(q[h].qy) < 1e18f && fabsf(q[h].qz) < 1e18f);
-    }
-    if (search_stats) atomicAdd(&search_stats[0], (unsigned long long)((valid[0] ? 1 : 0) + (valid[1] ? 1 : 0)));
-    // a query that must not run the fast traversal is replaced by a harmless one (the origin) and its result discarded
-    const bool runA = valid[0] && !presl[0], runB = valid[1] && !presl[1];
-    if (!runA) { q[0].qx = q[0].qy = q[0].qz = 0.f; }
-    if (!runB) { q[1].qx = q[1].qy = q[1].qz = 0.f; }
-    const uint32_t slow = tree_knn_fast2<K, DF, 64>(rsrc, alpha_eff, T, s_stackA, s_stackB, tid, q[0], q[1], runB);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (!valid[h]) continue;
-        const bool redo = presl[h] || ((slow >> h) & 1u);
-        if (redo) {
-            redo_list[atomicAdd(redo_count, 1u)] = (uint32_t)gi[h];
-        } else {
-#pragma unroll
-            for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi[h]] = q[h].set.id[j];
-        }
-    }
-}
-
 // The fast traversal over a LIST of queries (grid mode: what the tile kernel could not settle, with alpha_eff = 1). One-wave
 // workgroups, grid-stride over the list whose length lives on the device. Queries it cannot finish go to redo_list as usual.
 template <int K, int DF>
@@ -669,15 +615,6 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         static const int small_lanes = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); const int v = e ? atoi(e) : 16; return (v == 16 || v == 32) ? v : 64; }();
         // fewer than 2048 full waves (one or two scans): half-filled waves, see the kernel
         const int lanes = (blk == 64 && (size_t)((a.max_n + 63) / 64) * a.n_scans <= 2048) ? small_lanes : blk;
-        static const int dual = [] { const char* e = getenv("LOCGPU_FAST_DUAL"); return e ? atoi(e) : 1; }();  // two queries per lane for launches that fill the chip
-        if (blk == 64 && lds_pad == 0 && ((dual == 1 && lanes == 64) || dual == 2)) {  // LOCGPU_FAST_DUAL=2: also for small launches (tests)
-            dim3 g3((a.max_n + 127) / 128, a.n_scans);
-            hipLaunchKernelGGL((icp_search_fast2_kernel<K, DF>), g3, dim3(64), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                               a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats);
-            hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
-                               a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
-            return;
-        }
         dim3 g2((a.max_n + lanes - 1) / lanes, a.n_scans);
         if (blk == 64)
             hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 64>), g2, dim3(64), lds_pad, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,

@@ -474,169 +474,6 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
     return slow != 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// TWO queries per lane through the same fast traversal (tree_knn_fast, above — same decisions, same visit order, same rare-case
-// flags): lane l of a wave answers points base + l and base + 64 + l. The loop is bound by instruction issue, and ≈40 % of a
-// trip's instructions are scalar (lane-mask bookkeeping of the divergent regions, loop control, waits) that do not depend on how
-// much vector work the trip carries: with two independent traversals interleaved in one loop that overhead is paid once per two
-// node visits, and each query's dependent load has the other query's arithmetic to hide behind.
-template <int K>
-struct FastQ {
-    float qx, qy, qz;
-    SortedSet<K> set;
-    int sp, T;
-    uint32_t cur;
-    float min_drop;
-    uint32_t slow, live, need_pop, at_leaf;
-};
-
-template <int K, int DF, int BLK>
-__device__ __forceinline__ void fast_descend_step(__amdgpu_buffer_rsrc_t tree_rsrc, uint2 (*s_stack)[BLK], int tid, FastQ<K>& s) {
-    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(tree_rsrc, (int)(s.cur << 3), 0, 0);
-    const uint32_t meta = w.y;
-    const uint32_t tag = meta >> 30;
-    if (tag == 3u) { s.at_leaf = 1u; return; }
-    const float th = as_f32(w.x);
-    const float qa = tag == 0u ? s.qx : (tag == 1u ? s.qy : s.qz);
-    const float dd = qa - th;
-    const float d2 = dd * dd;
-    const uint32_t right = meta & 0x3FFFFFFFu;
-    const bool go_left = qa < th;
-    if (s.sp < s.T) {
-        s.min_drop = d2 < s.min_drop ? d2 : s.min_drop;
-    } else if (s.sp - s.T < DF) {
-        s_stack[s.sp - s.T][tid] = make_uint2(go_left ? right : s.cur + 1u, __float_as_uint(d2));
-    } else {
-        s.slow = 1;
-    }
-    s.sp++;
-    s.cur = go_left ? s.cur + 1u : right;
-}
-
-template <int K, int DF, int BLK>
-__device__ __forceinline__ void fast_main_step(__amdgpu_buffer_rsrc_t tree_rsrc, float alpha_eff, uint2 (*s_stack)[BLK], int tid, FastQ<K>& s) {
-    SortedSet<K>& set = s.set;
-    if (!s.need_pop) {  // ------------------------------------------------ VISIT one node (see tree_knn_fast)
-        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(tree_rsrc, (int)(s.cur << 3), 0, 0);
-        const uint32_t meta = w.y;
-        const uint32_t tag = meta >> 30;
-        const bool is_leaf = tag == 3u;
-        const float top = set.top();
-        if (is_leaf) {
-            const float dx = s.qx - as_f32(w.x), dy = s.qy - as_f32(w.z), dz = s.qz - as_f32(w.w);
-            const float dis2 = dx * dx + (dy * dy + dz * dz);
-            const bool ins = dis2 < top;
-            set.d[K - 1] = ins ? dis2 : set.d[K - 1];
-            set.id[K - 1] = ins ? s.cur : set.id[K - 1];
-#pragma unroll
-            for (int j = K - 1; j > 0; --j) {
-                const bool sw = set.d[j] < set.d[j - 1];
-                const float lo = sw ? set.d[j] : set.d[j - 1], hi = sw ? set.d[j - 1] : set.d[j];
-                const uint32_t ilo = sw ? set.id[j] : set.id[j - 1], ihi = sw ? set.id[j - 1] : set.id[j];
-                set.d[j - 1] = lo; set.d[j] = hi; set.id[j - 1] = ilo; set.id[j] = ihi;
-            }
-            s.slow |= (ins && top == set.d[K - 1] && top < __builtin_inff()) ? 1u : 0u;
-        }
-        const float th = as_f32(w.x);
-        const float qa = tag == 0u ? s.qx : (tag == 1u ? s.qy : s.qz);
-        const float dd = qa - th;
-        const float d2 = dd * dd;
-        const uint32_t right = meta & 0x3FFFFFFFu;
-        const bool go_left = qa < th;
-        const uint32_t far_slot = go_left ? right : s.cur + 1u;
-        const bool push = !is_leaf && d2 < top * alpha_eff;
-        const int idx = s.sp - s.T;
-        const bool drop = push && idx < 0;
-        const bool store = push && (unsigned)idx < (unsigned)DF;
-        s.slow |= (push && idx >= DF) ? 1u : 0u;
-        s.min_drop = (drop && d2 < s.min_drop) ? d2 : s.min_drop;
-        if (store) s_stack[idx][tid] = make_uint2(far_slot, __float_as_uint(d2));
-        s.sp += push ? 1 : 0;
-        s.need_pop = is_leaf ? 1u : 0u;
-        s.cur = go_left ? s.cur + 1u : right;
-    }
-    if (s.need_pop) {  // ------------------------------------------------- POP (see tree_knn_fast)
-        const float bound = set.top() * alpha_eff;
-        const int avail = s.sp - s.T;
-        if (avail <= 0) {
-            const bool may_pass = s.sp > 0 && !(s.min_drop >= bound);
-            s.live = may_pass ? 1u : 0u;
-            if (may_pass) {
-                const int levels = s.sp;
-                uint32_t c = 0;
-                s.sp = 0;
-                s.T = 0;
-                for (int l = 0; l < levels; ++l) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(tree_rsrc, (int)(c << 3), 0, 0);
-                    const uint32_t tg = v.y >> 30;
-                    const float th = as_f32(v.x);
-                    const float qa = tg == 0u ? s.qx : (tg == 1u ? s.qy : s.qz);
-                    const float dd = qa - th;
-                    const float d2 = dd * dd;
-                    const uint32_t right = v.y & 0x3FFFFFFFu;
-                    const bool go_left = qa < th;
-                    if (d2 < bound) {
-                        if (s.sp < DF) s_stack[s.sp][tid] = make_uint2(go_left ? right : c + 1u, __float_as_uint(d2));
-                        else s.slow = 1;
-                        s.sp++;
-                    }
-                    c = go_left ? c + 1u : right;
-                }
-                s.min_drop = __builtin_inff();
-            }
-        } else {
-            const uint32_t* s32 = reinterpret_cast<const uint32_t*>(&s_stack[0][0]);
-            float ed2[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = avail - 1 - j >= 0 ? avail - 1 - j : 0;
-                ed2[j] = __uint_as_float(s32[(row * BLK + tid) * 2 + 1]);
-            }
-            int hit = 4;
-#pragma unroll
-            for (int j = 3; j >= 0; --j) hit = (j < avail && ed2[j] < bound) ? j : hit;
-            const int row_hit = avail - 1 - hit >= 0 ? avail - 1 - hit : 0;
-            const uint32_t far_hit = s32[(row_hit * BLK + tid) * 2];
-            const bool found = hit < 4;
-            const int used = found ? hit + 1 : (avail < 4 ? avail : 4);
-            s.sp -= used;
-            s.cur = found ? far_hit : s.cur;
-            s.need_pop = found ? 0u : 1u;
-        }
-    }
-    s.live = s.slow ? 0u : s.live;
-}
-
-// Runs both queries to completion; returns bit 0 / bit 1 set when query A / B must be redone by the exact kernel.
-// validB = false: the lane has only query A.
-template <int K, int DF, int BLK>
-__device__ __forceinline__ uint32_t tree_knn_fast2(__amdgpu_buffer_rsrc_t tree_rsrc, float alpha_eff, int T, uint2 (*stackA)[BLK], uint2 (*stackB)[BLK],
-                                                   int tid, FastQ<K>& a, FastQ<K>& b, bool validB) {
-    a.set.init(); b.set.init();
-    a.sp = b.sp = 0; a.T = b.T = T;
-    a.cur = b.cur = 0;
-    a.min_drop = b.min_drop = __builtin_inff();
-    a.slow = b.slow = 0; a.need_pop = b.need_pop = 0;
-    a.at_leaf = 0; b.at_leaf = validB ? 0u : 1u;
-    // first descents, interleaved (two independent loads in flight per trip)
-    while (!(a.at_leaf & b.at_leaf)) {
-        if (!a.at_leaf) fast_descend_step<K, DF, BLK>(tree_rsrc, stackA, tid, a);
-        if (!b.at_leaf) fast_descend_step<K, DF, BLK>(tree_rsrc, stackB, tid, b);
-    }
-    a.live = a.slow ^ 1u;
-    b.live = validB ? (b.slow ^ 1u) : 0u;
-    while (a.live | b.live) {
-        if (a.live) fast_main_step<K, DF, BLK>(tree_rsrc, alpha_eff, stackA, tid, a);
-        if (b.live) fast_main_step<K, DF, BLK>(tree_rsrc, alpha_eff, stackB, tid, b);
-    }
-#pragma unroll
-    for (int j = 0; j + 1 < K; ++j) {  // equal distances in the final set: std::priority_queue's pop order is layout-dependent
-        a.slow |= a.set.d[j] == a.set.d[j + 1] ? 1u : 0u;
-        b.slow |= b.set.d[j] == b.set.d[j + 1] ? 1u : 0u;
-    }
-    return (a.slow ? 1u : 0u) | ((validB && b.slow) ? 2u : 0u);
-}
-
 // Pops the heap into ascending-distance order (kdtree.cpp:160-165).
 template <int KMAX>
 __device__ __forceinline__ void heap_to_sorted(KnnHeap<KMAX>& heap, uint32_t (&out)[KMAX], int& count) {
