@@ -365,3 +365,38 @@ def test_bfnn_matches_brute_force(gpu_ctx, api, locref, small_world, k):
         with pytest.raises(api.LocGpuError) as e:
             gpu_ctx.bfnn_knn(ql, k=k)
         assert e.value.code == -4
+
+
+# ----------------------------------------------------------------------------------------------- bench.py contract
+@pytest.mark.parametrize("mode", ["weak_streaming", "resident", "strong"])
+def test_bench_line_contract(mode):
+    """bench.py on a reduced workload (1 M-pt map, 8 scans): exactly one JSON line with the keys the driver and the judge read;
+    the streaming default really has the scan copy inside the timed region; the strong mode runs the sharded batch over RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--map-points", "1000000", "--no-cpu-baseline",
+           "--traffic", "none"]
+    if mode == "strong":
+        cmd += ["--scaling", "strong", "--total-scans", "8"]
+    else:
+        cmd += ["--scans-per-gpu", "8"] + (["--resident"] if mode == "resident" else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["unit"] == "scans/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["vs_baseline"] is None
+    assert d["scaling"] == ("strong" if mode == "strong" else "weak")
+    assert d["config"]["scan_h2d_in_timed_region"] == (mode != "resident")
+    assert d["h2d_bytes_per_step"] == (0 if mode == "resident" else 8 * 115200 * 16)
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-3 * d["value"]
+    assert d["median_translation_error_to_truth_m"] < 0.1
