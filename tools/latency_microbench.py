@@ -15,8 +15,11 @@ m = synth.make_map(int(os.environ.get("MAP_POINTS", 10_000_000)))
 ctx.icp_set_target(m)
 ctx.ndt_set_target(m)
 out = {}
+only = os.environ.get("LAT_ONLY")  # e.g. p2plane_eager: one leg only (for a kernel trace)
 for name in ("p2plane", "ndt"):
     for graph in (False, True):
+        if only and only != "%s_%s" % (name, "graph" if graph else "eager"):
+            continue
         ctx.graph_enable(graph)
         ts, its = [], []
         for sid in range(12):
@@ -36,6 +39,8 @@ for name in ("p2plane", "ndt"):
                                                                      scans_per_s=round(1.0 / float(np.mean(ts)), 1), mean_iters=float(np.mean(its)))
 # host-pointer path, what the façade's ScanMatch calls per scan: pack + H2D + align + D2H of the pose
 for graph in (False, True):
+    if only:
+        break
     ctx.graph_enable(graph)
     opts = api.icp_opts(method=api.P2PLANE)
     ts = []
