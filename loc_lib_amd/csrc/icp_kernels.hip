@@ -191,6 +191,8 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const uint2* __restri
 
 // ---------------------------------------------------------------------------------------------
 // Block reduction of `acc[0..NV)` → partials[block][0..NV). Wave butterfly, then LDS across the 4 waves.
+constexpr int kAccPad = kBlock + 2;  // LDS row stride of the plane kernel's point rows: consecutive rows four banks apart
+
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double* __restrict__ dst) {
     __shared__ double s_part[kBlock / 64][kAccW];
@@ -244,59 +246,97 @@ __device__ __forceinline__ void R_hat(const double* R, const D3& q, double (&Rh)
 
 
 // K2, P2Plane: IcpRegistration::CaculateMatrixHAndBP2Plane (icp_registration.cpp:161-213) + math::FitPlane (math_utils.h:112-136).
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void icp_plane_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_plane_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                  double max_plane_distance, double* __restrict__ partials, int kPlanePts) {
+    // The 28 sums (acc layout below) are NOT kept per thread — 56 VGPRs that would be live across the whole plane fit and cap the
+    // kernel at three waves per SIMD. Every thread leaves its point's row {J0..J5, -e, fit} in LDS; thread (entry, slice) then adds
+    // the products of its entry over its slice of the block's 256 rows: the same 28 FMAs per point and thread, one accumulator.
+    __shared__ double s_row[8][kAccPad];
+    __shared__ double s_slice[kBlock / 32][32];
     const int scan = blockIdx.y;
     if (st[scan].done) return;  // uniform per block
-    double acc[28];
+    const int tid = threadIdx.x;
+    const int ent = tid & 31, slice = tid >> 5;
+    // entry → the two row components it multiplies: 0..20 upper triangle of JᵀJ, 21..26 J·(−e), 27 fit·fit (a count), 28..31 idle
+    int ra = 7, rb = 7;
+    {
+        int o = 0;
 #pragma unroll
-    for (int v = 0; v < 28; ++v) acc[v] = 0.0;
-    // kPlanePts points per thread before the (≈500-instruction) 28-value wave reduction
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                if (o == ent) { ra = i; rb = j; }
+                ++o;
+            }
+        if (ent >= 21 && ent < 27) { ra = ent - 21; rb = 6; }
+    }
+    double sum = 0.0;
 #pragma unroll 1
     for (int pp = 0; pp < kPlanePts; ++pp) {
-    const int i = (blockIdx.x * kPlanePts + pp) * kBlock + threadIdx.x;
-    if (i < counts[scan]) {
-        const size_t gi = (size_t)scan * max_n + i;
-        const uint32_t s4 = nn[4 * nn_pitch + gi];
-        if (s4 != kInvalidSlot) {  // nn.size() > 3: k=5 yields 5 or (k > size_) none
-            const float4 p = src[gi];
-            const D3 q{(double)p.x, (double)p.y, (double)p.z};
-            const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
-            D3 nb[5];
+        const int i = (blockIdx.x * kPlanePts + pp) * kBlock + tid;
+        double J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double neg_e = 0.0, fitted = 0.0;
+        if (i < counts[scan]) {
+            const size_t gi = (size_t)scan * max_n + i;
+            const uint32_t s4 = nn[4 * nn_pitch + gi];
+            if (s4 != kInvalidSlot) {  // nn.size() > 3: k=5 yields 5 or (k > size_) none
+                const float4 p = src[gi];
+                const D3 q{(double)p.x, (double)p.y, (double)p.z};
+                const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
+                D3 nb[5];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, j == 4 ? s4 : nn[(size_t)j * nn_pitch + gi]);
-            double n4[4];
-            plane_null_vector(nb, n4);
-            const D3 n3{n4[0], n4[1], n4[2]};
-            bool fit = true;
+                for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, j == 4 ? s4 : nn[(size_t)j * nn_pitch + gi]);
+                double n4[4];
+                plane_null_vector(nb, n4);
+                const D3 n3{n4[0], n4[1], n4[2]};
+                bool fit = true;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const double err = dot3(n3, nb[j]) + n4[3];
-                if (err * err > 1e-2) fit = false;
-            }
-            if (fit) {
-                acc[27] += 1.0;  // effective_num++ before the residual gate (icp cpp:184)
-                const double dis = dot3(n3, qs) + n4[3];
-                if (!(fabs(dis) > max_plane_distance)) {
-                    const double* R = st[scan].R;
-                    double nR[3];
+                for (int j = 0; j < 5; ++j) {
+                    const double err = dot3(n3, nb[j]) + n4[3];
+                    if (err * err > 1e-2) fit = false;
+                }
+                if (fit) {
+                    fitted = 1.0;  // effective_num++ before the residual gate (icp cpp:184)
+                    const double dis = dot3(n3, qs) + n4[3];
+                    if (!(fabs(dis) > max_plane_distance)) {
+                        const double* R = st[scan].R;
+                        double nR[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) nR[c] = (-n3.x * R[c] + -n3.y * R[3 + c]) + -n3.z * R[6 + c];
-                    double J[1][6];
-                    J[0][0] = nR[1] * q.z - nR[2] * q.y;
-                    J[0][1] = nR[2] * q.x - nR[0] * q.z;
-                    J[0][2] = nR[0] * q.y - nR[1] * q.x;
-                    J[0][3] = n3.x; J[0][4] = n3.y; J[0][5] = n3.z;
-                    const double e[1] = {dis};
-                    add_rows<1>(acc, J, e);
+                        for (int c = 0; c < 3; ++c) nR[c] = (-n3.x * R[c] + -n3.y * R[3 + c]) + -n3.z * R[6 + c];
+                        J[0] = nR[1] * q.z - nR[2] * q.y;
+                        J[1] = nR[2] * q.x - nR[0] * q.z;
+                        J[2] = nR[0] * q.y - nR[1] * q.x;
+                        J[3] = n3.x; J[4] = n3.y; J[5] = n3.z;
+                        neg_e = -dis;
+                    }
                 }
             }
         }
+        if (pp) __syncthreads();  // the previous round's rows have been consumed
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s_row[c][tid] = J[c];
+        s_row[6][tid] = neg_e;
+        s_row[7][tid] = fitted;
+        __syncthreads();
+        if (ent < 28) {
+#pragma clang fp contract(fast)
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {  // rows slice, slice + 8, …: neighbouring slices read neighbouring LDS banks
+                const int col = k * (kBlock / 32) + slice;
+                sum += s_row[ra][col] * s_row[rb][col];
+            }
+        }
     }
+    s_slice[slice][ent] = sum;
+    __syncthreads();
+    if (tid < 28) {
+        double s = s_slice[0][tid];
+#pragma unroll
+        for (int w = 1; w < kBlock / 32; ++w) s += s_slice[w][tid];
+        partials[((size_t)scan * gridDim.x + blockIdx.x) * kAccW + tid] = s;
     }
-    block_reduce_store<28>(acc, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
 }
 
 // K2', P2P: CaculateMatrixHAndBP2P (icp_registration.cpp:57-103), including the /16 on the rotation block.
@@ -716,10 +756,12 @@ bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, i
 
 int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
     const int blocks = (a.max_n + kBlock - 1) / kBlock;
-    // points per thread: amortise the wave reduction when the batch already fills the chip; 1 for small launches (latency)
+    // points per thread: amortise the block reduction when the batch already fills the chip; 1 for small launches (latency).
+    // The plane kernel's reduction is cheap (LDS rows, see there): 4 is as good as 8 and leaves a finer tail; the line and point
+    // kernels still pay a 28-value wave reduction per block.
     static const int forced = [] { const char* e = getenv("LOCGPU_PLANE_PTS"); return e ? atoi(e) : 0; }();
     const long total_blocks = (long)blocks * a.n_scans;
-    int pts = forced > 0 ? forced : (total_blocks >= 8192 ? 8 : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1)));
+    int pts = forced > 0 ? forced : (total_blocks >= 8192 ? (method == 2 ? 4 : 8) : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1)));
     if (pts > 8) pts = 8;
     const dim3 grid((blocks + pts - 1) / pts, a.n_scans);
     if (method == 2)
