@@ -191,8 +191,6 @@ __global__ __launch_bounds__(kBlock) void knn_query_kernel(const uint2* __restri
 
 // ---------------------------------------------------------------------------------------------
 // Block reduction of `acc[0..NV)` → partials[block][0..NV). Wave butterfly, then LDS across the 4 waves.
-constexpr int kAccPad = kBlock + 2;  // LDS row stride of the plane kernel's point rows: consecutive rows four banks apart
-
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NV], double* __restrict__ dst) {
     __shared__ double s_part[kBlock / 64][kAccW];
@@ -234,6 +232,66 @@ __device__ __forceinline__ void add_rows(double (&acc)[28], const double (&J)[RO
     }
 }
 
+// Block-cooperative form of add_rows (the plane and line kernels). Keeping the 28 sums per thread costs 56 VGPRs that are live across
+// the whole plane/line fit and cap those kernels at three waves per SIMD. Instead every thread leaves its point's row
+// {J0..J5, -e, fit} in LDS, and thread (entry, slice) adds the products of ITS entry over its slice of the block's 256 rows: the
+// same 28 FMAs per point and thread, one accumulator. Entry → the two row components it multiplies: 0..20 the upper triangle of
+// JᵀJ, 21..26 J·(−e), 27 fit·fit (a count), 28..31 idle. Every thread of the block must call add()/store() (barriers inside).
+constexpr int kAccPad = kBlock + 2;  // LDS row stride: consecutive rows four banks apart
+struct RowAccum {
+    int ent, slice, ra, rb;
+    double sum;
+    bool used;
+    __device__ __forceinline__ void init() {
+        ent = threadIdx.x & 31;
+        slice = threadIdx.x >> 5;
+        ra = 7; rb = 7;
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                if (o == ent) { ra = i; rb = j; }
+                ++o;
+            }
+        if (ent >= 21 && ent < 27) { ra = ent - 21; rb = 6; }
+        sum = 0.0;
+        used = false;
+    }
+    template <int ROWS>
+    __device__ __forceinline__ void add(double (&s_row)[8][kAccPad], const double (&J)[ROWS][6], const double (&neg_e)[ROWS], double fitted) {
+#pragma clang fp contract(fast)
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            if (used) __syncthreads();  // the previous rows have been consumed
+            used = true;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) s_row[c][tid] = J[r][c];
+            s_row[6][tid] = neg_e[r];
+            s_row[7][tid] = r == 0 ? fitted : 0.0;
+            __syncthreads();
+            if (ent < 28) {
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) {  // rows slice, slice + 8, …: neighbouring slices read neighbouring LDS banks
+                    const int col = k * (kBlock / 32) + slice;
+                    sum += s_row[ra][col] * s_row[rb][col];
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(double (&s_slice)[kBlock / 32][32], double* __restrict__ dst) {
+        s_slice[slice][ent] = sum;
+        __syncthreads();
+        if (threadIdx.x < 28) {
+            double t = s_slice[0][threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < kBlock / 32; ++w) t += s_slice[w][threadIdx.x];
+            dst[threadIdx.x] = t;
+        }
+    }
+};
+
 // R·hat(q), coefficient order of the oracle's left-to-right 3×3 product (zeros of hat() drop out exactly).
 __device__ __forceinline__ void R_hat(const double* R, const D3& q, double (&Rh)[3][3]) {
 #pragma unroll
@@ -250,34 +308,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                  double max_plane_distance, double* __restrict__ partials, int kPlanePts) {
-    // The 28 sums (acc layout below) are NOT kept per thread — 56 VGPRs that would be live across the whole plane fit and cap the
-    // kernel at three waves per SIMD. Every thread leaves its point's row {J0..J5, -e, fit} in LDS; thread (entry, slice) then adds
-    // the products of its entry over its slice of the block's 256 rows: the same 28 FMAs per point and thread, one accumulator.
     __shared__ double s_row[8][kAccPad];
     __shared__ double s_slice[kBlock / 32][32];
     const int scan = blockIdx.y;
     if (st[scan].done) return;  // uniform per block
     const int tid = threadIdx.x;
-    const int ent = tid & 31, slice = tid >> 5;
-    // entry → the two row components it multiplies: 0..20 upper triangle of JᵀJ, 21..26 J·(−e), 27 fit·fit (a count), 28..31 idle
-    int ra = 7, rb = 7;
-    {
-        int o = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = i; j < 6; ++j) {
-                if (o == ent) { ra = i; rb = j; }
-                ++o;
-            }
-        if (ent >= 21 && ent < 27) { ra = ent - 21; rb = 6; }
-    }
-    double sum = 0.0;
+    RowAccum ra;  // see there: the 28 sums are not kept per thread
+    ra.init();
 #pragma unroll 1
     for (int pp = 0; pp < kPlanePts; ++pp) {
         const int i = (blockIdx.x * kPlanePts + pp) * kBlock + tid;
-        double J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double neg_e = 0.0, fitted = 0.0;
+        double J[1][6] = {{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
+        double neg_e[1] = {0.0};
+        double fitted = 0.0;
         if (i < counts[scan]) {
             const size_t gi = (size_t)scan * max_n + i;
             const uint32_t s4 = nn[4 * nn_pitch + gi];
@@ -305,38 +348,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                         double nR[3];
 #pragma unroll
                         for (int c = 0; c < 3; ++c) nR[c] = (-n3.x * R[c] + -n3.y * R[3 + c]) + -n3.z * R[6 + c];
-                        J[0] = nR[1] * q.z - nR[2] * q.y;
-                        J[1] = nR[2] * q.x - nR[0] * q.z;
-                        J[2] = nR[0] * q.y - nR[1] * q.x;
-                        J[3] = n3.x; J[4] = n3.y; J[5] = n3.z;
-                        neg_e = -dis;
+                        J[0][0] = nR[1] * q.z - nR[2] * q.y;
+                        J[0][1] = nR[2] * q.x - nR[0] * q.z;
+                        J[0][2] = nR[0] * q.y - nR[1] * q.x;
+                        J[0][3] = n3.x; J[0][4] = n3.y; J[0][5] = n3.z;
+                        neg_e[0] = -dis;
                     }
                 }
             }
         }
-        if (pp) __syncthreads();  // the previous round's rows have been consumed
-#pragma unroll
-        for (int c = 0; c < 6; ++c) s_row[c][tid] = J[c];
-        s_row[6][tid] = neg_e;
-        s_row[7][tid] = fitted;
-        __syncthreads();
-        if (ent < 28) {
-#pragma clang fp contract(fast)
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) {  // rows slice, slice + 8, …: neighbouring slices read neighbouring LDS banks
-                const int col = k * (kBlock / 32) + slice;
-                sum += s_row[ra][col] * s_row[rb][col];
-            }
-        }
+        ra.add<1>(s_row, J, neg_e, fitted);
     }
-    s_slice[slice][ent] = sum;
-    __syncthreads();
-    if (tid < 28) {
-        double s = s_slice[0][tid];
-#pragma unroll
-        for (int w = 1; w < kBlock / 32; ++w) s += s_slice[w][tid];
-        partials[((size_t)scan * gridDim.x + blockIdx.x) * kAccW + tid] = s;
-    }
+    ra.store(s_slice, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
 }
 
 // K2', P2P: CaculateMatrixHAndBP2P (icp_registration.cpp:57-103), including the /16 on the rotation block.
@@ -380,18 +403,25 @@ __global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __
 }
 
 // K2', P2Line: CaculateMatrixHAndBP2Line (icp_registration.cpp:105-159) + math::FitLine (math_utils.h:138-163).
-__global__ __launch_bounds__(kBlock) void icp_line_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void icp_line_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                 const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                 const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                 double max_line_distance, double* __restrict__ partials, int pts) {
+    __shared__ double s_row[8][kAccPad];
+    __shared__ double s_slice[kBlock / 32][32];
     const int scan = blockIdx.y;
     if (st[scan].done) return;
-    double acc[28];
-#pragma unroll
-    for (int v = 0; v < 28; ++v) acc[v] = 0.0;
+    RowAccum ra;
+    ra.init();
 #pragma unroll 1
     for (int pp = 0; pp < pts; ++pp) {
     const int i = (blockIdx.x * pts + pp) * kBlock + threadIdx.x;
+    double J[3][6], neg_e[3] = {0.0, 0.0, 0.0};
+    double fitted = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) J[r][c] = 0.0;
     if (i < counts[scan]) {
         const size_t gi = (size_t)scan * max_n + i;
         const uint32_t s4 = nn[4 * nn_pitch + gi];
@@ -417,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void icp_line_accum_kernel(const uint2* __r
                 if (dot3(c, c) > max_line_distance) fit = false;
             }
             if (fit) {
-                acc[27] += 1.0;
+                fitted = 1.0;
                 const D3 e3 = cross3(d, qs - p0);  // SO3::hat(d) * (qs - p0)
                 if (!(sqrt(dot3(e3, e3)) > max_line_distance)) {
                     const double hd[3][3] = {{0.0, -d.z, d.y}, {d.z, 0.0, -d.x}, {-d.y, d.x, 0.0}};
@@ -442,19 +472,18 @@ __global__ __launch_bounds__(kBlock) void icp_line_accum_kernel(const uint2* __r
                             s += hR[r][2] * hq[2][c];
                             A[r][c] = s;
                         }
-                    double J[3][6];
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
                         for (int c = 0; c < 3; ++c) { J[r][c] = -A[r][c]; J[r][3 + c] = hd[r][c]; }
-                    const double e[3] = {e3.x, e3.y, e3.z};
-                    add_rows<3>(acc, J, e);
+                    neg_e[0] = -e3.x; neg_e[1] = -e3.y; neg_e[2] = -e3.z;
                 }
             }
         }
     }
+    ra.add<3>(s_row, J, neg_e, fitted);
     }
-    block_reduce_store<28>(acc, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
+    ra.store(s_slice, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
 }
 
 // Sum of the block partials of one scan, per column, in a fixed order (chunk c takes rows c, c + 8, …; the chunks are then added in

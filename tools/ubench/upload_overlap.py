@@ -1,0 +1,19 @@
+import sys, time, numpy as np
+sys.path.insert(0, '.')
+from loc_lib_amd import api, synth
+ctx = api.Context(0)
+m = synth.make_map(10_000_000); ctx.icp_set_target(m)
+scans = [synth.make_scan(i) for i in range(256)]
+inits = np.stack([synth.make_pose(i)[1] for i in range(256)])
+b0 = ctx.batch(scans); b1 = ctx.batch(scans)
+opts = api.icp_opts(method=api.P2PLANE)
+for _ in range(2):
+    t0 = time.perf_counter(); b1.upload_async(scans); t1 = time.perf_counter(); b1.upload_wait(); t2 = time.perf_counter()
+    print("upload alone: start %.2f ms, total %.2f ms" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
+ctx.icp_align_batch(b0, inits, opts)
+for _ in range(3):
+    t0 = time.perf_counter(); ctx.icp_align_batch(b0, inits, opts); t1 = time.perf_counter()
+    print("align alone %.2f ms" % ((t1 - t0) * 1e3))
+for _ in range(3):
+    t0 = time.perf_counter(); b1.upload_async(scans); ctx.icp_align_batch(b0, inits, opts); t1 = time.perf_counter(); b1.upload_wait(); t2 = time.perf_counter()
+    print("align with upload %.2f ms, upload done at %.2f ms" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
