@@ -80,17 +80,26 @@ __device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&
     }
     for (int sweep = 0; sweep < 30; ++sweep) {
         bool rotated = false;
+        // Squared column norms: summed afresh once per sweep, then carried through the sweep's rotations by the exact identities
+        // α' = α − tγ, β' = β + tγ (they follow from γt² + (β−α)t − γ = 0). A pair then costs one inner product instead of three.
+        // The carried values only steer the rotation angle and scale the convergence test; orthogonality itself is always
+        // tested on a freshly summed γ, so the accuracy of the result is that of the plain scheme.
+        double nrm[N];
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            double sn = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) sn += a[c][i] * a[c][i];
+            nrm[c] = sn;
+        }
 #pragma unroll
         for (int p = 0; p < N - 1; ++p) {
 #pragma unroll
             for (int q = p + 1; q < N; ++q) {
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                const double alpha = nrm[p], beta = nrm[q];
+                double gamma = 0.0;
 #pragma unroll
-                for (int i = 0; i < M; ++i) {
-                    alpha += a[p][i] * a[p][i];
-                    beta += a[q][i] * a[q][i];
-                    gamma += a[p][i] * a[q][i];
-                }
+                for (int i = 0; i < M; ++i) gamma += a[p][i] * a[q][i];
                 // converged pair: |γ| ≤ 1e-15·√(αβ)  ⇔  γ² ≤ 1e-30·αβ (no square root on the common path)
                 if (!(gamma == 0.0 || gamma * gamma <= 1e-30 * (alpha * beta))) {
                     rotated = true;
@@ -107,6 +116,8 @@ __device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&
                     const double t = g2 * inv;
                     const double c = rsqrt_refined(1.0 + t * t);
                     const double s = c * t;
+                    nrm[p] = alpha - t * gamma;
+                    nrm[q] = beta + t * gamma;
 #pragma unroll
                     for (int i = 0; i < M; ++i) {
                         const double ap = a[p][i], aq = a[q][i];

@@ -323,14 +323,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         double fitted = 0.0;
         if (i < counts[scan]) {
             const size_t gi = (size_t)scan * max_n + i;
-            const uint32_t s4 = nn[4 * nn_pitch + gi];
-            if (s4 != kInvalidSlot) {  // nn.size() > 3: k=5 yields 5 or (k > size_) none
-                const float4 p = src[gi];
+            // all five indices and the point in one round trip (not: the fifth, then the rest behind its test)
+            uint32_t slot[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) slot[j] = nn[(size_t)j * nn_pitch + gi];
+            const float4 p = src[gi];
+            if (slot[4] != kInvalidSlot) {  // nn.size() > 3: k=5 yields 5 or (k > size_) none
                 const D3 q{(double)p.x, (double)p.y, (double)p.z};
                 const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
                 D3 nb[5];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, j == 4 ? s4 : nn[(size_t)j * nn_pitch + gi]);
+                for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, slot[j]);
                 double n4[4];
                 plane_null_vector(nb, n4);
                 const D3 n3{n4[0], n4[1], n4[2]};
@@ -424,14 +427,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         for (int c = 0; c < 6; ++c) J[r][c] = 0.0;
     if (i < counts[scan]) {
         const size_t gi = (size_t)scan * max_n + i;
-        const uint32_t s4 = nn[4 * nn_pitch + gi];
-        if (s4 != kInvalidSlot) {  // nn.size() == 5
-            const float4 p = src[gi];
+        uint32_t slot[5];  // one round trip for the five indices and the point (see the plane kernel)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) slot[j] = nn[(size_t)j * nn_pitch + gi];
+        const float4 p = src[gi];
+        if (slot[4] != kInvalidSlot) {  // nn.size() == 5
             const D3 q{(double)p.x, (double)p.y, (double)p.z};
             const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
             D3 nb[5];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, j == 4 ? s4 : nn[(size_t)j * nn_pitch + gi]);
+            for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, slot[j]);
             D3 sum{0.0, 0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < 5; ++j) sum = sum + nb[j];
