@@ -69,8 +69,9 @@ __device__ __forceinline__ double rsqrt_refined(double x) {
 // Fully unrolled over (p,q) so both arrays live in VGPRs; the sweep loop exits per lane when a sweep made no rotation.
 // This is FP64-issue bound, so FMA contraction is allowed HERE (results differ from the un-fused CPU oracle by
 // rounding only, ~1e-16 relative; the float32 search arithmetic stays un-fused).
+// `norms` (optional): the squared column norms of the result (the converged sweep's fresh sums — no rotation touched them).
 template <int M, int N, bool ACC_V = true>
-__device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&v)[N][N]) {
+__device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&v)[N][N], double* norms = nullptr) {
 #pragma clang fp contract(fast)
     if (ACC_V) {
 #pragma unroll
@@ -103,19 +104,18 @@ __device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&
                 // converged pair: |γ| ≤ 1e-15·√(αβ)  ⇔  γ² ≤ 1e-30·αβ (no square root on the common path)
                 if (!(gamma == 0.0 || gamma * gamma <= 1e-30 * (alpha * beta))) {
                     rotated = true;
-                    // Jacobi rotation that zeroes γ: t = tan θ = sign(ζ)/(|ζ|+√(1+ζ²)), ζ = (β−α)/(2γ), written as
-                    // t = 2γ / (d + sign(d)·√(d²+4γ²)) with d = β−α: one sqrt and one divide; c = 1/√(1+t²) from
-                    // v_rsq_f64 refined by two Newton steps (|c²+s²−1| ≲ 2e-16, as good as the divide-based form).
-                    const double d = beta - alpha, g2 = 2.0 * gamma;
-                    const double x2 = d * d + g2 * g2;                 // > 0 here (γ ≠ 0)
-                    const double r = x2 * rsqrt_refined(x2);           // √x2 without the IEEE sqrt expansion
-                    const double den = d + (d >= 0.0 ? r : -r);        // |den| ≥ |2γ| > 0
-                    double inv = __builtin_amdgcn_rcp(den);            // 1/den: v_rcp_f64 + two Newton steps instead of the IEEE divide
-                    inv = inv * (2.0 - den * inv);
-                    inv = inv * (2.0 - den * inv);
-                    const double t = g2 * inv;
-                    const double c = rsqrt_refined(1.0 + t * t);
-                    const double s = c * t;
+                    // Jacobi rotation that zeroes γ (the inner one, |θ| ≤ π/4). With d = β−α and r = √(d²+4γ²):
+                    //   c² = ½ + ½|d|/r,  s = sign(d)·γ/(r·c),  t = s/c  (t solves γt² + dt − γ = 0)
+                    // — two refined v_rsq_f64 (1/r and 1/c), no sqrt, no divide; c ≥ 1/√2, so nothing cancels.
+                    const double d = beta - alpha;
+                    const double x2 = d * d + 4.0 * (gamma * gamma);   // > 0 here (γ ≠ 0)
+                    const double ir = rsqrt_refined(x2);
+                    const double c2 = 0.5 + (0.5 * fabs(d)) * ir;
+                    const double ic = rsqrt_refined(c2);
+                    const double c = c2 * ic;
+                    const double gs = d >= 0.0 ? gamma : -gamma;
+                    const double s = (gs * ir) * ic;
+                    const double t = s * ic;
                     nrm[p] = alpha - t * gamma;
                     nrm[q] = beta + t * gamma;
 #pragma unroll
@@ -135,7 +135,22 @@ __device__ __forceinline__ void jacobi_svd_onesided(double (&a)[N][M], double (&
                 }
             }
         }
-        if (!rotated) break;
+        if (!rotated) {
+            if (norms) {
+#pragma unroll
+                for (int c = 0; c < N; ++c) norms[c] = nrm[c];
+            }
+            return;
+        }
+    }
+    if (norms) {  // sweep limit reached (never seen): sum them
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            double sn = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) sn += a[c][i] * a[c][i];
+            norms[c] = sn;
+        }
     }
 }
 
@@ -178,15 +193,13 @@ __device__ __forceinline__ void plane_null_vector(const D3 (&nb)[5], double (&n4
         }
     }
     double unused[4][4];
-    jacobi_svd_onesided<4, 4, false>(l, unused);
+    double sn4[4];
+    jacobi_svd_onesided<4, 4, false>(l, unused, sn4);
     int best = 0;
-    double bn = 1e300, mx = 0.0, sn4[4];
+    double bn = 1e300, mx = 0.0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        double sn = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sn += l[c][r] * l[c][r];
-        sn4[c] = sn;
+        const double sn = sn4[c];
         if (sn < bn) { bn = sn; best = c; }
         mx = sn > mx ? sn : mx;
     }
@@ -273,12 +286,13 @@ __device__ __forceinline__ D3 line_direction(const D3 (&dl)[5]) {
         }
     }
     double unused[3][3];
-    jacobi_svd_onesided<3, 3, false>(l, unused);
+    double sn3[3];
+    jacobi_svd_onesided<3, 3, false>(l, unused, sn3);
     int best = 0;
     double bn = -1.0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double sn = (l[c][0] * l[c][0] + l[c][1] * l[c][1]) + l[c][2] * l[c][2];
+        const double sn = sn3[c];
         if (sn > bn) { bn = sn; best = c; }
     }
     const double rw = bn > 0.0 ? rsqrt_refined(bn) : 0.0;
