@@ -55,14 +55,14 @@ __device__ __host__ inline void quat_to_R(const double* q, double* R) {
     R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
 }
 
-// 1/√x for x > 0 to double precision: v_rsq_f64 refined by two Newton steps.
+// 1/√x for x > 0 to double precision: v_rsq_f64 (≈2^-23 relative) refined by ONE third-order step,
+// y·(1 + e/2 + 3e²/8) with e = 1 − x·y² (error ∝ e³ ≈ 2^-67): five instructions instead of the seven of two Newton steps.
 __device__ __forceinline__ double rsqrt_refined(double x) {
 #pragma clang fp contract(fast)
-    const double hx = 0.5 * x;
-    double r = __builtin_amdgcn_rsq(x);
-    r = r * (1.5 - hx * r * r);
-    r = r * (1.5 - hx * r * r);
-    return r;
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y), y, 1.0);
+    const double q = __builtin_fma(0.375, e, 0.5) * e;
+    return __builtin_fma(y, q, y);
 }
 
 // One-sided (Hestenes) Jacobi SVD, M×N, columns in a[N][M], right vectors accumulated in v[N][N].
