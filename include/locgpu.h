@@ -206,7 +206,8 @@ LOCGPU_API int locgpu_graph_enable(locgpu_ctx* ctx, int on);
 /* ---- Measurement hooks (bench.py / tests; no reference counterpart). */
 /* Average device time in ms of each hot kernel over the calls since the last reset, measured with hipEvents on the
  * context's stream: out[0]=search, out[1]=fit+accumulate, out[2]=solve/update, out[3..5]=their launch counts.
- * Timing is only collected when enabled (it serialises launches with events). */
+ * Timing is only collected when enabled (it serialises launches with events): on = 1 times all three stages (four event
+ * records per iteration), on = 2 only the search stage (two records per iteration; out[1], out[2] and their counts stay 0). */
 LOCGPU_API int locgpu_profile_enable(locgpu_ctx* ctx, int on);
 LOCGPU_API int locgpu_profile_read(locgpu_ctx* ctx, double out[6], int reset);
 /* Total tree nodes / leaves visited by the search kernel of the NEXT align/hb call(s) when counting is on

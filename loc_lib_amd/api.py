@@ -551,6 +551,17 @@ class Submap:
         self.close()
 
 
+class MarshalledScans:
+    """The (pointer, count) arrays of a list of host scans, built once: what a C/C++ caller of locgpu_batch_upload_async holds
+    anyway. Pass it wherever a list of scans is accepted to skip the per-call Python marshalling (≈0.4 ms for 256 scans)."""
+
+    def __init__(self, scans):
+        self.scans, self.ptrs, self.cnts, self.stride = Batch._marshal(list(scans))
+
+    def __len__(self):
+        return len(self.scans)
+
+
 class Batch:
     """A batch of scans resident in HBM (locgpu_batch). ``n_scans`` = the scans poses are kept for (all n_total of a sharded batch)."""
 
@@ -573,6 +584,8 @@ class Batch:
 
     @staticmethod
     def _marshal(scans):
+        if isinstance(scans, MarshalledScans):
+            return scans.scans, scans.ptrs, scans.cnts, scans.stride
         scans = [_cloud(s) for s in scans]
         if not scans:
             raise ValueError("empty batch")

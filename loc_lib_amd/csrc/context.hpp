@@ -53,7 +53,7 @@ struct locgpu_ctx {
     int comm_rank = 0, comm_world = 1;
 
     // measurement
-    bool profile = false;
+    int profile = 0;  // 0 off, 1 = events around search / fit+accumulate / solve, 2 = around the search stage only
     std::vector<hipEvent_t> events;
     double prof_ms[3] = {0, 0, 0};
     long long prof_n[3] = {0, 0, 0};

@@ -552,13 +552,13 @@ namespace locgpu {
 
 bool IterLauncher::launch(int do_update) {
     hipStream_t s = ctx->stream;
-    const bool prof = ctx->profile && !capturing;
-    auto mark = [&]() {
-        if (!prof) return;
+    const int prof = capturing ? 0 : ctx->profile;
+    auto mark = [&](bool search_edge = false) {
+        if (!prof || (prof == 2 && !search_edge)) return;
         hipEvent_t ev = get_event(ctx, ev_used);
         if (ev) { (void)hipEventRecord(ev, s); ev_used++; }
     };
-    mark();
+    mark(true);
     int n_partial_blocks = b->blocks_per_scan;
     PoseState* st_local = b->d_state + b->first;  // kernels index the scans this rank holds: 0..n_scans-1
     if (!ndt) {
@@ -573,12 +573,12 @@ bool IterLauncher::launch(int do_update) {
         const GridSearchScratch gsc{b->d_grid_qkey, b->d_grid_sorted};
         const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, gsc, s) : launch_icp_search(sa, s);
         if (!ok_search) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
-        mark();
+        mark(true);
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
         AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
         n_partial_blocks = launch_icp_accum(prm.method, aa, s);
     } else {
-        mark();  // NDT has no separate search kernel: search slot stays empty
+        mark(true);  // NDT has no separate search kernel: search slot stays empty
         if (prm.method == 4)
             launch_inc_accum(ctx->inc, ctx->ndt_opts.res_outlier_th, ctx->ndt_opts.nearby_type == 0 ? 1 : 7, b->d_src, b->d_counts, st_local,
                              b->max_n, b->n_scans, b->d_partials, s);
@@ -604,8 +604,16 @@ bool IterLauncher::launch(int do_update) {
 }
 
 void IterLauncher::collect_profile() {
-    // launch() records four events per iteration: [0,1] search, [1,2] fit+accumulate, [2,3] solve.
-    if (ctx->profile) {
+    // launch() records four events per iteration: [0,1] search, [1,2] fit+accumulate, [2,3] solve — or, in the light mode, two: [0,1] search.
+    if (ctx->profile == 2) {
+        for (size_t i = 0; i + 1 < ev_used; i += 2) {
+            float ms = 0.f;
+            if (!ndt && hipEventElapsedTime(&ms, ctx->events[i], ctx->events[i + 1]) == hipSuccess) {
+                ctx->prof_ms[0] += ms;
+                ctx->prof_n[0] += 1;
+            }
+        }
+    } else if (ctx->profile) {
         for (size_t i = 0; i + 3 < ev_used; i += 4)
             for (int j = 0; j < 3; ++j) {
                 if (ndt && j == 0) continue;  // NDT has no search kernel
@@ -963,7 +971,7 @@ int locgpu_graph_enable(locgpu_ctx* ctx, int on) {
 
 int locgpu_profile_enable(locgpu_ctx* ctx, int on) {
     if (!ctx) return LOCGPU_ERR_INVALID;
-    ctx->profile = on != 0;
+    ctx->profile = on == 2 ? 2 : (on != 0 ? 1 : 0);
     return LOCGPU_OK;
 }
 
