@@ -91,6 +91,32 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
         for (int j = 0; j < 5; ++j) atomicAdd(&search_stats[2 + j], diag[j]);                 // lane sums
         if ((tid & 63) == 0) { for (int j = 0; j < 5; ++j) atomicAdd(&search_stats[7 + j], wmax[j]); atomicAdd(&search_stats[12], 1ull); }  // wave maxima, waves
     }
+    if (BLK == 64 && !STAMP) {
+        // One or two unfinished queries in this wave (the usual case: ≈30 of 29.5 M): answer them here with the exact traversal, the
+        // wave's LDS (all of its fast stacks are dead now) serving as their two stack columns — instead of a separate kernel whose
+        // ≈55 µs the whole iteration waits for. More than two (a lattice map: every distance ties) go to the list as before.
+        const unsigned long long slow_mask = __ballot(slow);
+        if (slow_mask != 0ull && __popcll(slow_mask) <= 2) {
+            if (slow) {
+                uint32_t(*s_far)[2] = reinterpret_cast<uint32_t(*)[2]>(&s_stack[0][0]);
+                float(*s_d2)[2] = reinterpret_cast<float(*)[2]>(reinterpret_cast<char*>(&s_stack[0][0]) + 64 * 2 * sizeof(uint32_t));
+                static_assert(sizeof(s_stack) >= 64 * 2 * 8, "exact stack columns do not fit");
+                const int col = __popcll(slow_mask & ((1ull << tid) - 1ull));
+                KnnHeap<K> heap;
+                uint32_t nvis = 0, lvis = 0, out[K];
+                int cnt;
+                tree_knn_flat<K, 64, false, 2>(tree, fqx, fqy, fqz, K, alpha_eff, s_far, s_d2, col, heap, nvis, lvis);
+                heap_to_sorted<K>(heap, out, cnt);
+#pragma unroll
+                for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = out[j];
+                if (search_stats) atomicAdd(&search_stats[1], 1ull);
+            } else {
+#pragma unroll
+                for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = set.id[j];
+            }
+            return;
+        }
+    }
     if (slow) {
         redo_list[atomicAdd(redo_count, 1u)] = (uint32_t)gi;
     } else {
