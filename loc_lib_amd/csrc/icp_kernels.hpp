@@ -345,12 +345,11 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
         const float d2 = dd * dd;
         const uint32_t right = meta & 0x3FFFFFFFu;
         const bool go_left = qa < th;
+        // T ≥ depth − DF (launch_fast_kd), and a descent pushes at most depth − 1 entries: position sp − T never reaches DF here
         if (sp < T) {
             min_drop = d2 < min_drop ? d2 : min_drop;
-        } else if (sp - T < DF) {
-            s_stack[sp - T][tid] = make_uint2(go_left ? right : cur + 1u, __float_as_uint(d2));
         } else {
-            slow = 1;
+            s_stack[sp - T][tid] = make_uint2(go_left ? right : cur + 1u, __float_as_uint(d2));
         }
         sp++;
         cur = go_left ? cur + 1u : right;
@@ -397,11 +396,12 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
             const bool go_left = qa < th;
             const uint32_t far_slot = go_left ? right : cur + 1u;
             const bool push = !is_leaf && d2 < top * alpha_eff;  // else NeedExpand can never come true later
-            const int idx = sp - T;                              // position in the stored part of the stack
-            const bool drop = push && idx < 0;
-            const bool store = push && (unsigned)idx < (unsigned)DF;
+            // Position in the stored part of the stack. Never negative here: the main loop only visits a node after popping a
+            // stored entry (sp ≥ T afterwards) or after the replay (T = 0), so the un-stored levels are first-descent business only.
+            // It can exceed the stored part only after a replay in a tree deeper than DF.
+            const int idx = sp - T;
+            const bool store = push && idx < DF;
             slow |= (push && idx >= DF) ? 1u : 0u;  // deeper than the fast stack
-            min_drop = (drop && d2 < min_drop) ? d2 : min_drop;
             if (store) s_stack[idx][tid] = make_uint2(far_slot, __float_as_uint(d2));
             sp += push ? 1 : 0;
             need_pop = is_leaf ? 1u : 0u;
