@@ -217,7 +217,8 @@ LOCGPU_API int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int res
 
 /* Search bookkeeping since the last reset (enabled by the first call): out[0] = queries handled by the fast search
  * kernel's launches, out[1] = queries it handed to the exact redo kernel (distance ties / near-misses on the top tree levels),
- * out[2] = grid mode: queries the tile kernel handed to the ring-walk kernel, out[3] = reserved (0). */
+ * out[2] = grid mode: queries the tile kernel handed to the ring-walk kernel, out[3] = diagnostic build (LOCGPU_STAMP=1) only: queries of the
+ * fast tree search that had to walk the un-stored top levels of their first descent again ("replays"); 0 otherwise. */
 LOCGPU_API int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset);
 
 /* =====================================================================================================================

@@ -415,7 +415,7 @@ class Context:
     def search_stats_read(self, reset=True):
         out = np.zeros(4, dtype=np.uint64)
         self._check(lib().locgpu_search_stats_read(self._h, out.ctypes.data, int(reset)))
-        return dict(searched=int(out[0]), redone=int(out[1]), walked=int(out[2]))
+        return dict(searched=int(out[0]), redone=int(out[1]), walked=int(out[2]), replayed=int(out[3]))
 
 
 def _xyzi(a):

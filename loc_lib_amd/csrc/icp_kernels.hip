@@ -79,7 +79,7 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
     // astronomically far goes straight to the exact kernel.
     const float fqx = (float)qs.x, fqy = (float)qs.y, fqz = (float)qs.z;
     const bool sane = fabsf(fqx) < 1e18f && fabsf(fqy) < 1e18f && fabsf(fqz) < 1e18f;
-    const bool slow = !sane || tree_knn_fast<K, DF, BLK, STAMP>(rsrc, fqx, fqy, fqz, alpha_eff, T, s_stack, tid, set, diag);
+    const bool slow = !sane || tree_knn_fast<K, DF, BLK, STAMP>(rsrc, fqx, fqy, fqz, alpha_eff, T, s_stack, tid, set, diag, (STAMP && search_stats) ? search_stats + 15 : nullptr);
     if (STAMP && search_stats) {
         // per-wave maxima (what the wave pays) and per-lane sums (useful work); search_stats[2..] are diagnostic slots
         unsigned long long wmax[5];

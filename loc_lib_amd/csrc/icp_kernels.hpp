@@ -320,14 +320,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // main-loop trips, VISIT trips and POP rounds. Never instantiated in the timed path.
 template <int K, int DF, int BLK, bool STAMP = false>
 __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, float qx, float qy, float qz, float alpha_eff, int T,
-                                              uint2 (*s_stack)[BLK], int tid, SortedSet<K>& set, unsigned long long* diag = nullptr) {
+                                              uint2 (*s_stack)[BLK], int tid, SortedSet<K>& set, unsigned long long* diag = nullptr,
+                                              unsigned long long* replay_counter = nullptr) {
     unsigned long long t_begin = 0, t_mid = 0;
     unsigned int n_trips = 0, n_visit = 0, n_pop = 0;
     if (STAMP) t_begin = __builtin_amdgcn_s_memtime();
     set.init();
     int sp = 0;
     uint32_t cur = 0;
-    float min_drop = __builtin_inff();
+    // The un-stored levels: the smallest d² among them with its far slot, and the second smallest d². If only the smallest can
+    // still pass NeedExpand when the stack has drained, that one entry is expanded directly (the younger ones are tested before it
+    // and fail, the older ones after it against a bound that has only shrunk) — no replay from the root.
+    float min_drop = __builtin_inff(), min_drop2 = __builtin_inff();
+    uint32_t far_drop = 0;
     // Loop-carried flags live in VGPRs as integers: a divergent `bool` is a lane mask in SGPRs, and every region that
     // assigns it costs three scalar mask instructions at its merge point — the scalar unit is shared by the CU's four SIMDs.
     uint32_t slow = 0, live = 1, need_pop = 0;
@@ -346,10 +351,14 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
         const uint32_t right = meta & 0x3FFFFFFFu;
         const bool go_left = qa < th;
         // T ≥ depth − DF (launch_fast_kd), and a descent pushes at most depth − 1 entries: position sp − T never reaches DF here
+        const uint32_t far_slot = go_left ? right : cur + 1u;
         if (sp < T) {
-            min_drop = d2 < min_drop ? d2 : min_drop;
+            const bool lt = d2 < min_drop;
+            min_drop2 = lt ? min_drop : (d2 < min_drop2 ? d2 : min_drop2);
+            far_drop = lt ? far_slot : far_drop;
+            min_drop = lt ? d2 : min_drop;
         } else {
-            s_stack[sp - T][tid] = make_uint2(go_left ? right : cur + 1u, __float_as_uint(d2));
+            s_stack[sp - T][tid] = make_uint2(far_slot, __float_as_uint(d2));
         }
         sp++;
         cur = go_left ? cur + 1u : right;
@@ -414,7 +423,16 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                 // nothing stored is left. sp > 0: only un-stored first-descent entries (levels 0..sp-1) remain.
                 const bool may_pass = sp > 0 && !(min_drop >= bound);
                 live = may_pass ? 1u : 0u;  // otherwise finished: every un-stored entry is rejected by the final bound
-                if (may_pass) {
+                const bool single = may_pass && min_drop2 >= bound;  // exactly one of them can pass, now or later
+                if (single) {
+                    cur = far_drop;
+                    sp = 0;
+                    T = 0;
+                    need_pop = 0;
+                    min_drop = __builtin_inff();
+                    min_drop2 = __builtin_inff();
+                } else if (may_pass) {
+                    if (STAMP && replay_counter) atomicAdd(replay_counter, 1ull);  // diagnostic build only: a live pointer across the loop costs 1.6 %
                     // Rare: walk the un-stored levels 0..sp-1 again from the root (same `<` decisions, hence the same internal
                     // nodes) and push them under the pruning rule with the CURRENT bound; from now on every position is stored.
                     const int levels = sp;
@@ -438,6 +456,7 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                         c = go_left ? c + 1u : right;
                     }
                     min_drop = __builtin_inff();
+                    min_drop2 = __builtin_inff();
                 }
                 // need_pop stays set: the re-pushed entries are popped like any others (an empty stack ends the query next trip)
             } else {

@@ -996,7 +996,7 @@ int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset) {
     LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     unsigned long long h[16];
     LOCGPU_HIP(ctx, hipMemcpy(h, ctx->d_search_stats, sizeof(h), hipMemcpyDeviceToHost));
-    out[0] = h[0]; out[1] = h[1]; out[2] = getenv("LOCGPU_STAMP") ? 0 : h[2]; out[3] = 0;
+    out[0] = h[0]; out[1] = h[1]; out[2] = getenv("LOCGPU_STAMP") ? 0 : h[2]; out[3] = getenv("LOCGPU_STAMP") ? h[15] : 0;
     if (getenv("LOCGPU_STAMP") && h[12]) {  // diagnostic build only
         const double q = (double)h[0], w = (double)h[12];
         fprintf(stderr, "[locgpu stamp] per lane: descent %.0f cyc, total %.0f cyc, trips %.1f (visit %.1f, pop-only %.1f) | per wave (max over lanes): "

@@ -54,7 +54,7 @@ def main():
     q = vc["queries"]
     k = 1 if args.method == 0 else 5
     sbytes = q * 16 + vc["nodes"] * 16 + q * 4 * k
-    print(json.dumps(dict(variant=os.environ.get("LOCGPU_SEARCH_VARIANT", "0"), search=args.search, scans=args.scans, queries=q, hb_identical_to_default=same, redo_frac=round(ss["redone"] / max(ss["searched"], 1), 6), walk_frac=round(ss["walked"] / max(ss["searched"], 1), 5),
+    print(json.dumps(dict(variant=os.environ.get("LOCGPU_SEARCH_VARIANT", "0"), search=args.search, scans=args.scans, queries=q, hb_identical_to_default=same, redo_frac=round(ss["redone"] / max(ss["searched"], 1), 6), walk_frac=round(ss["walked"] / max(ss["searched"], 1), 5), replay_frac=round(ss["replayed"] / max(ss["searched"], 1), 5),
                           search_ms=round(p["search_ms"], 4), accum_ms=round(p["accum_ms"], 4), solve_ms=round(p["solve_ms"], 4),
                           search_us_per_scan=round(1e3 * p["search_ms"] / args.scans, 2),
                           search_alg_GBs=round(sbytes / 1e9 / (p["search_ms"] / 1e3), 1),
