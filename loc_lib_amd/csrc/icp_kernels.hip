@@ -687,12 +687,19 @@ static bool launch_search_k(const SearchArgs& a, hipStream_t s) {
     else return false;
     return true;
 }
-// LDS stack entries per thread in the fast kernel (8 B each): 20 → 40 KB per 256-thread workgroup, 4 workgroups per CU.
-// Default workgroup = one wave (64 threads, 10 KB LDS): waves retire independently. LOCGPU_FAST_STACK=16|24 and
-// LOCGPU_FAST_BLOCK=128|256 select other shapes for experiments.
+// Stored LDS stack entries per thread in the fast kernel (8 B each; the levels above them are not stored, see tree_knn_fast).
+// One-wave workgroups (waves retire independently), so DF sets the waves a CU holds: 15 → 7.5 KB → 21 waves per CU. Since a single
+// un-stored entry that can still pass is expanded without a replay, the un-stored levels are cheap and the balance is between
+// occupancy and the (rare) paths deeper than DF that go to the exact traversal — measured on the bench workload (search ms per
+// 256-scan step): 12 → 30.0, 13 → 28.2, 14 → 26.2, 15 → 25.5, 16 → 27.2, 20 → 29.0, 24 → 35.9.
+// LOCGPU_FAST_STACK=12..16|20|24 and LOCGPU_FAST_BLOCK=128|256 select other shapes for experiments.
 static int fast_stack_depth() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("LOCGPU_FAST_STACK"); v = e ? atoi(e) : 20; if (v != 16 && v != 24) v = 20; }
+    if (v < 0) {
+        const char* e = getenv("LOCGPU_FAST_STACK");
+        v = e ? atoi(e) : 15;
+        if (!((v >= 12 && v <= 16) || v == 20 || v == 24)) v = 15;
+    }
     return v;
 }
 
@@ -735,9 +742,13 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
 template <int K, int D>
 static void launch_fast_d(const SearchArgs& a, hipStream_t s) {
     switch (fast_stack_depth()) {
+        case 12: launch_fast_kd<K, D, 12>(a, s); break;
+        case 13: launch_fast_kd<K, D, 13>(a, s); break;
+        case 14: launch_fast_kd<K, D, 14>(a, s); break;
         case 16: launch_fast_kd<K, D, 16>(a, s); break;
+        case 20: launch_fast_kd<K, D, 20>(a, s); break;
         case 24: launch_fast_kd<K, D, 24>(a, s); break;
-        default: launch_fast_kd<K, D, 20>(a, s); break;
+        default: launch_fast_kd<K, D, 15>(a, s); break;
     }
 }
 template <int K>
@@ -770,7 +781,7 @@ bool launch_icp_search_redo(const SearchArgs& a, hipStream_t s) {
 // have been zeroed on the stream; a.alpha_eff is the pruning factor (1 = exact).
 template <int K>
 static bool launch_fast_list_k(const SearchArgs& a, const uint32_t* list, const unsigned int* n_list, hipStream_t s) {
-    constexpr int DF = 20;
+    constexpr int DF = 15;
     const int T = a.depth > DF ? a.depth - DF : 0;
     hipLaunchKernelGGL((icp_search_fast_list_kernel<K, DF>), dim3(4096), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.alpha_eff, T,
                        (unsigned int)a.tree_bytes, list, n_list, a.redo_list, a.redo_count, a.search_stats);
