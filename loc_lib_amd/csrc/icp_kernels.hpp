@@ -328,11 +328,14 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
     set.init();
     int sp = 0;
     uint32_t cur = 0;
-    // The un-stored levels: the smallest d² among them with its far slot, and the second smallest d². If only the smallest can
-    // still pass NeedExpand when the stack has drained, that one entry is expanded directly (the younger ones are tested before it
-    // and fail, the older ones after it against a bound that has only shrunk) — no replay from the root.
-    float min_drop = __builtin_inff(), min_drop2 = __builtin_inff();
-    uint32_t far_drop = 0;
+    // The un-stored levels: the two smallest d² among them with their far slots (c1 ≤ c2, and which of the two is the deeper,
+    // i.e. younger, level) and the third smallest d². When the stack has drained, the entries that can still pass NeedExpand are
+    // among these — the bound only shrinks, so an entry that fails once fails for good. If at most the two candidates can pass,
+    // they are expanded directly, the younger first and the other re-tested after it, exactly as the recursion would (entries
+    // younger than a candidate are tested before it and fail; older ones after it, against a smaller bound). Only when the third
+    // could pass as well are the top levels replayed from the root.
+    float c1_d2 = __builtin_inff(), c2_d2 = __builtin_inff(), c3_d2 = __builtin_inff();
+    uint32_t c1_far = 0, c2_far = 0, c1_younger = 0;
     // Loop-carried flags live in VGPRs as integers: a divergent `bool` is a lane mask in SGPRs, and every region that
     // assigns it costs three scalar mask instructions at its merge point — the scalar unit is shared by the CU's four SIMDs.
     uint32_t slow = 0, live = 1, need_pop = 0;
@@ -352,11 +355,14 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
         const bool go_left = qa < th;
         // T ≥ depth − DF (launch_fast_kd), and a descent pushes at most depth − 1 entries: position sp − T never reaches DF here
         const uint32_t far_slot = go_left ? right : cur + 1u;
-        if (sp < T) {
-            const bool lt = d2 < min_drop;
-            min_drop2 = lt ? min_drop : (d2 < min_drop2 ? d2 : min_drop2);
-            far_drop = lt ? far_slot : far_drop;
-            min_drop = lt ? d2 : min_drop;
+        if (sp < T) {  // levels come in increasing depth: the new entry is younger than both candidates
+            const bool lt1 = d2 < c1_d2, lt2 = d2 < c2_d2;
+            c3_d2 = lt2 ? c2_d2 : (d2 < c3_d2 ? d2 : c3_d2);
+            c2_d2 = lt1 ? c1_d2 : (lt2 ? d2 : c2_d2);
+            c2_far = lt1 ? c1_far : (lt2 ? far_slot : c2_far);
+            c1_younger = lt1 ? 1u : (lt2 ? 0u : c1_younger);
+            c1_far = lt1 ? far_slot : c1_far;
+            c1_d2 = lt1 ? d2 : c1_d2;
         } else {
             s_stack[sp - T][tid] = make_uint2(far_slot, __float_as_uint(d2));
         }
@@ -420,21 +426,26 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
             const float bound = set.top() * alpha_eff;  // +inf while the set is not full: everything passes
             const int avail = sp - T;
             if (avail <= 0) {
-                // nothing stored is left. sp > 0: only un-stored first-descent entries (levels 0..sp-1) remain.
-                const bool may_pass = sp > 0 && !(min_drop >= bound);
-                live = may_pass ? 1u : 0u;  // otherwise finished: every un-stored entry is rejected by the final bound
-                const bool single = may_pass && min_drop2 >= bound;  // exactly one of them can pass, now or later
-                if (single) {
-                    cur = far_drop;
+                // nothing stored is left: only un-stored first-descent entries remain, of which the candidates are what matters
+                const bool p1 = c1_d2 < bound;  // false also when there is none (+inf)
+                live = p1 ? 1u : 0u;            // otherwise finished: every un-stored entry is rejected by the final bound
+                if (p1 && !(c3_d2 < bound)) {
+                    const bool p2 = c2_d2 < bound;
+                    const bool take1 = !p2 || c1_younger != 0u;
+                    cur = take1 ? c1_far : c2_far;
+                    // the other candidate stays on for a later test if it passes now; else it (like everything else) is out for good
+                    c1_d2 = p2 ? (take1 ? c2_d2 : c1_d2) : __builtin_inff();
+                    c1_far = take1 ? c2_far : c1_far;
+                    c2_d2 = __builtin_inff();
+                    c3_d2 = __builtin_inff();
                     sp = 0;
                     T = 0;
                     need_pop = 0;
-                    min_drop = __builtin_inff();
-                    min_drop2 = __builtin_inff();
-                } else if (may_pass) {
+                } else if (p1) {
                     if (STAMP && replay_counter) atomicAdd(replay_counter, 1ull);  // diagnostic build only: a live pointer across the loop costs 1.6 %
-                    // Rare: walk the un-stored levels 0..sp-1 again from the root (same `<` decisions, hence the same internal
-                    // nodes) and push them under the pruning rule with the CURRENT bound; from now on every position is stored.
+                    // Rare: three or more could pass. Walk the un-stored levels 0..sp-1 again from the root (same `<` decisions, hence
+                    // the same internal nodes) and push them under the pruning rule with the CURRENT bound; from now on every position
+                    // is stored. (No direct expansion has happened before: it leaves c3 = +inf.)
                     const int levels = sp;
                     uint32_t c = 0;
                     sp = 0;
@@ -455,8 +466,9 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                         }
                         c = go_left ? c + 1u : right;
                     }
-                    min_drop = __builtin_inff();
-                    min_drop2 = __builtin_inff();
+                    c1_d2 = __builtin_inff();
+                    c2_d2 = __builtin_inff();
+                    c3_d2 = __builtin_inff();
                 }
                 // need_pop stays set: the re-pushed entries are popped like any others (an empty stack ends the query next trip)
             } else {
