@@ -400,3 +400,20 @@ def test_bench_line_contract(mode):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
     assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-3 * d["value"]
     assert d["median_translation_error_to_truth_m"] < 0.1
+
+
+# ----------------------------------------------------------------------------------------------- other LDS stack depths
+@pytest.mark.parametrize("rows", ["12", "24"])
+def test_search_parity_at_other_stack_depths(rows):
+    """The fast traversal stores `LOCGPU_FAST_STACK` stack rows in LDS and keeps the levels above them as candidates (direct
+    expansion, replay) — with 12 rows the replay and overflow paths run ~100× more often than at the default 15, with 24 hardly
+    ever. The index-list / H,B / alignment parity tests must pass unchanged either way (the setting is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LOCGPU_FAST_STACK=rows)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x", "-k",
+                          "knn or hb or align or golden or 10m"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
+    assert " passed" in out.stdout
