@@ -417,3 +417,35 @@ def test_search_parity_at_other_stack_depths(rows):
                           "knn or hb or align or golden or 10m"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
     assert " passed" in out.stdout
+
+
+# ----------------------------------------------------------------------------------------------- measurement hooks
+def test_profile_modes_and_marshalled_scans():
+    """locgpu_profile_enable: 1 times all three stages, 2 only the search stage (what bench.py uses inside its timed region); a
+    pre-marshalled scan list uploads the same bytes as the list itself."""
+    from loc_lib_amd import api, synth
+    ctx = api.Context(0)
+    m = synth.make_map(200_000)
+    ctx.icp_set_target(m)
+    scans = [synth.make_scan(i, subsample=20000) for i in range(4)]
+    inits = np.stack([synth.make_pose(i)[1] for i in range(4)])
+    opts = api.icp_opts(method=api.P2PLANE)
+    b = ctx.batch(scans)
+    ref, _ = ctx.icp_align_batch(b, inits, opts)
+    for mode, stages in ((1, ("search", "accum", "solve")), (2, ("search",))):
+        ctx.profile_read(reset=True)
+        ctx.profile_enable(mode)
+        poses, _ = ctx.icp_align_batch(b, inits, opts)
+        ctx.profile_enable(False)
+        p = ctx.profile_read(reset=True)
+        assert np.array_equal(poses, ref)
+        for st in ("search", "accum", "solve"):
+            if st in stages:
+                assert p[st + "_n"] > 0 and p[st + "_ms"] > 0
+            else:
+                assert p[st + "_n"] == 0 and p[st + "_ms"] == 0
+    b2 = ctx.batch_empty(4, max(len(s) for s in scans)) if hasattr(ctx, "batch_empty") else ctx.batch(scans)
+    b2.upload_async(api.MarshalledScans(scans))
+    b2.upload_wait()
+    poses2, _ = ctx.icp_align_batch(b2, inits, opts)
+    assert np.array_equal(poses2, ref)
