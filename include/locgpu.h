@@ -220,6 +220,11 @@ LOCGPU_API int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int res
  * out[2] = grid mode: queries the tile kernel handed to the ring-walk kernel, out[3] = diagnostic build (LOCGPU_STAMP=1) only: queries of the
  * fast tree search that had to walk the un-stored top levels of their first descent again ("replays"); 0 otherwise. */
 LOCGPU_API int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset);
+/* Test hook: the neighbour lists the batch's most recent search stage left behind (the one inside the last locgpu_icp_hb_batch /
+ * align call on it; k = 5, or 1 for P2P), as ORIGINAL point indices of the target cloud in ascending distance — the order
+ * KdTree::GetClosestPoint returns (kdtree.cpp:160-165). out[(scan * max_points + i) * k + j]; -1 where there is none
+ * (points beyond a scan's count hold stale values). This is how the tests compare the HOT search kernel's lists with the oracle's. */
+LOCGPU_API int locgpu_debug_batch_nn(locgpu_ctx* ctx, locgpu_batch* batch, int k, int32_t* out);
 
 /* =====================================================================================================================
  * Clouds resident in HBM and the filters either side of the matcher.

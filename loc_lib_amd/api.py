@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "locgpu_transform_cloud", "locgpu_batch_create", "locgpu_batch_destroy", "locgpu_icp_align_batch", "locgpu_ndt_align_batch",
     "locgpu_icp_hb_batch", "locgpu_gn_update", "locgpu_ndt_set_target", "locgpu_ndt_target_info", "locgpu_ndt_dump",
     "locgpu_ndt_align", "locgpu_profile_enable", "locgpu_profile_read", "locgpu_visit_count_enable", "locgpu_visit_count_read",
-    "locgpu_search_stats_read", "locgpu_graph_enable",
+    "locgpu_search_stats_read", "locgpu_debug_batch_nn", "locgpu_graph_enable",
     "locgpu_cloud_create", "locgpu_cloud_destroy", "locgpu_cloud_upload", "locgpu_cloud_info", "locgpu_cloud_download", "locgpu_cloud_copy",
     "locgpu_cloud_remove_nan", "locgpu_cloud_voxel_filter", "locgpu_cloud_crop_box", "locgpu_cloud_transform", "locgpu_cloud_append",
     "locgpu_icp_set_target_cloud", "locgpu_ndt_set_target_cloud", "locgpu_icp_align_cloud", "locgpu_ndt_align_cloud",
@@ -103,7 +103,7 @@ def lib():
             "locgpu_ndt_dump": (i32, [vp, vp, vp, vp, sz, vp]), "locgpu_ndt_align": (i32, [vp, vp, sz, sz, vp, vp, vp]),
             "locgpu_profile_enable": (i32, [vp, i32]), "locgpu_profile_read": (i32, [vp, vp, i32]),
             "locgpu_visit_count_enable": (i32, [vp, i32]), "locgpu_visit_count_read": (i32, [vp, vp, i32]),
-            "locgpu_search_stats_read": (i32, [vp, vp, i32]), "locgpu_graph_enable": (i32, [vp, i32]),
+            "locgpu_search_stats_read": (i32, [vp, vp, i32]), "locgpu_debug_batch_nn": (i32, [vp, vp, i32, vp]), "locgpu_graph_enable": (i32, [vp, i32]),
             "locgpu_cloud_create": (i32, [vp, vp]), "locgpu_cloud_destroy": (None, [vp]),
             "locgpu_cloud_upload": (i32, [vp, vp, sz, sz, sz, i32]), "locgpu_cloud_info": (i32, [vp, vp, vp]),
             "locgpu_cloud_download": (i32, [vp, vp, sz, sz, sz]), "locgpu_cloud_copy": (i32, [vp, vp]),
@@ -412,6 +412,12 @@ class Context:
         return dict(nodes=int(out[0]), leaves=int(out[1]), queries=int(out[2]))
 
 
+    def debug_batch_nn(self, batch, k=5):
+        """Neighbour lists of the batch's most recent search stage as target point indices, [n_scans, max_points, k] (-1 = none)."""
+        out = np.empty((batch.n_local, batch.max_points, k), dtype=np.int32)
+        self._check(lib().locgpu_debug_batch_nn(self._h, batch._h, int(k), out.ctypes.data))
+        return out  # rows beyond a scan's point count are stale
+
     def search_stats_read(self, reset=True):
         out = np.zeros(4, dtype=np.uint64)
         self._check(lib().locgpu_search_stats_read(self._h, out.ctypes.data, int(reset)))
@@ -571,10 +577,12 @@ class Batch:
         self._keep = None
         if scans is None:  # capacity only; fill with upload_async
             self.n_local = self.n_scans = int(n_scans)
+            self.max_points = int(max_points)
             ctx._check(lib().locgpu_batch_create_empty(ctx._h, self.n_scans, int(max_points), ctypes.byref(self._h)))
             return
         scans, ptrs, cnts, stride = self._marshal(scans)
         self.n_local = len(scans)
+        self.max_points = max(s.shape[0] for s in scans)
         if n_total is None:
             self.n_scans = self.n_local
             ctx._check(lib().locgpu_batch_create(ctx._h, ptrs, cnts, stride, self.n_local, ctypes.byref(self._h)))

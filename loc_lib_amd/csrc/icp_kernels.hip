@@ -643,8 +643,23 @@ __global__ __launch_bounds__(kBlock) void transform_cloud_kernel(const float4* _
     dst[i] = o;
 }
 
+// Test hook: the search stage's slot lists as original point indices (what knn_query_kernel reports), out[(gi * k) + j].
+__global__ __launch_bounds__(kBlock) void nn_to_index_kernel(const uint2* __restrict__ tree, const uint32_t* __restrict__ nn, size_t nn_pitch, size_t n_queries,
+                                                             int k, int32_t* __restrict__ out) {
+    const size_t gi = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gi >= n_queries) return;
+    for (int j = 0; j < k; ++j) {
+        const uint32_t slot = nn[(size_t)j * nn_pitch + gi];
+        out[gi * k + j] = slot == kInvalidSlot ? -1 : (int32_t)(tree[slot].y & 0x3FFFFFFFu);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Launchers (declared in launch.hpp).
+void launch_nn_to_index(const uint2* tree, const uint32_t* nn, size_t nn_pitch, size_t n_queries, int k, int32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(nn_to_index_kernel, dim3((unsigned)((n_queries + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, tree, nn, nn_pitch, n_queries, k, out);
+}
+
 template <int KMAX, int D>
 static void launch_search_kd(const SearchArgs& a, hipStream_t s) {
     dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);

@@ -879,6 +879,22 @@ int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* poses, c
     return LOCGPU_OK;
 }
 
+int locgpu_debug_batch_nn(locgpu_ctx* ctx, locgpu_batch* b, int k, int32_t* out) {
+    if (!ctx || !b || b->ctx != ctx || !out || k < 1 || k > 5) return fail(ctx, LOCGPU_ERR_INVALID, "debug_batch_nn: bad arguments");
+    if (!ctx->d_tree) return fail(ctx, LOCGPU_ERR_NO_TARGET, "debug_batch_nn: no ICP target");
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nq = (size_t)b->n_scans * b->max_n;
+    int32_t* d_out = nullptr;
+    LOCGPU_HIP(ctx, hipMalloc((void**)&d_out, nq * k * sizeof(int32_t)));
+    launch_nn_to_index(ctx->d_tree, b->d_nn, b->pitch, nq, k, d_out, ctx->stream);
+    const hipError_t e = hipMemcpyAsync(out, d_out, nq * k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_out);
+    LOCGPU_HIP(ctx, e);
+    LOCGPU_HIP(ctx, e2);
+    return LOCGPU_OK;
+}
+
 int locgpu_icp_hb(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double pose[7], const locgpu_icp_opts* opts, double H[36],
                   double B[6], int64_t* effective_num, int* ok) {
     GnParams prm{};

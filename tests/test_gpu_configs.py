@@ -413,8 +413,9 @@ def test_search_parity_at_other_stack_depths(rows):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LOCGPU_FAST_STACK=rows)
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x", "-k",
-                          "knn or hb or align or golden or 10m"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_configs.py"),
+                          "-q", "-m", "gpu", "-x", "-k", "knn or hb or (align and not sharded and not ndt) or golden or hot_search"], env=env, capture_output=True, text=True,
+                         timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
     assert " passed" in out.stdout
 
@@ -449,3 +450,64 @@ def test_profile_modes_and_marshalled_scans():
     b2.upload_wait()
     poses2, _ = ctx.icp_align_batch(b2, inits, opts)
     assert np.array_equal(poses2, ref)
+
+
+# ----------------------------------------------------------------------------------------------- the hot search kernel's own lists
+def _oracle_lists(locref, tree, scan, pose, k, approximate):
+    q = locref.transform_points(pose, np.ascontiguousarray(scan[:, :3], dtype=np.float64)).astype(np.float32)  # SE3·p in f64, then ToPointType
+    return tree.knn(q, k, approximate=approximate, alpha=0.1)
+
+
+@pytest.mark.parametrize("approximate", [True, False])
+def test_hot_search_kernel_lists_equal_oracle(approximate):
+    """The neighbour lists of the search stage that the alignments actually run (icp_search_fast_kernel: un-stored top levels,
+    direct expansion of the candidates, in-wave exact traversal, redo list) — read back through locgpu_debug_batch_nn — equal the
+    oracle's KdTree::GetClosestPoint lists index for index, in order: ragged batch, poses from far off to converged, ANN and exact."""
+    from loc_lib_amd import api, synth
+    from oracle import locref
+    ctx = api.Context(0)
+    m = synth.make_map(1_000_000)
+    ctx.icp_set_target(m)
+    tree = locref.KdTree(m)
+    scans = [synth.make_scan(0), synth.make_scan(5, subsample=30000), synth.make_scan(9, subsample=777)]
+    truth = [synth.make_pose(s)[0] for s in (0, 5, 9)]
+    inits = [synth.make_pose(s)[1] for s in (0, 5, 9)]
+    far = [synth.make_pose(s, trans_amp=3.0, rot_amp_deg=20.0)[1] for s in (0, 5, 9)]
+    b = ctx.batch(scans)
+    opts = api.icp_opts(method=api.P2PLANE)
+    opts.approximate = 1 if approximate else 0
+    for poses in (inits, truth, far):
+        ctx.icp_hb_batch(b, np.stack(poses), opts)
+        got = ctx.debug_batch_nn(b, 5)
+        for i, (scan, pose) in enumerate(zip(scans, poses)):
+            want = _oracle_lists(locref, tree, scan, pose, 5, approximate)
+            assert np.array_equal(got[i, :len(scan)], want), (i, int(np.sum(np.any(got[i, :len(scan)] != want, axis=1))))
+
+
+def test_hot_search_kernel_lists_on_ties_duplicates_and_p2p():
+    """Same check where the fast traversal cannot finish on its own: a lattice map (every distance ties → exact traversal in the
+    wave or through the redo list), a map of duplicated points, and the k = 1 search of the point-to-point method."""
+    from loc_lib_amd import api
+    from oracle import locref
+    rng = np.random.default_rng(5)
+    g = np.arange(-12, 13, dtype=np.float32)
+    lattice = np.stack(np.meshgrid(g, g, g[:6], indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float32)
+    dup = np.repeat(rng.uniform(-20, 20, size=(4000, 3)).astype(np.float32), 3, axis=0)
+    pose = np.array([0.01, -0.02, 0.03, 0.0, 0.11, -0.07, 0.05])
+    pose[3] = np.sqrt(1.0 - np.sum(pose[:3] ** 2))
+    for cloud in (lattice, dup):
+        ctx = api.Context(0)
+        ctx.icp_set_target(cloud)
+        tree = locref.KdTree(cloud)
+        scan = (cloud[rng.choice(len(cloud), 5000)] + rng.normal(0, 0.05, size=(5000, 3))).astype(np.float32)
+        scan_exact = cloud[rng.choice(len(cloud), 3000)].copy()  # queries ON map points: zero distances, ties everywhere
+        for s in (scan, scan_exact):
+            b = ctx.batch([s])
+            for method, k in ((api.P2PLANE, 5), (api.P2P, 1)):
+                opts = api.icp_opts(method=method)
+                ctx.icp_hb_batch(b, pose[None], opts)
+                got = ctx.debug_batch_nn(b, k)[0, :len(s)]
+                want = _oracle_lists(locref, tree, s, pose, k, True)
+                assert np.array_equal(got, want), (len(cloud), method, int(np.sum(np.any(got != want, axis=1))))
+            b.close()
+        ctx.close() if hasattr(ctx, "close") else None
