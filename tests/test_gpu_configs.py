@@ -368,7 +368,7 @@ def test_bfnn_matches_brute_force(gpu_ctx, api, locref, small_world, k):
 
 
 # ----------------------------------------------------------------------------------------------- bench.py contract
-@pytest.mark.parametrize("mode", ["weak_streaming", "resident", "strong"])
+@pytest.mark.parametrize("mode", ["weak_streaming", "strong"])  # --resident differs by one flag; each mode is a fresh interpreter that imports torch
 def test_bench_line_contract(mode):
     """bench.py on a reduced workload (1 M-pt map, 8 scans): exactly one JSON line with the keys the driver and the judge read;
     the streaming default really has the scan copy inside the timed region; the strong mode runs the sharded batch over RCCL."""
