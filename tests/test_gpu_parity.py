@@ -625,6 +625,15 @@ def test_bench_config_parity_10m(gpu_ctx, api, locref, synth):
         dt, dr = pose_delta(out[i], ro["pose"])
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and dt < 1e-9, (i, dt, dr)
         assert stats[i]["iterations"] == ro["iters"]
+    # and the hot search kernel's neighbour lists themselves, at the poses an alignment starts from and ends at (230 400 queries each)
+    tree = locref.KdTree(m)
+    for poses in (inits, out):
+        gpu_ctx.icp_hb_batch(b, poses, api.icp_opts(method=2))
+        got = gpu_ctx.debug_batch_nn(b, 5)
+        for i, s in enumerate(scans):
+            q = locref.transform_points(poses[i], np.ascontiguousarray(s[:, :3], dtype=np.float64)).astype(np.float32)
+            want = tree.knn(q, 5, approximate=True, alpha=0.1)
+            assert np.array_equal(got[i, :len(s)], want), (i, int(np.sum(np.any(got[i, :len(s)] != want, axis=1))))
     b.close()
 
 
