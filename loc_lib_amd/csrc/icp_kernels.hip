@@ -46,8 +46,9 @@ __global__ __launch_bounds__(kBlock) void icp_search_kernel(const uint2* __restr
     }
 }
 
-// Streaming accesses of the search kernel (each element touched once per launch): keep them from evicting tree nodes out of L2
-// (search 25.0 -> 24.3 ms per 256-scan step; the same hint on the fit kernel's reads of these arrays makes the search slower again).
+// Streaming accesses (elements touched once per launch) are marked non-temporal so that they do not evict tree nodes from L2 —
+// measured one by one on the bench workload (search ms per 256-scan step): the search kernel's neighbour-list stores and source loads
+// 25.0 -> 24.3; the fit kernel's neighbour-list loads -> 24.0. NOT the fit kernel's source loads (-> 24.7: the next search wants them cached).
 typedef float f32x4_nt __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 load_once(const float4* __restrict__ p) {
     const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             // all five indices and the point in one round trip (not: the fifth, then the rest behind its test)
             uint32_t slot[5];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) slot[j] = nn[(size_t)j * nn_pitch + gi];
+            for (int j = 0; j < 5; ++j) slot[j] = __builtin_nontemporal_load(&nn[(size_t)j * nn_pitch + gi]);
             const float4 p = src[gi];
             if (slot[4] != kInvalidSlot) {  // nn.size() > 3: k=5 yields 5 or (k > size_) none
                 const D3 q{(double)p.x, (double)p.y, (double)p.z};
