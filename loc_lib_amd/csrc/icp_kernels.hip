@@ -364,8 +364,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             for (int j = 0; j < 5; ++j) slot[j] = __builtin_nontemporal_load(&nn[(size_t)j * nn_pitch + gi]);
             const float4 p = src[gi];
             if (slot[4] != kInvalidSlot) {  // nn.size() > 3: k=5 yields 5 or (k > size_) none
-                const D3 q{(double)p.x, (double)p.y, (double)p.z};
-                const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
                 D3 nb[5];
 #pragma unroll
                 for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, slot[j]);
@@ -380,6 +378,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 }
                 if (fit) {
                     fitted = 1.0;  // effective_num++ before the residual gate (icp cpp:184)
+                    const D3 q{(double)p.x, (double)p.y, (double)p.z};  // the transformed point is only needed from here on
+                    const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
                     const double dis = dot3(n3, qs) + n4[3];
                     if (!(fabs(dis) > max_plane_distance)) {
                         const double* R = st[scan].R;
