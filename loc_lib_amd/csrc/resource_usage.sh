@@ -1,7 +1,7 @@
 #!/bin/bash
 # Prints name / VGPRs / scratch / LDS / occupancy of every kernel in a .hip file (compiler view).
 f=${1:-icp_kernels.hip}
-/opt/rocm/bin/hipcc -std=c++17 -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -fPIC -c "$f" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 \
+/opt/rocm/bin/hipcc -std=c++17 -O3 --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize $( [ "$(basename "$f")" = icp_kernels.hip ] && echo -mllvm -amdgpu-sched-strategy=max-ilp ) -fPIC -c "$f" -o /dev/null -Rpass-analysis=kernel-resource-usage 2>&1 \
  | python3 -c '
 import sys,re
 cur={}
