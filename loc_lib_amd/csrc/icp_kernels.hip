@@ -1,6 +1,7 @@
 // loc_lib_amd/csrc/icp_kernels.hip — kernel bodies + launchers of the ICP hot path (see icp_kernels.hpp).
 #include "icp_kernels.hpp"
 #include "launch.hpp"
+#include "search_walk.hpp"
 
 #include <cstdlib>
 
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
     const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
     SortedSet<K> set;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
-    unsigned long long diag[5] = {0, 0, 0, 0, 0};
+    unsigned long long diag[6] = {0, 0, 0, 0, 0, 0};
     // The fast traversal assumes finite arithmetic (the tree is `bounded`, kdtree_build.cpp): a query that is NaN, infinite or
     // astronomically far goes straight to the exact kernel.
     const float fqx = (float)qs.x, fqy = (float)qs.y, fqz = (float)qs.z;
@@ -99,6 +100,9 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
         }
         for (int j = 0; j < 5; ++j) atomicAdd(&search_stats[2 + j], diag[j]);                 // lane sums
         if ((tid & 63) == 0) { for (int j = 0; j < 5; ++j) atomicAdd(&search_stats[7 + j], wmax[j]); atomicAdd(&search_stats[12], 1ull); }  // wave maxima, waves
+        atomicAdd(&search_stats[16 + min((int)(diag[2] >> 1), 63)], 1ull);
+        redo_list[nn_pitch + gi] = (uint32_t)(diag[5] << 16) | (uint32_t)min(diag[2], 65535ull);  // the diagnostic build allocates 2 x pitch entries
+        if ((tid & 63) == 0) atomicAdd(&search_stats[80 + min((int)(wmax[2] >> 1), 63)], 1ull);
     }
     if (BLK == 64 && !STAMP) {
         // One or two unfinished queries in this wave (the usual case: ≈30 of 29.5 M): answer them here with the exact traversal, the
@@ -131,6 +135,97 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
     } else {
 #pragma unroll
         for (int j = 0; j < K; ++j) __builtin_nontemporal_store(set.id[j], &nn[(size_t)j * nn_pitch + gi]);
+    }
+}
+
+// K1, round 3: the traversal of search_walk.hpp. One-wave workgroups; dynamic LDS = DF rows x 64 lanes x 8 B (the stack is the
+// ONLY LDS of the kernel: a push beyond the last row must fall off the allocation). `dummy` = slot of the sentinel leaf.
+template <int K, int DF>
+__global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+                                                             const int* __restrict__ counts, const PoseState* __restrict__ st,
+                                                             uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, float alpha_eff, int T,
+                                                             unsigned int tree_bytes, uint32_t dummy, int skip_nonfinite, uint32_t* __restrict__ redo_list,
+                                                             unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats, int lanes) {
+    extern __shared__ uint2 s_dyn[];
+    constexpr int ROWB = 64 * 8;
+    const int scan = blockIdx.y;
+    if (st[scan].done) return;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * lanes + tid;
+    if (tid >= lanes || i >= counts[scan]) return;
+    const size_t gi = (size_t)scan * max_n + i;
+    const float4 p = load_once(&src[gi]);
+    if (skip_nonfinite && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {  // pcl::isFinite, icp cpp:64 (P2P only)
+#pragma unroll
+        for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = kInvalidSlot;
+        return;
+    }
+    if (search_stats) atomicAdd(&search_stats[0], 1ull);
+    const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
+    Walk<K> w;
+    w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
+#pragma unroll
+    for (int j = 0; j < K; ++j) { w.d[j] = __builtin_inff(); w.id[j] = kInvalidSlot; }
+    w.slow = 0;
+    // finite-arithmetic precondition of the fast traversal (the tree is `bounded`): anything else goes to the exact kernel
+    const bool sane = fabsf(w.qx) < 1e18f && fabsf(w.qy) < 1e18f && fabsf(w.qz) < 1e18f;
+    const uint32_t col_addr = (uint32_t)(size_t)(&s_dyn[tid]);
+    if (sane) {
+        walk_descend<K, ROWB>(rsrc, w, T, col_addr);
+    } else {
+        w.cur = dummy; w.avail = 0; w.max_avail = 0; w.c3n = 0; w.slow = 1;
+    }
+    for (;;) {
+        bool replay;
+        do replay = walk_trip<K, ROWB>(rsrc, w, alpha_eff, dummy, T, col_addr); while (__ballot(replay) == 0ull && __ballot(w.cur != dummy || w.avail > 0) != 0ull);
+        if (__ballot(w.c3n == 1u) == 0ull) break;
+#ifdef LOCGPU_WALK_STATS
+        if (search_stats && w.c3n == 1u) atomicAdd(&search_stats[4], 1ull);
+#endif
+        walk_replay<K, ROWB>(rsrc, w, alpha_eff, dummy, T, col_addr);
+    }
+    bool slow = w.slow != 0u || w.max_avail > DF;
+#ifdef LOCGPU_WALK_STATS
+    if (search_stats) {
+        if (w.max_avail > DF) atomicAdd(&search_stats[2], 1ull);
+        if (w.slow != 0u) atomicAdd(&search_stats[3], 1ull);
+    }
+#endif
+#pragma unroll
+    for (int j = 0; j + 1 < K; ++j) slow |= w.d[j] == w.d[j + 1];  // equal distances in the final set: heap pop order is layout-dependent
+#ifdef LOCGPU_WALK_STATS
+    if (search_stats && slow) atomicAdd(&search_stats[5], 1ull);
+#endif
+    {
+        // One or two unfinished queries in this wave: answer them here with the exact traversal on the wave's (now dead) stacks.
+        const unsigned long long slow_mask = __ballot(slow);
+        if (slow_mask != 0ull && __popcll(slow_mask) <= 2) {
+            if (slow) {
+                uint32_t(*s_far)[2] = reinterpret_cast<uint32_t(*)[2]>(&s_dyn[0]);
+                float(*s_d2)[2] = reinterpret_cast<float(*)[2]>(reinterpret_cast<char*>(&s_dyn[0]) + 64 * 2 * sizeof(uint32_t));
+                static_assert(DF * ROWB >= 64 * 2 * 8, "exact stack columns do not fit");
+                const int col = __popcll(slow_mask & ((1ull << tid) - 1ull));
+                KnnHeap<K> heap;
+                uint32_t nvis = 0, lvis = 0, out[K];
+                int cnt;
+                tree_knn_flat<K, 64, false, 2>(tree, w.qx, w.qy, w.qz, K, alpha_eff, s_far, s_d2, col, heap, nvis, lvis);
+                heap_to_sorted<K>(heap, out, cnt);
+#pragma unroll
+                for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = out[j];
+                if (search_stats) atomicAdd(&search_stats[1], 1ull);
+            } else {
+#pragma unroll
+                for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
+            }
+            return;
+        }
+    }
+    if (slow) {
+        redo_list[atomicAdd(redo_count, 1u)] = (uint32_t)gi;
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
     }
 }
 
@@ -741,6 +836,19 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         return;
     }
     static const int blk = [] { const char* e = getenv("LOCGPU_FAST_BLOCK"); const int v = e ? atoi(e) : 64; return (v == 256 || v == 128) ? v : 64; }();
+    static const int walk = [] { const char* e = getenv("LOCGPU_WALK"); return e ? atoi(e) : 0; }();
+    if (walk == 1) {
+        // round-3 traversal (search_walk.hpp): rows 0/1 of the DF stored rows hold the candidates of the un-stored levels
+        const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
+        static const int small_lanes = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); const int v = e ? atoi(e) : 16; return (v == 16 || v == 32) ? v : 64; }();
+        const int lanes = ((size_t)((a.max_n + 63) / 64) * a.n_scans <= 2048) ? small_lanes : 64;
+        dim3 g2((a.max_n + lanes - 1) / lanes, a.n_scans);
+        hipLaunchKernelGGL((icp_search_walk_kernel<K, DF>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+                           a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, (uint32_t)(a.tree_bytes / 8), a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats, lanes);
+        hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
+                           a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
+        return;
+    }
     if (blk != 256) {
         static const int lds_pad = [] { const char* e = getenv("LOCGPU_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiment: extra dynamic LDS lowers occupancy
         static const int small_lanes = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); const int v = e ? atoi(e) : 16; return (v == 16 || v == 32) ? v : 64; }();

@@ -23,6 +23,7 @@ namespace locgpu {
 constexpr int kBlock = 256;
 constexpr int kAccW = 32;          // doubles per block partial: 21 H (upper) + 6 B + effective_num + 4 spare
 constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
+constexpr int kSearchStatSlots = 16 + 2 * 64;  // [0..15] counters, then two 64-bin histograms of the LOCGPU_STAMP diagnostic build
 
 struct GnParams {
     int method;              // locgpu_icp_method, 3 = direct NDT, 4 = incremental NDT
@@ -323,7 +324,7 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
                                               uint2 (*s_stack)[BLK], int tid, SortedSet<K>& set, unsigned long long* diag = nullptr,
                                               unsigned long long* replay_counter = nullptr) {
     unsigned long long t_begin = 0, t_mid = 0;
-    unsigned int n_trips = 0, n_visit = 0, n_pop = 0;
+    unsigned int n_trips = 0, n_visit = 0, n_pop = 0, n_desc = 0;
     if (STAMP) t_begin = __builtin_amdgcn_s_memtime();
     set.init();
     int sp = 0;
@@ -347,6 +348,7 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
         const uint32_t meta = w.y;
         const uint32_t tag = meta >> 30;
         if (tag == 3u) break;
+        if (STAMP) n_desc++;
         const float th = as_f32(w.x);
         const float qa = tag == 0u ? qx : (tag == 1u ? qy : qz);
         const float dd = qa - th;
@@ -500,7 +502,7 @@ __device__ __forceinline__ bool tree_knn_fast(__amdgpu_buffer_rsrc_t tree_rsrc, 
     for (int j = 0; j + 1 < K; ++j) slow |= set.d[j] == set.d[j + 1] ? 1u : 0u;
     if (STAMP) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-        diag[0] = t_mid - t_begin; diag[1] = t_end - t_begin; diag[2] = n_trips; diag[3] = n_visit; diag[4] = n_pop;
+        diag[0] = t_mid - t_begin; diag[1] = t_end - t_begin; diag[2] = n_trips; diag[3] = n_visit; diag[4] = n_pop; diag[5] = n_desc;
     }
     return slow != 0;
 }

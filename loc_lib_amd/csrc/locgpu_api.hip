@@ -217,7 +217,7 @@ static int build_host_tree(locgpu_ctx* ctx, const void* pts, size_t n, size_t st
 static int install_tree_meta(locgpu_ctx* ctx, const long long meta[6]) {
     free_grid(ctx);
     const size_t slots = (size_t)meta[0], leaves = (size_t)meta[1];
-    if (slots > ctx->tree_cap_slots) {
+    if (slots + 2 > ctx->tree_cap_slots) {  // + the sentinel leaf behind the tree (search_walk.hpp)
         if (ctx->d_tree) { LOCGPU_HIP(ctx, hipFree(ctx->d_tree)); ctx->d_tree = nullptr; ctx->tree_cap_slots = 0; }
         const size_t cap = slots + slots / 4 + 1024;
         LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_tree, cap * sizeof(uint64_t)));
@@ -237,6 +237,13 @@ static int install_tree_meta(locgpu_ctx* ctx, const long long meta[6]) {
     ctx->tree_bounded = meta[5] != 0;
     ctx->target_epoch++;
     return LOCGPU_OK;
+}
+
+// The sentinel leaf behind the packed tree (two slots at index tree_slots): what a lane of the search kernel "visits" when it has
+// no node to visit. Its coordinates are so large that the squared distance overflows to +inf for every sane query.
+static hipError_t write_sentinel_leaf(locgpu_ctx* ctx) {
+    static const uint32_t leaf[4] = {0x7F61B1E6u /* 3.0e38f */, 0xC0000000u, 0x7F61B1E6u, 0x7F61B1E6u};
+    return hipMemcpyAsync(ctx->d_tree + ctx->tree_slots, leaf, sizeof(leaf), hipMemcpyHostToDevice, ctx->stream);
 }
 
 int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes) {
@@ -260,6 +267,7 @@ int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
     lap("device buffers");
     LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_leaf_slots, t.leaf_slots.data(), t.leaf_slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    LOCGPU_HIP(ctx, write_sentinel_leaf(ctx));
     LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     lap("H2D");
     return LOCGPU_OK;
@@ -299,6 +307,7 @@ int locgpu_icp_set_target_bcast(locgpu_ctx* ctx, const void* pts, size_t n, size
     if (rccl().Broadcast(ctx->d_tree, ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ncclChar, root, comm, s) != ncclSuccess ||
         rccl().Broadcast(ctx->d_leaf_slots, ctx->d_leaf_slots, ctx->num_leaves * sizeof(uint32_t), ncclChar, root, comm, s) != ncclSuccess)
         return fail(ctx, LOCGPU_ERR_NO_DEVICE, "icp_set_target_bcast: broadcast of the tree failed");
+    LOCGPU_HIP(ctx, write_sentinel_leaf(ctx));
     LOCGPU_HIP(ctx, hipStreamSynchronize(s));
     return LOCGPU_OK;
 }
@@ -405,7 +414,7 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               hip_ok(ctx, hipMalloc((void**)&b->d_nn, 5 * b->pitch * sizeof(uint32_t)), "hipMalloc nn") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_partials, (size_t)n_scans * b->blocks_per_scan * kAccW * sizeof(double)), "hipMalloc partials") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_hb, (size_t)n_total * 44 * sizeof(double)), "hipMalloc hb") &&
-              hip_ok(ctx, hipMalloc((void**)&b->d_redo_list, b->pitch * sizeof(uint32_t)), "hipMalloc redo") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_redo_list, (getenv("LOCGPU_STAMP") ? 2 : 1) * b->pitch * sizeof(uint32_t)), "hipMalloc redo") &&  // diagnostic build: + per-query trip counts
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, 2 * sizeof(unsigned int)), "hipMalloc redo") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_total * sizeof(PoseState)), "hipHostMalloc state") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_total * 44 * sizeof(double)), "hipHostMalloc hb") &&
@@ -1006,11 +1015,11 @@ int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset) {
     if (!ctx || !out) return LOCGPU_ERR_INVALID;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_search_stats) {
-        LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_search_stats, 16 * sizeof(unsigned long long)));
-        LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, 16 * sizeof(unsigned long long)));
+        LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_search_stats, kSearchStatSlots * sizeof(unsigned long long)));
+        LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, kSearchStatSlots * sizeof(unsigned long long)));
     }
     LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long h[16];
+    unsigned long long h[kSearchStatSlots];
     LOCGPU_HIP(ctx, hipMemcpy(h, ctx->d_search_stats, sizeof(h), hipMemcpyDeviceToHost));
     out[0] = h[0]; out[1] = h[1]; out[2] = getenv("LOCGPU_STAMP") ? 0 : h[2]; out[3] = getenv("LOCGPU_STAMP") ? h[15] : 0;
     if (getenv("LOCGPU_STAMP") && h[12]) {  // diagnostic build only
@@ -1018,7 +1027,14 @@ int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset) {
         fprintf(stderr, "[locgpu stamp] per lane: descent %.0f cyc, total %.0f cyc, trips %.1f (visit %.1f, pop-only %.1f) | per wave (max over lanes): "
                         "descent %.0f cyc, total %.0f cyc, trips %.1f (visit %.1f, pop %.1f)\n",
                 h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / w, h[8] / w, h[9] / w, h[10] / w, h[11] / w);
+        // histograms of main-loop trips (bins of two trips): what a lane needs, and what its wave pays (the maximum over its lanes)
+        fprintf(stderr, "[locgpu stamp] main-loop trips, lanes:");
+        for (int j = 0; j < 64; ++j) fprintf(stderr, " %llu", h[16 + j]);
+        fprintf(stderr, "\n[locgpu stamp] main-loop trips, wave maxima:");
+        for (int j = 0; j < 64; ++j) fprintf(stderr, " %llu", h[80 + j]);
+        fprintf(stderr, "\n");
     }
+    if (getenv("LOCGPU_WALK_DEBUG")) fprintf(stderr, "[locgpu walk] searched %llu exact-in-wave+redo %llu overflow %llu tie-evict %llu replays %llu slow %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
     if (reset) LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, sizeof(h)));
     return LOCGPU_OK;
 }
@@ -1048,6 +1064,16 @@ int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset) {
 }
 
 }  // extern "C"
+
+// Diagnostic build only (LOCGPU_STAMP=1 when the batch was created): per query (first-descent trips << 16 | main-loop trips) of the batch's
+// most recent search stage, out[n_scans * max_n].
+extern "C" __attribute__((visibility("default"))) int locgpu_debug_stamp_trips(locgpu_ctx* ctx, locgpu_batch* b, uint32_t* out) {
+    if (!ctx || !b || !out || !getenv("LOCGPU_STAMP")) return LOCGPU_ERR_INVALID;
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LOCGPU_HIP(ctx, hipMemcpy(out, b->d_redo_list + b->pitch, b->pitch * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return LOCGPU_OK;
+}
 
 // Test hook (not part of include/locgpu.h): the device-built exact-search grid of the current target, copied out so the test-suite
 // can check its invariants. info = {dims x,y,z, occupied cells, occupied tiles, hash capacity, tile dims x,y,z};

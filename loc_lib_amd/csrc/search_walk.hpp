@@ -1,0 +1,241 @@
+// loc_lib_amd/csrc/search_walk.hpp — round-3 form of the hot search traversal (K1), see DESIGN.md §3.
+//
+// Same recursion as tree_knn_fast (kdtree.cpp:169-236 replayed node for node), reorganised so that ONE straight-line, fully
+// predicated region is executed per loop trip — no per-lane branches, hence no exec-mask bookkeeping on the CU's shared scalar unit:
+//
+//   * every lane visits exactly one node per trip. A lane that has nothing to visit (it is still popping, or it is finished) visits
+//     the SENTINEL LEAF behind the packed tree (coordinates 3e38: its squared distance overflows to +inf and is never inserted), so
+//     "leaf" is the only predicate of the trip: internal node → push the far side, step to the near side; leaf → result-set update,
+//     then POP up to four stack entries;
+//   * the stack holds {far slot, −d²}. With the sign flipped, `d² < bound` is a SIGNED INTEGER compare of the raw bits against the
+//     bits of −bound (non-positive floats order like their magnitudes), a row below the stack's bottom reads as 0 from outside the
+//     workgroup's LDS allocation (never "less than" a non-positive bound) and INT_MIN (−0.0f) as the bound switches a test off:
+//     the `j < avail` and `is this lane popping` predicates cost nothing;
+//   * the push is an unconditional LDS store to the row above the top (garbage there is harmless; beyond the last row it falls off
+//     the allocation) followed by `avail += pushed`;
+//   * the two candidates of the un-stored top levels (tree_knn_fast) are materialised as rows 0 and 1 of the stack after the first
+//     descent — older below younger, which is the recursion's order — so the drain to them is an ordinary pop; only the third
+//     smallest d² stays in a register, and only when it could pass as well are the top levels replayed (rare wave-uniform branch);
+//   * the result set is updated with v_med3_f32: inserting x into ascending d[0..K) and dropping the largest is
+//     d'[j] = med3(d[j-1], x, d[j]), d'[0] = min(d[0], x).
+//
+// A query is flagged `slow` (→ exact recomputation with the libstdc++ heap, as before) when an eviction happens while the maximum
+// is tied, when two distances of its final set are equal, or when its stack outgrew the stored rows.
+#pragma once
+#include "icp_kernels.hpp"
+
+namespace locgpu {
+
+constexpr float kSentinelCoord = 3.0e38f;  // the sentinel leaf behind the tree: (q − 3e38)² = +inf for every sane query
+
+template <int K>
+struct Walk {
+    float qx, qy, qz;
+    float d[K];        // ascending; +inf = empty
+    uint32_t id[K];
+    uint32_t cur;      // slot to visit next (`dummy` = the sentinel leaf: nothing to visit)
+    int avail;         // rows on the stack
+    int max_avail;     // high-water mark (overflow of the stored rows ⇒ slow)
+    uint32_t c3n;      // bits of −(third smallest d² of the un-stored levels); 0 = none / resolved
+    uint32_t slow;
+};
+
+typedef uint32_t __attribute__((address_space(3))) lds_u32;
+
+__device__ __forceinline__ lds_u32* lds_ptr(uint32_t byte_addr) { return reinterpret_cast<lds_u32*>(byte_addr); }
+
+// First descent (result set empty ⇒ every level pushes). Levels 0..T-1 are not stored: their two smallest d² become rows 0/1, the
+// third smallest goes to w.c3n. Levels ≥ T are stored from row 2 on. Leaves w.cur at the first leaf (not yet visited).
+// col_addr = LDS byte address of this lane's stack column (row stride ROWB bytes).
+template <int K, int ROWB>
+__device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, int T, uint32_t col_addr) {
+    float c1 = __builtin_inff(), c2 = __builtin_inff(), c3 = __builtin_inff();
+    uint32_t f1 = 0, f2 = 0, c1_younger = 0;
+    int sp = 0;
+    uint32_t cur = 0;
+    const float qx = w.qx, qy = w.qy, qz = w.qz;  // values, not lvalues: `c ? w.qx : w.qy` is a select of ADDRESSES and pins w in scratch
+    for (;;) {
+        const u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
+        const uint32_t meta = n.y;
+        if (meta >= 0xC0000000u) break;
+        const float th = as_f32(n.x);
+        const float qa = meta < 0x40000000u ? qx : (meta < 0x80000000u ? qy : qz);
+        const float dd = qa - th;
+        const float d2 = dd * dd;
+        const uint32_t right = meta & 0x3FFFFFFFu;
+        const bool go_left = qa < th;
+        const uint32_t far_slot = go_left ? right : cur + 1u;
+        if (sp < T) {  // levels come in increasing depth: the new entry is younger than both candidates
+            const bool lt1 = d2 < c1, lt2 = d2 < c2;
+            c3 = lt2 ? c2 : (d2 < c3 ? d2 : c3);
+            c2 = lt1 ? c1 : (lt2 ? d2 : c2);
+            f2 = lt1 ? f1 : (lt2 ? far_slot : f2);
+            c1_younger = lt1 ? 1u : (lt2 ? 0u : c1_younger);
+            f1 = lt1 ? far_slot : f1;
+            c1 = lt1 ? d2 : c1;
+        } else {
+            lds_u32* p = lds_ptr(col_addr + (uint32_t)(2 + sp - T) * ROWB);
+            p[0] = far_slot;
+            p[1] = __float_as_uint(-d2);
+        }
+        sp++;
+        cur = go_left ? cur + 1u : right;
+    }
+    // rows 0 (older) and 1 (younger): popped younger first, each against the bound of its own moment — the recursion's order
+    const bool y1 = c1_younger != 0u;
+    lds_u32* p0 = lds_ptr(col_addr);
+    const uint32_t f_old = y1 ? f2 : f1, f_young = y1 ? f1 : f2;
+    const float c_old = y1 ? c2 : c1, c_young = y1 ? c1 : c2;
+    p0[0] = f_old;
+    p0[1] = __float_as_uint(-c_old);
+    p0[ROWB / 4] = f_young;
+    p0[ROWB / 4 + 1] = __float_as_uint(-c_young);
+    w.cur = cur;
+    w.avail = 2 + (sp > T ? sp - T : 0);
+    w.max_avail = w.avail;
+    w.c3n = c3 < __builtin_inff() ? __float_as_uint(-c3) : 0u;
+}
+
+// One trip of the main loop for every lane of the wave (see the header comment). DF = stored rows (incl. rows 0/1).
+// Returns true for a lane that needs walk_replay() before its next trip. A lane is finished when w.cur == dummy && w.avail == 0.
+template <int K, int ROWB>
+__device__ __forceinline__ bool walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, int T, uint32_t col_addr) {
+    // every field is copied to a value first: a conditional between two members is an lvalue (a select of addresses) and would pin w in scratch
+    const float qx = w.qx, qy = w.qy, qz = w.qz;
+    const uint32_t cur = w.cur;
+    const int avail = w.avail;
+    float d[K];
+    uint32_t id[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { d[j] = w.d[j]; id[j] = w.id[j]; }
+    const u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
+    const uint32_t meta = n.y;
+    const bool is_leaf = meta >= 0xC0000000u;
+
+    // ---- leaf: ComputeDisForLeaf (kdtree.cpp:197-212). x = +inf for internal nodes and for the sentinel: nothing is inserted.
+    const float dx = qx - as_f32(n.x), dy = qy - as_f32(n.z), dz = qz - as_f32(n.w);
+    const float dis2 = dx * dx + (dy * dy + dz * dz);  // Eigen squaredNorm order, no FMA
+    const float x = is_leaf ? dis2 : __builtin_inff();
+    bool c[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) c[j] = x < d[j];  // strict: an equal distance is not inserted before its equals (kdtree.cpp:207)
+    if (K >= 2) {
+        // eviction while the maximum is tied: which of the tied elements leaves is a matter of heap layout ⇒ slow.
+        // d[K-1] − d[K-2] is NaN while the set is not full (inf − inf), 0 exactly when a finite maximum is tied.
+        const float gap = d[K - 1] - d[K - 2];
+        const float xt = gap == 0.0f ? x : __builtin_inff();
+        const uint32_t slow0 = w.slow;
+        w.slow = xt < d[K - 1] ? 1u : slow0;
+    }
+#pragma unroll
+    for (int j = K - 1; j >= 1; --j) {
+        const uint32_t below = id[j - 1], here = id[j];
+        const uint32_t t = c[j] ? cur : here;
+        id[j] = c[j - 1] ? below : t;
+        d[j] = __builtin_amdgcn_fmed3f(d[j - 1], x, d[j]);
+    }
+    {
+        const uint32_t here = id[0];
+        id[0] = c[0] ? cur : here;
+        d[0] = __builtin_fminf(d[0], x);
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        // pin the updated set HERE: otherwise its computation is sunk below the (rare) replay branch and comes back as a dozen
+        // register copies at the loop header
+        asm volatile("" : "+v"(d[j]), "+v"(id[j]));
+        w.d[j] = d[j]; w.id[j] = id[j];
+    }
+
+    // −bound of this trip: for an internal node the set is unchanged, so one product serves the push test and the pop
+    const uint32_t nbound = __float_as_uint(-(d[K - 1] * alpha));  // −inf while the set is not full: everything passes
+
+    // ---- internal: Knn (kdtree.cpp:177-194)
+    const float th = as_f32(n.x);
+    const float qa = meta < 0x40000000u ? qx : (meta < 0x80000000u ? qy : qz);
+    const float dd = qa - th;
+    const uint32_t nd2 = __float_as_uint(-(dd * dd));
+    const uint32_t right = meta & 0x3FFFFFFFu;
+    const bool go_left = qa < th;
+    const uint32_t cur1 = cur + 1u;
+    const uint32_t next = go_left ? cur1 : right;
+    const uint32_t far_slot = go_left ? right : cur1;
+    // unconditional store to the row above the top; it counts only if the entry can still pass NeedExpand (else it never will)
+    const uint32_t top = col_addr + (uint32_t)avail * ROWB;
+    *lds_ptr(top) = far_slot;
+    *lds_ptr(top + 4u) = nd2;
+    const uint32_t nd2g = is_leaf ? 0u : nd2;
+    const bool push = (int)nd2g < (int)nbound;
+    const int avail1 = avail + (push ? 1 : 0);
+    const int max0 = w.max_avail;
+    w.max_avail = max0 > avail1 ? max0 : avail1;
+
+    // ---- pop (NeedExpand, kdtree.cpp:214-236), youngest first, up to four rows; only lanes on a leaf (real or sentinel)
+    const uint32_t nb = is_leaf ? nbound : 0x80000000u;  // INT_MIN: nothing passes
+    const uint32_t a4 = col_addr + (uint32_t)(avail1 - 4) * ROWB;  // row avail-4; rows below 0 lie outside the allocation and read 0
+    // (plain integer address arithmetic: it wraps by definition, pointer arithmetic below the array would not)
+    const int e3 = (int)*lds_ptr(a4 + 4u), e2 = (int)*lds_ptr(a4 + 4u + ROWB), e1 = (int)*lds_ptr(a4 + 4u + 2u * ROWB), e0 = (int)*lds_ptr(a4 + 4u + 3u * ROWB);
+    int hit = 4;
+    hit = e3 < (int)nb ? 3 : hit;
+    hit = e2 < (int)nb ? 2 : hit;
+    hit = e1 < (int)nb ? 1 : hit;
+    hit = e0 < (int)nb ? 0 : hit;
+    const uint32_t far_hit = *lds_ptr(a4 + (uint32_t)(3 - hit) * ROWB);  // hit == 4: row avail-5, unused
+    const int avail_eff = is_leaf ? avail1 : 0;
+    const int h1 = hit + 1;
+    const int used = min(min(h1, 4), avail_eff);
+    // did the scan reach rows 0/1 while the third un-stored entry could pass as well? (lowest row examined: avail-1-min(hit,3))
+    const int low = avail_eff - 1 - min(hit, 3);
+    const uint32_t c3n = w.c3n;
+    const uint32_t c3sel = low < 2 ? c3n : 0u;
+    const bool replay = (int)c3sel < (int)nb;
+    const uint32_t fallback = is_leaf ? dummy : next;
+    w.cur = hit < 4 ? far_hit : fallback;
+    w.avail = avail1 - used;
+
+    w.c3n = replay ? 1u : c3n;  // 1 = "replay me" (a positive value never passes the test above); walk_replay() answers it
+    return replay;
+}
+
+// The rare case (≈1e-3 of the queries): the stack has drained to rows 0/1 while three or more un-stored entries could still pass.
+// Rows 0/1 are dropped (everything above them has been consumed) and the top T levels are walked again from the root — the same
+// `<` decisions, hence the same nodes — pushing what passes under the CURRENT bound, which only shrinks; afterwards every pending
+// entry is a stored row. Kept OUT of the trip loop (a branch inside it costs a dozen register copies per trip) and written
+// WITHOUT per-lane branches: the whole wave runs the T iterations, lanes that do not replay load from outside the tree buffer
+// and store outside the LDS allocation. (A divergent `if` here gives the enclosing loop a second back edge; LLVM then splits it
+// into nested loops and evaluates the wave-wide ballots of the trip loop among the replaying lanes only.)
+template <int K, int ROWB>
+__device__ __forceinline__ void walk_replay(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, int T, uint32_t col_addr) {
+    const bool rp = w.c3n == 1u;
+    const float qx = w.qx, qy = w.qy, qz = w.qz;
+    const int nb = rp ? (int)__float_as_uint(-(w.d[K - 1] * alpha)) : (int)0x80000000u;  // INT_MIN: nothing passes
+    const uint32_t base = rp ? col_addr : 0xF0000000u;                                    // outside every LDS allocation
+    int a = 0;
+    uint32_t cn = rp ? 0u : 0x1FFFFFFFu;  // slot whose byte offset lies outside the tree buffer: the load returns zeros
+    bool open = rp;
+    for (int l = 0; l < T; ++l) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cn << 3), 0, 0);
+        const uint32_t m = v.y;
+        open = open && m < 0xC0000000u;  // a first descent that met its leaf above level T: stop there
+        const float t2 = as_f32(v.x);
+        const float qb = m < 0x40000000u ? qx : (m < 0x80000000u ? qy : qz);
+        const float d1 = qb - t2;
+        const uint32_t n2 = __float_as_uint(-(d1 * d1));
+        const uint32_t rgt = m & 0x3FFFFFFFu;
+        const bool gl = qb < t2;
+        const uint32_t row = base + (uint32_t)a * ROWB;
+        *lds_ptr(row) = gl ? rgt : cn + 1u;
+        *lds_ptr(row + 4u) = n2;
+        a += (open && (int)n2 < nb) ? 1 : 0;
+        const uint32_t nx = gl ? cn + 1u : rgt;
+        cn = open ? nx : 0x1FFFFFFFu;
+    }
+    const int max1 = w.max_avail, av = w.avail;
+    const uint32_t cur = w.cur, c3 = w.c3n;
+    w.avail = rp ? a : av;
+    w.max_avail = (rp && a > max1) ? a : max1;
+    w.cur = rp ? dummy : cur;
+    w.c3n = rp ? 0u : c3;
+}
+
+}  // namespace locgpu
