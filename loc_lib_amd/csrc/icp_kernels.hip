@@ -139,15 +139,58 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
 }
 
 // K1, round 3: the traversal of search_walk.hpp. One-wave workgroups; dynamic LDS = DF rows x 64 lanes x 8 B (the stack is the
-// ONLY LDS of the kernel: a push beyond the last row must fall off the allocation). `dummy` = slot of the sentinel leaf.
+// ONLY LDS of the kernel: a row below its bottom must lie outside the allocation). `dummy` = slot of the sentinel leaf.
+// Every lane of the wave must call walk_query (wave-wide ballots inside); a lane without a query passes valid = false.
+template <int K, int ROWB>
+__device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, bool valid, float alpha_eff, int T, uint32_t dummy, uint32_t col_addr) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) { w.d[j] = __builtin_inff(); w.id[j] = kInvalidSlot; }
+    w.slow = 0;
+    // finite-arithmetic precondition of the traversal (the tree is `bounded`): anything else goes to the exact kernel
+    const bool sane = fabsf(w.qx) < 1e18f && fabsf(w.qy) < 1e18f && fabsf(w.qz) < 1e18f;
+    if (valid && sane) {
+        walk_descend<K, ROWB>(rsrc, w, T, col_addr);
+    } else {
+        w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = valid ? 1u : 0u;
+    }
+    do walk_trip<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr); while (__ballot(w.cur != dummy || w.avail > 0) != 0ull);
+#pragma unroll
+    for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;  // equal distances in the final set: heap pop order is layout-dependent
+}
+
+// One or two queries of the wave that need the exact traversal (ties): answered here, the wave's LDS (its stacks are dead now)
+// serving as their two stack columns. Returns false when there are more (the caller appends them to the redo list).
+template <int K>
+__device__ __forceinline__ bool walk_exact_in_wave(const uint2* __restrict__ tree, bool slow, float qx, float qy, float qz, float alpha_eff, uint2* lds,
+                                                   uint32_t* __restrict__ nn, size_t nn_pitch, size_t gi, unsigned long long* __restrict__ search_stats) {
+    const unsigned long long slow_mask = __ballot(slow);
+    if (slow_mask == 0ull || __popcll(slow_mask) > 2) return slow_mask == 0ull;
+    if (slow) {
+        uint32_t(*s_far)[2] = reinterpret_cast<uint32_t(*)[2]>(lds);
+        float(*s_d2)[2] = reinterpret_cast<float(*)[2]>(reinterpret_cast<char*>(lds) + 64 * 2 * sizeof(uint32_t));
+        const int col = __popcll(slow_mask & ((1ull << (threadIdx.x & 63)) - 1ull));
+        KnnHeap<K> heap;
+        uint32_t nvis = 0, lvis = 0, out[K];
+        int cnt;
+        tree_knn_flat<K, 64, false, 2>(tree, qx, qy, qz, K, alpha_eff, s_far, s_d2, col, heap, nvis, lvis);
+        heap_to_sorted<K>(heap, out, cnt);
+#pragma unroll
+        for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = out[j];
+        if (search_stats) atomicAdd(&search_stats[1], 1ull);
+    }
+    return true;
+}
+
 template <int K, int DF>
 __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                              const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                              uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, float alpha_eff, int T,
                                                              unsigned int tree_bytes, uint32_t dummy, int skip_nonfinite, uint32_t* __restrict__ redo_list,
-                                                             unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats, int lanes) {
+                                                             unsigned int* __restrict__ redo_count, uint32_t* __restrict__ deep_list,
+                                                             unsigned int* __restrict__ deep_count, unsigned long long* __restrict__ search_stats, int lanes) {
     extern __shared__ uint2 s_dyn[];
     constexpr int ROWB = 64 * 8;
+    static_assert(DF * ROWB >= 64 * 2 * 8, "exact stack columns do not fit");
     const int scan = blockIdx.y;
     if (st[scan].done) return;
     const int tid = threadIdx.x;
@@ -165,67 +208,53 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
     Walk<K> w;
     w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
-#pragma unroll
-    for (int j = 0; j < K; ++j) { w.d[j] = __builtin_inff(); w.id[j] = kInvalidSlot; }
-    w.slow = 0;
-    // finite-arithmetic precondition of the fast traversal (the tree is `bounded`): anything else goes to the exact kernel
-    const bool sane = fabsf(w.qx) < 1e18f && fabsf(w.qy) < 1e18f && fabsf(w.qz) < 1e18f;
-    const uint32_t col_addr = (uint32_t)(size_t)(&s_dyn[tid]);
-    if (sane) {
-        walk_descend<K, ROWB>(rsrc, w, T, col_addr);
-    } else {
-        w.cur = dummy; w.avail = 0; w.max_avail = 0; w.c3n = 0; w.slow = 1;
-    }
-    for (;;) {
-        bool replay;
-        do replay = walk_trip<K, ROWB>(rsrc, w, alpha_eff, dummy, T, col_addr); while (__ballot(replay) == 0ull && __ballot(w.cur != dummy || w.avail > 0) != 0ull);
-        if (__ballot(w.c3n == 1u) == 0ull) break;
-#ifdef LOCGPU_WALK_STATS
-        if (search_stats && w.c3n == 1u) atomicAdd(&search_stats[4], 1ull);
-#endif
-        walk_replay<K, ROWB>(rsrc, w, alpha_eff, dummy, T, col_addr);
-    }
-    bool slow = w.slow != 0u || w.max_avail > DF;
-#ifdef LOCGPU_WALK_STATS
-    if (search_stats) {
-        if (w.max_avail > DF) atomicAdd(&search_stats[2], 1ull);
-        if (w.slow != 0u) atomicAdd(&search_stats[3], 1ull);
-    }
-#endif
-#pragma unroll
-    for (int j = 0; j + 1 < K; ++j) slow |= w.d[j] == w.d[j + 1];  // equal distances in the final set: heap pop order is layout-dependent
-#ifdef LOCGPU_WALK_STATS
-    if (search_stats && slow) atomicAdd(&search_stats[5], 1ull);
-#endif
-    {
-        // One or two unfinished queries in this wave: answer them here with the exact traversal on the wave's (now dead) stacks.
-        const unsigned long long slow_mask = __ballot(slow);
-        if (slow_mask != 0ull && __popcll(slow_mask) <= 2) {
-            if (slow) {
-                uint32_t(*s_far)[2] = reinterpret_cast<uint32_t(*)[2]>(&s_dyn[0]);
-                float(*s_d2)[2] = reinterpret_cast<float(*)[2]>(reinterpret_cast<char*>(&s_dyn[0]) + 64 * 2 * sizeof(uint32_t));
-                static_assert(DF * ROWB >= 64 * 2 * 8, "exact stack columns do not fit");
-                const int col = __popcll(slow_mask & ((1ull << tid) - 1ull));
-                KnnHeap<K> heap;
-                uint32_t nvis = 0, lvis = 0, out[K];
-                int cnt;
-                tree_knn_flat<K, 64, false, 2>(tree, w.qx, w.qy, w.qz, K, alpha_eff, s_far, s_d2, col, heap, nvis, lvis);
-                heap_to_sorted<K>(heap, out, cnt);
-#pragma unroll
-                for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = out[j];
-                if (search_stats) atomicAdd(&search_stats[1], 1ull);
-            } else {
-#pragma unroll
-                for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
-            }
-            return;
-        }
-    }
-    if (slow) {
-        redo_list[atomicAdd(redo_count, 1u)] = (uint32_t)gi;
-    } else {
+    walk_query<K, ROWB>(rsrc, w, true, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]));
+    const bool deep = w.c3n == 1u;
+    const bool slow = !deep && w.slow != 0u;
+    if (!deep && !slow) {
 #pragma unroll
         for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
+    }
+    wave_append(deep_list, deep_count, deep, (uint32_t)gi);
+    if (!walk_exact_in_wave<K>(tree, slow, w.qx, w.qy, w.qz, alpha_eff, s_dyn, nn, nn_pitch, gi, search_stats))
+        wave_append(redo_list, redo_count, slow, (uint32_t)gi);
+}
+
+// The deep pass: the same traversal with EVERY level stored (T = 0, D + 2 rows) over the list of queries whose un-stored top
+// levels could not be resolved from two candidates (≈1e-3 of them at 15 rows). One-wave workgroups, grid-stride over the list
+// whose length lives on the device.
+template <int K, int D>
+__global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+                                                                  const PoseState* __restrict__ st, uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
+                                                                  float alpha_eff, unsigned int tree_bytes, uint32_t dummy, const uint32_t* __restrict__ list,
+                                                                  const unsigned int* __restrict__ n_list, uint32_t* __restrict__ redo_list,
+                                                                  unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats) {
+    extern __shared__ uint2 s_dyn[];
+    constexpr int ROWB = 64 * 8;
+    const unsigned int n = *n_list;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0 && search_stats) atomicAdd(&search_stats[2], (unsigned long long)n);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
+    for (unsigned int r0 = blockIdx.x * 64u; r0 < n; r0 += gridDim.x * 64u) {
+        const unsigned int r = r0 + (unsigned int)tid;
+        const bool valid = r < n;
+        const uint32_t gi = valid ? list[r] : 0u;
+        Walk<K> w;
+        w.qx = w.qy = w.qz = 0.f;
+        if (valid) {
+            const int scan = (int)(gi / (uint32_t)max_n);
+            const float4 p = src[gi];
+            const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
+            w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
+        }
+        walk_query<K, ROWB>(rsrc, w, valid, alpha_eff, 0, dummy, (uint32_t)(size_t)(&s_dyn[tid]));
+        const bool slow = valid && w.slow != 0u;
+        if (valid && !slow) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = w.id[j];
+        }
+        if (!walk_exact_in_wave<K>(tree, slow, w.qx, w.qy, w.qz, alpha_eff, s_dyn, nn, nn_pitch, gi, search_stats))
+            wave_append(redo_list, redo_count, slow, gi);
     }
 }
 
@@ -817,7 +846,7 @@ static int fast_stack_depth() {
     if (v < 0) {
         const char* e = getenv("LOCGPU_FAST_STACK");
         v = e ? atoi(e) : 15;
-        if (!((v >= 12 && v <= 16) || v == 20 || v == 24)) v = 15;
+        if (!((v >= 8 && v <= 16) || v == 20 || v == 24)) v = 15;
     }
     return v;
 }
@@ -836,15 +865,22 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         return;
     }
     static const int blk = [] { const char* e = getenv("LOCGPU_FAST_BLOCK"); const int v = e ? atoi(e) : 64; return (v == 256 || v == 128) ? v : 64; }();
-    static const int walk = [] { const char* e = getenv("LOCGPU_WALK"); return e ? atoi(e) : 0; }();
-    if (walk == 1) {
-        // round-3 traversal (search_walk.hpp): rows 0/1 of the DF stored rows hold the candidates of the un-stored levels
+    static const int walk = [] { const char* e = getenv("LOCGPU_WALK"); return e ? atoi(e) : 1; }();  // 0 = the round-2 kernel (A/B runs)
+    if (walk == 1 && a.redo_list2) {
+        // round-3 traversal (search_walk.hpp): rows 0/1 of the DF stored rows hold the candidates of the un-stored levels, the other
+        // DF-2 rows one level each — T is chosen so that the stack cannot outgrow them. Queries whose un-stored levels need more than
+        // two candidates go through a.redo_list2 to the deep pass (every level stored), ties to the exact redo kernel as before.
         const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
         static const int small_lanes = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); const int v = e ? atoi(e) : 16; return (v == 16 || v == 32) ? v : 64; }();
         const int lanes = ((size_t)((a.max_n + 63) / 64) * a.n_scans <= 2048) ? small_lanes : 64;
+        const uint32_t dummy = (uint32_t)(a.tree_bytes / 8);
         dim3 g2((a.max_n + lanes - 1) / lanes, a.n_scans);
-        hipLaunchKernelGGL((icp_search_walk_kernel<K, DF>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, (uint32_t)(a.tree_bytes / 8), a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats, lanes);
+        static const int wpad = [] { const char* e = getenv("LOCGPU_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiment: extra dynamic LDS lowers occupancy
+        hipLaunchKernelGGL((icp_search_walk_kernel<K, DF>), g2, dim3(64), DF * 64 * 8 + wpad, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+                           a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
+                           a.search_stats, lanes);
+        hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(1024), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
+                           a.alpha_eff, (unsigned int)a.tree_bytes + 16u, dummy, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count, a.search_stats);
         hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                            a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
         return;
@@ -874,6 +910,10 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
 template <int K, int D>
 static void launch_fast_d(const SearchArgs& a, hipStream_t s) {
     switch (fast_stack_depth()) {
+        case 8: launch_fast_kd<K, D, 8>(a, s); break;
+        case 9: launch_fast_kd<K, D, 9>(a, s); break;
+        case 10: launch_fast_kd<K, D, 10>(a, s); break;
+        case 11: launch_fast_kd<K, D, 11>(a, s); break;
         case 12: launch_fast_kd<K, D, 12>(a, s); break;
         case 13: launch_fast_kd<K, D, 13>(a, s); break;
         case 14: launch_fast_kd<K, D, 14>(a, s); break;

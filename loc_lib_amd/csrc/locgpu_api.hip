@@ -415,6 +415,7 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               hip_ok(ctx, hipMalloc((void**)&b->d_partials, (size_t)n_scans * b->blocks_per_scan * kAccW * sizeof(double)), "hipMalloc partials") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_hb, (size_t)n_total * 44 * sizeof(double)), "hipMalloc hb") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_list, (getenv("LOCGPU_STAMP") ? 2 : 1) * b->pitch * sizeof(uint32_t)), "hipMalloc redo") &&  // diagnostic build: + per-query trip counts
+              hip_ok(ctx, hipMalloc((void**)&b->d_redo_list2, b->pitch * sizeof(uint32_t)), "hipMalloc redo2") &&  // deep pass / grid search: second work list
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, 2 * sizeof(unsigned int)), "hipMalloc redo") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_total * sizeof(PoseState)), "hipHostMalloc state") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_total * 44 * sizeof(double)), "hipHostMalloc hb") &&
@@ -577,7 +578,7 @@ bool IterLauncher::launch(int do_update) {
         const bool grid_mode = alpha_eff < 0.f && ctx->tree_bounded;
         if (alpha_eff < 0.f) sa.alpha_eff = 1.0f;                       // grid mode is exact by construction (`approximate` is ignored)
         if (!ctx->tree_bounded) sa.redo_list = nullptr;                 // huge / non-finite map coordinates: exact tree kernel only
-        if (grid_mode && !b->d_redo_list2) { fail(ctx, LOCGPU_ERR_INVALID, "grid search: work list missing (ensure_grid_lists was not called)"); return false; }
+        if (grid_mode && !b->d_grid_qkey) { fail(ctx, LOCGPU_ERR_INVALID, "grid search: work list missing (ensure_grid_lists was not called)"); return false; }
         sa.redo_list2 = b->d_redo_list2;
         const GridSearchScratch gsc{b->d_grid_qkey, b->d_grid_sorted};
         const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, gsc, s) : launch_icp_search(sa, s);
@@ -649,8 +650,7 @@ static int batch_ready(locgpu_ctx* ctx, locgpu_batch* b) {
 }
 
 static int ensure_grid_lists(locgpu_ctx* ctx, locgpu_batch* b, float alpha_eff) {
-    if (alpha_eff < 0.f && !b->d_redo_list2) {
-        LOCGPU_HIP(ctx, hipMalloc((void**)&b->d_redo_list2, b->pitch * sizeof(uint32_t)));
+    if (alpha_eff < 0.f && !b->d_grid_qkey) {
         LOCGPU_HIP(ctx, hipMalloc((void**)&b->d_grid_qkey, b->pitch * sizeof(uint32_t)));
         LOCGPU_HIP(ctx, hipMalloc((void**)&b->d_grid_sorted, b->pitch * sizeof(uint2)));
     }

@@ -15,12 +15,16 @@
 //     the allocation) followed by `avail += pushed`;
 //   * the two candidates of the un-stored top levels (tree_knn_fast) are materialised as rows 0 and 1 of the stack after the first
 //     descent — older below younger, which is the recursion's order — so the drain to them is an ordinary pop; only the third
-//     smallest d² stays in a register, and only when it could pass as well are the top levels replayed (rare wave-uniform branch);
+//     smallest d² stays in a register. A query for which it could pass as well (≈1e-3 of them) is marked and recomputed by the
+//     DEEP PASS: the same traversal with every level stored, over a device-side list. The other DF−2 rows hold one level each and
+//     T (the number of un-stored levels) is chosen so that the stack cannot outgrow them: there is no overflow case;
+//   * a pop only happens on a leaf, and a lane on a leaf pushes nothing: the four youngest rows are read at the top of the trip,
+//     next to the node load, not behind it;
 //   * the result set is updated with v_med3_f32: inserting x into ascending d[0..K) and dropping the largest is
 //     d'[j] = med3(d[j-1], x, d[j]), d'[0] = min(d[0], x).
 //
 // A query is flagged `slow` (→ exact recomputation with the libstdc++ heap, as before) when an eviction happens while the maximum
-// is tied, when two distances of its final set are equal, or when its stack outgrew the stored rows.
+// is tied or when two distances of its final set are equal.
 #pragma once
 #include "icp_kernels.hpp"
 
@@ -35,8 +39,7 @@ struct Walk {
     uint32_t id[K];
     uint32_t cur;      // slot to visit next (`dummy` = the sentinel leaf: nothing to visit)
     int avail;         // rows on the stack
-    int max_avail;     // high-water mark (overflow of the stored rows ⇒ slow)
-    uint32_t c3n;      // bits of −(third smallest d² of the un-stored levels); 0 = none / resolved
+    uint32_t c3n;      // bits of −(third smallest d² of the un-stored levels); 0 = none; 1 = the query needs the deep pass
     uint32_t slow;
 };
 
@@ -92,14 +95,21 @@ __device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, Walk<K
     p0[ROWB / 4 + 1] = __float_as_uint(-c_young);
     w.cur = cur;
     w.avail = 2 + (sp > T ? sp - T : 0);
-    w.max_avail = w.avail;
     w.c3n = c3 < __builtin_inff() ? __float_as_uint(-c3) : 0u;
 }
 
-// One trip of the main loop for every lane of the wave (see the header comment). DF = stored rows (incl. rows 0/1).
-// Returns true for a lane that needs walk_replay() before its next trip. A lane is finished when w.cur == dummy && w.avail == 0.
+// One trip of the main loop for every lane of the wave (see the header comment).
+// A lane is finished when w.cur == dummy && w.avail == 0. A lane whose stack drains to rows 0/1 while the THIRD un-stored entry
+// could pass as well cannot be continued from two candidates: it is marked (w.c3n = 1, sticky) and recomputed by the deep pass
+// (the same traversal with every level stored); what it computes from there on is discarded.
+//
+// Latency: a pop only happens on a leaf, and a lane on a leaf pushes nothing — so the four youngest stack rows are read at the TOP
+// of the trip, next to the node load, instead of behind it (two LDS round trips less on the dependent chain).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 __attribute__((address_space(3))) lds_u32x2;
+
 template <int K, int ROWB>
-__device__ __forceinline__ bool walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, int T, uint32_t col_addr) {
+__device__ __forceinline__ void walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr) {
     // every field is copied to a value first: a conditional between two members is an lvalue (a select of addresses) and would pin w in scratch
     const float qx = w.qx, qy = w.qy, qz = w.qz;
     const uint32_t cur = w.cur;
@@ -109,6 +119,11 @@ __device__ __forceinline__ bool walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& 
 #pragma unroll
     for (int j = 0; j < K; ++j) { d[j] = w.d[j]; id[j] = w.id[j]; }
     const u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
+    // rows avail-4 .. avail-1 as {far slot, −d²}; a row below 0 lies outside the allocation and reads {0, 0} (plain integer
+    // address arithmetic: it wraps by definition)
+    const uint32_t a4 = col_addr + (uint32_t)(avail - 4) * ROWB;
+    const u32x2 r3 = *reinterpret_cast<lds_u32x2*>(a4), r2 = *reinterpret_cast<lds_u32x2*>(a4 + ROWB),
+                r1 = *reinterpret_cast<lds_u32x2*>(a4 + 2u * ROWB), r0 = *reinterpret_cast<lds_u32x2*>(a4 + 3u * ROWB);
     const uint32_t meta = n.y;
     const bool is_leaf = meta >= 0xC0000000u;
 
@@ -140,12 +155,7 @@ __device__ __forceinline__ bool walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& 
         d[0] = __builtin_fminf(d[0], x);
     }
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        // pin the updated set HERE: otherwise its computation is sunk below the (rare) replay branch and comes back as a dozen
-        // register copies at the loop header
-        asm volatile("" : "+v"(d[j]), "+v"(id[j]));
-        w.d[j] = d[j]; w.id[j] = id[j];
-    }
+    for (int j = 0; j < K; ++j) { w.d[j] = d[j]; w.id[j] = id[j]; }
 
     // −bound of this trip: for an internal node the set is unchanged, so one product serves the push test and the pop
     const uint32_t nbound = __float_as_uint(-(d[K - 1] * alpha));  // −inf while the set is not full: everything passes
@@ -162,80 +172,27 @@ __device__ __forceinline__ bool walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& 
     const uint32_t far_slot = go_left ? right : cur1;
     // unconditional store to the row above the top; it counts only if the entry can still pass NeedExpand (else it never will)
     const uint32_t top = col_addr + (uint32_t)avail * ROWB;
-    *lds_ptr(top) = far_slot;
-    *lds_ptr(top + 4u) = nd2;
+    *reinterpret_cast<lds_u32x2*>(top) = u32x2{far_slot, nd2};
     const uint32_t nd2g = is_leaf ? 0u : nd2;
     const bool push = (int)nd2g < (int)nbound;
-    const int avail1 = avail + (push ? 1 : 0);
-    const int max0 = w.max_avail;
-    w.max_avail = max0 > avail1 ? max0 : avail1;
 
     // ---- pop (NeedExpand, kdtree.cpp:214-236), youngest first, up to four rows; only lanes on a leaf (real or sentinel)
-    const uint32_t nb = is_leaf ? nbound : 0x80000000u;  // INT_MIN: nothing passes
-    const uint32_t a4 = col_addr + (uint32_t)(avail1 - 4) * ROWB;  // row avail-4; rows below 0 lie outside the allocation and read 0
-    // (plain integer address arithmetic: it wraps by definition, pointer arithmetic below the array would not)
-    const int e3 = (int)*lds_ptr(a4 + 4u), e2 = (int)*lds_ptr(a4 + 4u + ROWB), e1 = (int)*lds_ptr(a4 + 4u + 2u * ROWB), e0 = (int)*lds_ptr(a4 + 4u + 3u * ROWB);
+    const int nb = (int)(is_leaf ? nbound : 0x80000000u);  // INT_MIN: nothing passes
     int hit = 4;
-    hit = e3 < (int)nb ? 3 : hit;
-    hit = e2 < (int)nb ? 2 : hit;
-    hit = e1 < (int)nb ? 1 : hit;
-    hit = e0 < (int)nb ? 0 : hit;
-    const uint32_t far_hit = *lds_ptr(a4 + (uint32_t)(3 - hit) * ROWB);  // hit == 4: row avail-5, unused
-    const int avail_eff = is_leaf ? avail1 : 0;
-    const int h1 = hit + 1;
-    const int used = min(min(h1, 4), avail_eff);
+    uint32_t far_hit = is_leaf ? dummy : next;
+    hit = (int)r3.y < nb ? 3 : hit; far_hit = (int)r3.y < nb ? r3.x : far_hit;
+    hit = (int)r2.y < nb ? 2 : hit; far_hit = (int)r2.y < nb ? r2.x : far_hit;
+    hit = (int)r1.y < nb ? 1 : hit; far_hit = (int)r1.y < nb ? r1.x : far_hit;
+    hit = (int)r0.y < nb ? 0 : hit; far_hit = (int)r0.y < nb ? r0.x : far_hit;
+    const int avail_eff = is_leaf ? avail : 0;
+    const int used = min(min(hit + 1, 4), avail_eff);
     // did the scan reach rows 0/1 while the third un-stored entry could pass as well? (lowest row examined: avail-1-min(hit,3))
     const int low = avail_eff - 1 - min(hit, 3);
     const uint32_t c3n = w.c3n;
     const uint32_t c3sel = low < 2 ? c3n : 0u;
-    const bool replay = (int)c3sel < (int)nb;
-    const uint32_t fallback = is_leaf ? dummy : next;
-    w.cur = hit < 4 ? far_hit : fallback;
-    w.avail = avail1 - used;
-
-    w.c3n = replay ? 1u : c3n;  // 1 = "replay me" (a positive value never passes the test above); walk_replay() answers it
-    return replay;
-}
-
-// The rare case (≈1e-3 of the queries): the stack has drained to rows 0/1 while three or more un-stored entries could still pass.
-// Rows 0/1 are dropped (everything above them has been consumed) and the top T levels are walked again from the root — the same
-// `<` decisions, hence the same nodes — pushing what passes under the CURRENT bound, which only shrinks; afterwards every pending
-// entry is a stored row. Kept OUT of the trip loop (a branch inside it costs a dozen register copies per trip) and written
-// WITHOUT per-lane branches: the whole wave runs the T iterations, lanes that do not replay load from outside the tree buffer
-// and store outside the LDS allocation. (A divergent `if` here gives the enclosing loop a second back edge; LLVM then splits it
-// into nested loops and evaluates the wave-wide ballots of the trip loop among the replaying lanes only.)
-template <int K, int ROWB>
-__device__ __forceinline__ void walk_replay(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, int T, uint32_t col_addr) {
-    const bool rp = w.c3n == 1u;
-    const float qx = w.qx, qy = w.qy, qz = w.qz;
-    const int nb = rp ? (int)__float_as_uint(-(w.d[K - 1] * alpha)) : (int)0x80000000u;  // INT_MIN: nothing passes
-    const uint32_t base = rp ? col_addr : 0xF0000000u;                                    // outside every LDS allocation
-    int a = 0;
-    uint32_t cn = rp ? 0u : 0x1FFFFFFFu;  // slot whose byte offset lies outside the tree buffer: the load returns zeros
-    bool open = rp;
-    for (int l = 0; l < T; ++l) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cn << 3), 0, 0);
-        const uint32_t m = v.y;
-        open = open && m < 0xC0000000u;  // a first descent that met its leaf above level T: stop there
-        const float t2 = as_f32(v.x);
-        const float qb = m < 0x40000000u ? qx : (m < 0x80000000u ? qy : qz);
-        const float d1 = qb - t2;
-        const uint32_t n2 = __float_as_uint(-(d1 * d1));
-        const uint32_t rgt = m & 0x3FFFFFFFu;
-        const bool gl = qb < t2;
-        const uint32_t row = base + (uint32_t)a * ROWB;
-        *lds_ptr(row) = gl ? rgt : cn + 1u;
-        *lds_ptr(row + 4u) = n2;
-        a += (open && (int)n2 < nb) ? 1 : 0;
-        const uint32_t nx = gl ? cn + 1u : rgt;
-        cn = open ? nx : 0x1FFFFFFFu;
-    }
-    const int max1 = w.max_avail, av = w.avail;
-    const uint32_t cur = w.cur, c3 = w.c3n;
-    w.avail = rp ? a : av;
-    w.max_avail = (rp && a > max1) ? a : max1;
-    w.cur = rp ? dummy : cur;
-    w.c3n = rp ? 0u : c3;
+    w.c3n = (int)c3sel < nb ? 1u : c3n;  // 1 = "deep pass" (a positive value never passes this test again)
+    w.cur = far_hit;
+    w.avail = avail + (push ? 1 : 0) - used;
 }
 
 }  // namespace locgpu
