@@ -44,16 +44,41 @@ struct Walk {
 };
 
 typedef uint32_t __attribute__((address_space(3))) lds_u32;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 __attribute__((address_space(3))) lds_u32x2;
 
 __device__ __forceinline__ lds_u32* lds_ptr(uint32_t byte_addr) { return reinterpret_cast<lds_u32*>(byte_addr); }
 
 // First descent (result set empty ⇒ every level pushes). Levels 0..T-1 are not stored: their two smallest d² become rows 0/1, the
 // third smallest goes to w.c3n. Levels ≥ T are stored from row 2 on. Leaves w.cur at the first leaf (not yet visited).
 // col_addr = LDS byte address of this lane's stack column (row stride ROWB bytes).
-template <int K, int ROWB>
+// TWO: a step to the LEFT child needs no load when that child is an internal node — its header is the upper half of the parent's
+// 16 bytes (preorder layout) — so it is visited in the same trip: fewer dependent memory round trips per query.
+struct DescendState {
+    float c1, c2, c3;
+    uint32_t f1, f2, c1_younger;
+};
+// one level of the first descent, branch-free: the candidates see d2 only while the level is un-stored (else +inf: no effect), the
+// store goes to row 2+sp-T — below row 0, i.e. outside the allocation, while the level is un-stored. `on` gates everything.
+template <int ROWB>
+__device__ __forceinline__ void descend_level(DescendState& c, float d2, uint32_t far_slot, int sp, int T, uint32_t col_addr, bool on) {
+    const float dc = (on && sp < T) ? d2 : __builtin_inff();
+    const bool lt1 = dc < c.c1, lt2 = dc < c.c2, lt3 = dc < c.c3;
+    const float c1 = c.c1, c2 = c.c2, c3 = c.c3;
+    const uint32_t f1 = c.f1, f2 = c.f2, y = c.c1_younger;
+    c.c3 = lt2 ? c2 : (lt3 ? dc : c3);
+    c.c2 = lt1 ? c1 : (lt2 ? dc : c2);
+    c.f2 = lt1 ? f1 : (lt2 ? far_slot : f2);
+    c.c1_younger = lt1 ? 1u : (lt2 ? 0u : y);  // levels come in increasing depth: the new entry is younger than both candidates
+    c.f1 = lt1 ? far_slot : f1;
+    c.c1 = lt1 ? dc : c1;
+    const uint32_t row = on ? col_addr + (uint32_t)(2 + sp - T) * ROWB : 0xF0000000u;
+    *reinterpret_cast<u32x2 __attribute__((address_space(3)))*>(row) = u32x2{far_slot, __float_as_uint(-d2)};
+}
+
+template <int K, int ROWB, bool TWO>
 __device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, int T, uint32_t col_addr) {
-    float c1 = __builtin_inff(), c2 = __builtin_inff(), c3 = __builtin_inff();
-    uint32_t f1 = 0, f2 = 0, c1_younger = 0;
+    DescendState c{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0u, 0u, 0u};
     int sp = 0;
     uint32_t cur = 0;
     const float qx = w.qx, qy = w.qy, qz = w.qz;  // values, not lvalues: `c ? w.qx : w.qy` is a select of ADDRESSES and pins w in scratch
@@ -64,38 +89,39 @@ __device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, Walk<K
         const float th = as_f32(n.x);
         const float qa = meta < 0x40000000u ? qx : (meta < 0x80000000u ? qy : qz);
         const float dd = qa - th;
-        const float d2 = dd * dd;
         const uint32_t right = meta & 0x3FFFFFFFu;
         const bool go_left = qa < th;
-        const uint32_t far_slot = go_left ? right : cur + 1u;
-        if (sp < T) {  // levels come in increasing depth: the new entry is younger than both candidates
-            const bool lt1 = d2 < c1, lt2 = d2 < c2;
-            c3 = lt2 ? c2 : (d2 < c3 ? d2 : c3);
-            c2 = lt1 ? c1 : (lt2 ? d2 : c2);
-            f2 = lt1 ? f1 : (lt2 ? far_slot : f2);
-            c1_younger = lt1 ? 1u : (lt2 ? 0u : c1_younger);
-            f1 = lt1 ? far_slot : f1;
-            c1 = lt1 ? d2 : c1;
-        } else {
-            lds_u32* p = lds_ptr(col_addr + (uint32_t)(2 + sp - T) * ROWB);
-            p[0] = far_slot;
-            p[1] = __float_as_uint(-d2);
-        }
+        const uint32_t cur1 = cur + 1u;
+        descend_level<ROWB>(c, dd * dd, go_left ? right : cur1, sp, T, col_addr, true);
         sp++;
-        cur = go_left ? cur + 1u : right;
+        cur = go_left ? cur1 : right;
+        if (TWO) {
+            const uint32_t m2 = go_left ? n.w : 0xFFFFFFFFu;
+            const bool second = m2 < 0xC0000000u;
+            const float th2 = as_f32(n.z);
+            const float qa2 = m2 < 0x40000000u ? qx : (m2 < 0x80000000u ? qy : qz);
+            const float dd2 = qa2 - th2;
+            const uint32_t right2 = m2 & 0x3FFFFFFFu;
+            const bool gl2 = qa2 < th2;
+            const uint32_t cur2 = cur1 + 1u;
+            descend_level<ROWB>(c, dd2 * dd2, gl2 ? right2 : cur2, sp, T, col_addr, second);
+            sp += second ? 1 : 0;
+            const uint32_t nx2 = gl2 ? cur2 : right2;
+            cur = second ? nx2 : cur;
+        }
     }
     // rows 0 (older) and 1 (younger): popped younger first, each against the bound of its own moment — the recursion's order
-    const bool y1 = c1_younger != 0u;
+    const bool y1 = c.c1_younger != 0u;
     lds_u32* p0 = lds_ptr(col_addr);
-    const uint32_t f_old = y1 ? f2 : f1, f_young = y1 ? f1 : f2;
-    const float c_old = y1 ? c2 : c1, c_young = y1 ? c1 : c2;
+    const uint32_t f_old = y1 ? c.f2 : c.f1, f_young = y1 ? c.f1 : c.f2;
+    const float c_old = y1 ? c.c2 : c.c1, c_young = y1 ? c.c1 : c.c2;
     p0[0] = f_old;
     p0[1] = __float_as_uint(-c_old);
     p0[ROWB / 4] = f_young;
     p0[ROWB / 4 + 1] = __float_as_uint(-c_young);
     w.cur = cur;
     w.avail = 2 + (sp > T ? sp - T : 0);
-    w.c3n = c3 < __builtin_inff() ? __float_as_uint(-c3) : 0u;
+    w.c3n = c.c3 < __builtin_inff() ? __float_as_uint(-c.c3) : 0u;
 }
 
 // One trip of the main loop for every lane of the wave (see the header comment).
@@ -105,10 +131,7 @@ __device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, Walk<K
 //
 // Latency: a pop only happens on a leaf, and a lane on a leaf pushes nothing — so the four youngest stack rows are read at the TOP
 // of the trip, next to the node load, instead of behind it (two LDS round trips less on the dependent chain).
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef u32x2 __attribute__((address_space(3))) lds_u32x2;
-
-template <int K, int ROWB>
+template <int K, int ROWB, bool TWO>
 __device__ __forceinline__ void walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr) {
     // every field is copied to a value first: a conditional between two members is an lvalue (a select of addresses) and would pin w in scratch
     const float qx = w.qx, qy = w.qy, qz = w.qz;
@@ -175,11 +198,32 @@ __device__ __forceinline__ void walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& 
     *reinterpret_cast<lds_u32x2*>(top) = u32x2{far_slot, nd2};
     const uint32_t nd2g = is_leaf ? 0u : nd2;
     const bool push = (int)nd2g < (int)nbound;
+    // TWO: the left child's header is the upper half of these 16 bytes; if the step goes left into an internal node, visit it now
+    uint32_t next_after = next;
+    int pushed = push ? 1 : 0;
+    if (TWO) {
+        const uint32_t mL = go_left ? n.w : 0xFFFFFFFFu;
+        const uint32_t m2 = is_leaf ? 0xFFFFFFFFu : mL;
+        const bool second = m2 < 0xC0000000u;
+        const float th2 = as_f32(n.z);
+        const float qa2 = m2 < 0x40000000u ? qx : (m2 < 0x80000000u ? qy : qz);
+        const float dd2 = qa2 - th2;
+        const uint32_t nd22 = __float_as_uint(-(dd2 * dd2));
+        const uint32_t right2 = m2 & 0x3FFFFFFFu;
+        const bool gl2 = qa2 < th2;
+        const uint32_t cur2 = cur1 + 1u;
+        const uint32_t top2 = col_addr + (uint32_t)(avail + pushed) * ROWB;
+        *reinterpret_cast<lds_u32x2*>(top2) = u32x2{gl2 ? right2 : cur2, nd22};
+        const bool push2 = (int)(second ? nd22 : 0u) < (int)nbound;
+        pushed += push2 ? 1 : 0;
+        const uint32_t nx2 = gl2 ? cur2 : right2;
+        next_after = second ? nx2 : next;
+    }
 
     // ---- pop (NeedExpand, kdtree.cpp:214-236), youngest first, up to four rows; only lanes on a leaf (real or sentinel)
     const int nb = (int)(is_leaf ? nbound : 0x80000000u);  // INT_MIN: nothing passes
     int hit = 4;
-    uint32_t far_hit = is_leaf ? dummy : next;
+    uint32_t far_hit = is_leaf ? dummy : next_after;
     hit = (int)r3.y < nb ? 3 : hit; far_hit = (int)r3.y < nb ? r3.x : far_hit;
     hit = (int)r2.y < nb ? 2 : hit; far_hit = (int)r2.y < nb ? r2.x : far_hit;
     hit = (int)r1.y < nb ? 1 : hit; far_hit = (int)r1.y < nb ? r1.x : far_hit;
@@ -192,7 +236,87 @@ __device__ __forceinline__ void walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& 
     const uint32_t c3sel = low < 2 ? c3n : 0u;
     w.c3n = (int)c3sel < nb ? 1u : c3n;  // 1 = "deep pass" (a positive value never passes this test again)
     w.cur = far_hit;
-    w.avail = avail + (push ? 1 : 0) - used;
+    w.avail = avail + pushed - used;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// "Rounds" form of the main loop: the kernel is bound by VALU issue (87 % busy, profiles/r03_pmc_kernels.md) and in the flat loop
+// above every trip pays for the leaf block (≈45 instructions) AND the internal block (≈20) although a lane uses only one of them.
+// Here a round is: leaf stage for the whole wave (every live lane sits on a leaf: result-set update + pop, to the next node), then
+// a per-lane loop of internal steps down to the next leaf. A wave pays per round the longest descent of its lanes, but at the price
+// of the small internal body only: search 21.9 -> 20.0 ms per 256-scan step. (Tried on top: an inner loop that keeps popping when
+// four rows failed instead of a sentinel round — 20.5 ms, not kept.)
+template <int K, int ROWB>
+__device__ __forceinline__ void walk_rounds(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr) {
+    const float qx = w.qx, qy = w.qy, qz = w.qz;
+    uint32_t cur = w.cur;
+    int avail = w.avail;
+    float d[K];
+    uint32_t id[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { d[j] = w.d[j]; id[j] = w.id[j]; }
+    uint32_t slow = w.slow, c3n = w.c3n;
+    u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);  // the first leaf (or the sentinel)
+    do {
+        // ---- leaf stage: ComputeDisForLeaf (kdtree.cpp:197-212), then NeedExpand over the four youngest rows (kdtree.cpp:214-236)
+        const uint32_t a4 = col_addr + (uint32_t)(avail - 4) * ROWB;
+        const u32x2 r3 = *reinterpret_cast<lds_u32x2*>(a4), r2 = *reinterpret_cast<lds_u32x2*>(a4 + ROWB),
+                    r1 = *reinterpret_cast<lds_u32x2*>(a4 + 2u * ROWB), r0 = *reinterpret_cast<lds_u32x2*>(a4 + 3u * ROWB);
+        const float dx = qx - as_f32(n.x), dy = qy - as_f32(n.z), dz = qz - as_f32(n.w);
+        const float x = dx * dx + (dy * dy + dz * dz);  // Eigen squaredNorm order, no FMA; +inf for the sentinel
+        bool c[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) c[j] = x < d[j];
+        if (K >= 2) {
+            const float gap = d[K - 1] - d[K - 2];
+            const float xt = gap == 0.0f ? x : __builtin_inff();
+            slow = xt < d[K - 1] ? 1u : slow;
+        }
+#pragma unroll
+        for (int j = K - 1; j >= 1; --j) {
+            const uint32_t below = id[j - 1], here = id[j];
+            const uint32_t t = c[j] ? cur : here;
+            id[j] = c[j - 1] ? below : t;
+            d[j] = __builtin_amdgcn_fmed3f(d[j - 1], x, d[j]);
+        }
+        {
+            const uint32_t here = id[0];
+            id[0] = c[0] ? cur : here;
+            d[0] = __builtin_fminf(d[0], x);
+        }
+        const int nb = (int)__float_as_uint(-(d[K - 1] * alpha));  // −inf while the set is not full: everything passes
+        int hit = 4;
+        uint32_t nxt = dummy;
+        hit = (int)r3.y < nb ? 3 : hit; nxt = (int)r3.y < nb ? r3.x : nxt;
+        hit = (int)r2.y < nb ? 2 : hit; nxt = (int)r2.y < nb ? r2.x : nxt;
+        hit = (int)r1.y < nb ? 1 : hit; nxt = (int)r1.y < nb ? r1.x : nxt;
+        hit = (int)r0.y < nb ? 0 : hit; nxt = (int)r0.y < nb ? r0.x : nxt;
+        const int used = min(min(hit + 1, 4), avail);
+        const int low = avail - 1 - min(hit, 3);
+        const uint32_t c3sel = low < 2 ? c3n : 0u;
+        c3n = (int)c3sel < nb ? 1u : c3n;
+        cur = nxt;
+        avail -= used;
+        // ---- internal steps (Knn, kdtree.cpp:177-194) down to the next leaf; the bound does not change on the way
+        n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
+        while (n.y < 0xC0000000u) {
+            const uint32_t meta = n.y;
+            const float th = as_f32(n.x);
+            const float qa = meta < 0x40000000u ? qx : (meta < 0x80000000u ? qy : qz);
+            const float dd = qa - th;
+            const uint32_t nd2 = __float_as_uint(-(dd * dd));
+            const uint32_t right = meta & 0x3FFFFFFFu;
+            const bool go_left = qa < th;
+            const uint32_t cur1 = cur + 1u;
+            *reinterpret_cast<lds_u32x2*>(col_addr + (uint32_t)avail * ROWB) = u32x2{go_left ? right : cur1, nd2};
+            avail += (int)nd2 < nb ? 1 : 0;
+            cur = go_left ? cur1 : right;
+            n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
+        }
+    } while (__ballot(cur != dummy || avail > 0) != 0ull);
+#pragma unroll
+    for (int j = 0; j < K; ++j) { w.d[j] = d[j]; w.id[j] = id[j]; }
+    w.slow = slow; w.c3n = c3n; w.cur = cur; w.avail = avail;
 }
 
 }  // namespace locgpu

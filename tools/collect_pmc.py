@@ -42,7 +42,7 @@ def main():
                     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    keep = [k for k in agg if any(s in k for s in ("icp_search_fast_kernel", "icp_plane_accum_kernel", "icp_search_redo_kernel", "gn_solve_kernel"))]
+    keep = [k for k in agg if any(s in k for s in ("icp_search_walk", "icp_search_fast_kernel", "icp_plane_accum_kernel", "icp_search_redo_kernel", "gn_solve_kernel"))]
     lines = ["# PMC counters of the hot kernels (mean per dispatch; `bench.py --steps 2 --resident --scans-per-gpu %d`, 10 M-pt map)" % a.scans, "",
              "Collected by `tools/collect_pmc.py`: one `rocprofv3 --pmc` pass per counter group, nothing else enabled. SQ_*_CYCLES and SQ_WAIT_* count quad-cycles",
              "(MI355X_MICROARCH.md); per-wave values = counter / SQ_WAVES of the same pass.", ""]
