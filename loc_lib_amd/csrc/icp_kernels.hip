@@ -141,7 +141,7 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
 // K1, round 3: the traversal of search_walk.hpp. One-wave workgroups; dynamic LDS = DF rows x 64 lanes x 8 B (the stack is the
 // ONLY LDS of the kernel: a row below its bottom must lie outside the allocation). `dummy` = slot of the sentinel leaf.
 // Every lane of the wave must call walk_query (wave-wide ballots inside); a lane without a query passes valid = false.
-template <int K, int ROWB, int MODE>  // MODE 0: flat trips, 1: flat trips with the free left step, 2: rounds
+template <int K, int ROWB, int MODE>  // MODE 0: flat trips, 2: rounds
 __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, bool valid, float alpha_eff, int T, uint32_t dummy, uint32_t col_addr) {
 #pragma unroll
     for (int j = 0; j < K; ++j) { w.d[j] = __builtin_inff(); w.id[j] = kInvalidSlot; }
@@ -149,12 +149,12 @@ __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, Walk<K>&
     // finite-arithmetic precondition of the traversal (the tree is `bounded`): anything else goes to the exact kernel
     const bool sane = fabsf(w.qx) < 1e18f && fabsf(w.qy) < 1e18f && fabsf(w.qz) < 1e18f;
     if (valid && sane) {
-        walk_descend<K, ROWB, MODE == 1>(rsrc, w, T, col_addr);
+        walk_descend<K, ROWB>(rsrc, w, T, col_addr);
     } else {
         w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = valid ? 1u : 0u;
     }
     if (MODE == 2) walk_rounds<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr);
-    else do walk_trip<K, ROWB, MODE == 1>(rsrc, w, alpha_eff, dummy, col_addr); while (__ballot(w.cur != dummy || w.avail > 0) != 0ull);
+    else do walk_trip<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr); while (__ballot(w.cur != dummy || w.avail > 0) != 0ull);
 #pragma unroll
     for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;  // equal distances in the final set: heap pop order is layout-dependent
 }
@@ -847,7 +847,7 @@ static int fast_stack_depth() {
     if (v < 0) {
         const char* e = getenv("LOCGPU_FAST_STACK");
         v = e ? atoi(e) : 15;
-        if (!((v >= 8 && v <= 16) || v == 20 || v == 24)) v = 15;
+        if (!((v >= 12 && v <= 16) || v == 20 || v == 24)) v = 15;
     }
     return v;
 }
@@ -882,7 +882,6 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
                                                  a.max_n, a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count,       \
                                                  a.redo_list2, a.redo_count2, a.search_stats, lanes)
         if (mode == 2) LOCGPU_WALK_LAUNCH(2);
-        else if (mode == 1) LOCGPU_WALK_LAUNCH(1);
         else LOCGPU_WALK_LAUNCH(0);
 #undef LOCGPU_WALK_LAUNCH
         hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(1024), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
@@ -916,10 +915,6 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
 template <int K, int D>
 static void launch_fast_d(const SearchArgs& a, hipStream_t s) {
     switch (fast_stack_depth()) {
-        case 8: launch_fast_kd<K, D, 8>(a, s); break;
-        case 9: launch_fast_kd<K, D, 9>(a, s); break;
-        case 10: launch_fast_kd<K, D, 10>(a, s); break;
-        case 11: launch_fast_kd<K, D, 11>(a, s); break;
         case 12: launch_fast_kd<K, D, 12>(a, s); break;
         case 13: launch_fast_kd<K, D, 13>(a, s); break;
         case 14: launch_fast_kd<K, D, 14>(a, s); break;

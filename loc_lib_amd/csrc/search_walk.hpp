@@ -52,76 +52,69 @@ __device__ __forceinline__ lds_u32* lds_ptr(uint32_t byte_addr) { return reinter
 // First descent (result set empty ⇒ every level pushes). Levels 0..T-1 are not stored: their two smallest d² become rows 0/1, the
 // third smallest goes to w.c3n. Levels ≥ T are stored from row 2 on. Leaves w.cur at the first leaf (not yet visited).
 // col_addr = LDS byte address of this lane's stack column (row stride ROWB bytes).
-// TWO: a step to the LEFT child needs no load when that child is an internal node — its header is the upper half of the parent's
-// 16 bytes (preorder layout) — so it is visited in the same trip: fewer dependent memory round trips per query.
-struct DescendState {
-    float c1, c2, c3;
-    uint32_t f1, f2, c1_younger;
-};
-// one level of the first descent, branch-free: the candidates see d2 only while the level is un-stored (else +inf: no effect), the
-// store goes to row 2+sp-T — below row 0, i.e. outside the allocation, while the level is un-stored. `on` gates everything.
-template <int ROWB>
-__device__ __forceinline__ void descend_level(DescendState& c, float d2, uint32_t far_slot, int sp, int T, uint32_t col_addr, bool on) {
-    const float dc = (on && sp < T) ? d2 : __builtin_inff();
-    const bool lt1 = dc < c.c1, lt2 = dc < c.c2, lt3 = dc < c.c3;
-    const float c1 = c.c1, c2 = c.c2, c3 = c.c3;
-    const uint32_t f1 = c.f1, f2 = c.f2, y = c.c1_younger;
-    c.c3 = lt2 ? c2 : (lt3 ? dc : c3);
-    c.c2 = lt1 ? c1 : (lt2 ? dc : c2);
-    c.f2 = lt1 ? f1 : (lt2 ? far_slot : f2);
-    c.c1_younger = lt1 ? 1u : (lt2 ? 0u : y);  // levels come in increasing depth: the new entry is younger than both candidates
-    c.f1 = lt1 ? far_slot : f1;
-    c.c1 = lt1 ? dc : c1;
-    const uint32_t row = on ? col_addr + (uint32_t)(2 + sp - T) * ROWB : 0xF0000000u;
-    *reinterpret_cast<u32x2 __attribute__((address_space(3)))*>(row) = u32x2{far_slot, __float_as_uint(-d2)};
-}
-
-template <int K, int ROWB, bool TWO>
+// Every lane still in the loop is on the same level (one level per trip from the root), so "is this level stored" is a scalar
+// question: two loops — candidates only, then stores only — instead of one body that carries both (the kernel is VALU-bound).
+template <int K, int ROWB>
 __device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, int T, uint32_t col_addr) {
-    DescendState c{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0u, 0u, 0u};
-    int sp = 0;
+    float c1 = __builtin_inff(), c2 = __builtin_inff(), c3 = __builtin_inff();
+    uint32_t f1 = 0, f2 = 0, c1_younger = 0;
     uint32_t cur = 0;
     const float qx = w.qx, qy = w.qy, qz = w.qz;  // values, not lvalues: `c ? w.qx : w.qy` is a select of ADDRESSES and pins w in scratch
-    for (;;) {
+    bool at_leaf = false;
+    for (int l = 0; l < T; ++l) {  // un-stored levels: sorted insertion of d² into (c1 ≤ c2 ≤ c3), far slots of the first two
         const u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
         const uint32_t meta = n.y;
-        if (meta >= 0xC0000000u) break;
+        if (meta >= 0xC0000000u) { at_leaf = true; break; }
         const float th = as_f32(n.x);
         const float qa = meta < 0x40000000u ? qx : (meta < 0x80000000u ? qy : qz);
         const float dd = qa - th;
+        const float d2 = dd * dd;
         const uint32_t right = meta & 0x3FFFFFFFu;
         const bool go_left = qa < th;
         const uint32_t cur1 = cur + 1u;
-        descend_level<ROWB>(c, dd * dd, go_left ? right : cur1, sp, T, col_addr, true);
-        sp++;
+        const uint32_t far_slot = go_left ? right : cur1;
+        const bool lt1 = d2 < c1, lt2 = d2 < c2;
+        c3 = __builtin_amdgcn_fmed3f(c2, d2, c3);
+        c2 = __builtin_amdgcn_fmed3f(c1, d2, c2);
+        c1 = __builtin_fminf(c1, d2);
+        const uint32_t f2n = lt2 ? far_slot : f2;
+        f2 = lt1 ? f1 : f2n;
+        f1 = lt1 ? far_slot : f1;
+        const uint32_t yn = lt2 ? 0u : c1_younger;  // levels come in increasing depth: the new entry is younger than both candidates
+        c1_younger = lt1 ? 1u : yn;
         cur = go_left ? cur1 : right;
-        if (TWO) {
-            const uint32_t m2 = go_left ? n.w : 0xFFFFFFFFu;
-            const bool second = m2 < 0xC0000000u;
-            const float th2 = as_f32(n.z);
-            const float qa2 = m2 < 0x40000000u ? qx : (m2 < 0x80000000u ? qy : qz);
-            const float dd2 = qa2 - th2;
-            const uint32_t right2 = m2 & 0x3FFFFFFFu;
-            const bool gl2 = qa2 < th2;
-            const uint32_t cur2 = cur1 + 1u;
-            descend_level<ROWB>(c, dd2 * dd2, gl2 ? right2 : cur2, sp, T, col_addr, second);
-            sp += second ? 1 : 0;
-            const uint32_t nx2 = gl2 ? cur2 : right2;
-            cur = second ? nx2 : cur;
+    }
+    int rows = 2;
+    if (!at_leaf) {
+        uint32_t row = col_addr + 2u * ROWB;
+        for (;;) {  // stored levels
+            const u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
+            const uint32_t meta = n.y;
+            if (meta >= 0xC0000000u) break;
+            const float th = as_f32(n.x);
+            const float qa = meta < 0x40000000u ? qx : (meta < 0x80000000u ? qy : qz);
+            const float dd = qa - th;
+            const uint32_t right = meta & 0x3FFFFFFFu;
+            const bool go_left = qa < th;
+            const uint32_t cur1 = cur + 1u;
+            *reinterpret_cast<lds_u32x2*>(row) = u32x2{go_left ? right : cur1, __float_as_uint(-(dd * dd))};
+            row += ROWB;
+            rows++;
+            cur = go_left ? cur1 : right;
         }
     }
     // rows 0 (older) and 1 (younger): popped younger first, each against the bound of its own moment — the recursion's order
-    const bool y1 = c.c1_younger != 0u;
+    const bool y1 = c1_younger != 0u;
     lds_u32* p0 = lds_ptr(col_addr);
-    const uint32_t f_old = y1 ? c.f2 : c.f1, f_young = y1 ? c.f1 : c.f2;
-    const float c_old = y1 ? c.c2 : c.c1, c_young = y1 ? c.c1 : c.c2;
+    const uint32_t f_old = y1 ? f2 : f1, f_young = y1 ? f1 : f2;
+    const float c_old = y1 ? c2 : c1, c_young = y1 ? c1 : c2;
     p0[0] = f_old;
     p0[1] = __float_as_uint(-c_old);
     p0[ROWB / 4] = f_young;
     p0[ROWB / 4 + 1] = __float_as_uint(-c_young);
     w.cur = cur;
-    w.avail = 2 + (sp > T ? sp - T : 0);
-    w.c3n = c.c3 < __builtin_inff() ? __float_as_uint(-c.c3) : 0u;
+    w.avail = rows;
+    w.c3n = c3 < __builtin_inff() ? __float_as_uint(-c3) : 0u;
 }
 
 // One trip of the main loop for every lane of the wave (see the header comment).
@@ -131,7 +124,7 @@ __device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, Walk<K
 //
 // Latency: a pop only happens on a leaf, and a lane on a leaf pushes nothing — so the four youngest stack rows are read at the TOP
 // of the trip, next to the node load, instead of behind it (two LDS round trips less on the dependent chain).
-template <int K, int ROWB, bool TWO>
+template <int K, int ROWB>
 __device__ __forceinline__ void walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr) {
     // every field is copied to a value first: a conditional between two members is an lvalue (a select of addresses) and would pin w in scratch
     const float qx = w.qx, qy = w.qy, qz = w.qz;
@@ -198,27 +191,8 @@ __device__ __forceinline__ void walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& 
     *reinterpret_cast<lds_u32x2*>(top) = u32x2{far_slot, nd2};
     const uint32_t nd2g = is_leaf ? 0u : nd2;
     const bool push = (int)nd2g < (int)nbound;
-    // TWO: the left child's header is the upper half of these 16 bytes; if the step goes left into an internal node, visit it now
-    uint32_t next_after = next;
-    int pushed = push ? 1 : 0;
-    if (TWO) {
-        const uint32_t mL = go_left ? n.w : 0xFFFFFFFFu;
-        const uint32_t m2 = is_leaf ? 0xFFFFFFFFu : mL;
-        const bool second = m2 < 0xC0000000u;
-        const float th2 = as_f32(n.z);
-        const float qa2 = m2 < 0x40000000u ? qx : (m2 < 0x80000000u ? qy : qz);
-        const float dd2 = qa2 - th2;
-        const uint32_t nd22 = __float_as_uint(-(dd2 * dd2));
-        const uint32_t right2 = m2 & 0x3FFFFFFFu;
-        const bool gl2 = qa2 < th2;
-        const uint32_t cur2 = cur1 + 1u;
-        const uint32_t top2 = col_addr + (uint32_t)(avail + pushed) * ROWB;
-        *reinterpret_cast<lds_u32x2*>(top2) = u32x2{gl2 ? right2 : cur2, nd22};
-        const bool push2 = (int)(second ? nd22 : 0u) < (int)nbound;
-        pushed += push2 ? 1 : 0;
-        const uint32_t nx2 = gl2 ? cur2 : right2;
-        next_after = second ? nx2 : next;
-    }
+    const int pushed = push ? 1 : 0;
+    const uint32_t next_after = next;
 
     // ---- pop (NeedExpand, kdtree.cpp:214-236), youngest first, up to four rows; only lanes on a leaf (real or sentinel)
     const int nb = (int)(is_leaf ? nbound : 0x80000000u);  // INT_MIN: nothing passes
