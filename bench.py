@@ -8,11 +8,14 @@ One "step" = one pass of the hot path over one batch: every rank aligns `--scans
 mode). The map and its tree are in HBM before the timed region starts. The SCANS are not: scans/sec includes the source deep
 copy of every ScanMatch call (SetSource, icp_registration.cpp:221,252-265) — every step aligns a batch that
 was copied host → HBM for it through pinned staging on a copy stream, while the previous step's Gauss–Newton loop ran
-(two batches alternate as a double buffer; `--resident` keeps one batch in HBM instead and is reported as the secondary number).
-Multi-GPU, default (`--scaling weak`): every rank aligns its own `--scans-per-gpu` scans, no data-path collective (each scan's
-Gauss–Newton loop is local); `value` = scans all ranks completed ÷ max-over-ranks time. `--scaling strong` is BASELINE.json
-configs[3] as written: `--total-scans` (256) scans in all, sharded contiguously over the ranks, per-iteration RCCL all-reduce of
-the per-scan normal equations inside liblocgpu.so (every rank solves every scan and holds all poses).
+(three batches rotate: one is being copied, two are being aligned; `--resident` keeps the scans in HBM instead and is reported as
+the secondary number). Two alignments are in flight at any time (`locgpu_*_align_batch_begin` / `locgpu_align_batch_end`): the
+first Gauss–Newton iterations of step i+1 run under the last ones of step i, which hold a handful of unconverged scans
+(`--pipeline 1` = one at a time, for A/B). Every step still begins and ends inside the timed region.
+One GPU: BASELINE.json configs[2], every step aligns `--scans-per-gpu` (256) scans. Several GPUs, default (`--scaling strong`):
+configs[3] as written — `--total-scans` (256) scans in all, sharded contiguously over the ranks, per-iteration RCCL all-reduce of
+the per-scan normal equations inside liblocgpu.so (every rank solves every scan and holds all poses). `--scaling weak`: every
+rank aligns its own `--scans-per-gpu` scans, no data-path collective; `value` = scans all ranks completed ÷ max-over-ranks time.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8 ...
@@ -30,6 +33,28 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (≈6.3 TB/s achievable)
+
+
+def usable_cores():
+    """Host threads this process may actually run on: the affinity mask, capped by the cgroup CPU quota when there is one
+    (os.cpu_count() reports the machine, not what the container grants)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()  # cgroup v2: "<quota> <period>" or "max <period>"
+        if q[0] != "max":
+            n = max(1, min(n, int(float(q[0]) / float(q[1]) + 0.5)))
+    except (OSError, ValueError, IndexError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = max(1, min(n, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def cpu_baseline(map_xyz, scans, inits, seconds_budget=20.0, method="p2plane"):
@@ -59,13 +84,13 @@ def cpu_baseline(map_xyz, scans, inits, seconds_budget=20.0, method="p2plane"):
         t1 = time.time()
         p2, _ = icp.align_flat(scans[:done], inits[:done], threads=1)
         t_r2 = time.time() - t1
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         n_par = min(len(scans), max(done, cores))
         t1 = time.time()
         p3, _ = icp.align_flat(scans[:n_par], inits[:n_par], threads=cores)
         t_r3 = time.time() - t1
         r2 = dict(value=done / t_r2, unit="scans/s", cores=1, scans=done, identical_to_r1=bool(all(np.array_equal(a, b) for a, b in zip(p2, poses))))
-        r3 = dict(value=n_par / t_r3, unit="scans/s", cores=cores, scans=n_par,
+        r3 = dict(value=n_par / t_r3, unit="scans/s", cores=cores, machine_threads=os.cpu_count(), scans=n_par,
                   identical_to_r1=bool(all(np.array_equal(a, b) for a, b in zip(p3[:done], poses))))
     return dict(value=done / t_align, unit="scans/s", cores=1, kind="port",
                 sample="R1 = %d full %d-pt scans vs the same %.0fM-pt map, oracle/locref.cpp %s (the reference's own style: pointer tree, std::priority_queue "
@@ -149,9 +174,14 @@ def main():
                          "SetEnableANN(false) semantics through the tree or through the exact cell grid")
     ap.add_argument("--resident", action="store_true",
                     help="secondary number: the scans are uploaded once before the timed region (no per-step H2D)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: --scans-per-gpu scans on every rank, no collective; strong: --total-scans in all, sharded over the "
-                         "ranks with the per-iteration RCCL all-reduce (BASELINE configs[3])")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="strong (default with several GPUs): --total-scans in all, sharded over the ranks with the per-iteration RCCL "
+                         "all-reduce (BASELINE configs[3]); weak (default with one GPU): --scans-per-gpu scans on every rank, no collective")
+    ap.add_argument("--pipeline", type=int, choices=[0, 1, 2], default=0,
+                    help="alignments in flight: 2 = step i+1 is begun before step i is ended, 1 = one at a time, 0 (default) = 2 when a "
+                         "rank holds fewer than 128 scans (the shards of the multi-GPU runs), else 1 — at 256 scans per GPU two in flight "
+                         "give +6 %% scans/s but every kernel's launch duration then includes the other batch's share of the chip, and "
+                         "`roofline` is defined on launch durations")
     ap.add_argument("--total-scans", type=int, default=256)
     ap.add_argument("--traffic", choices=["live", "profiles", "none"], default="live",
                     help="roofline.traffic: live = two rocprofv3 --pmc child runs now (1 GPU only), profiles = newest committed collection")
@@ -164,6 +194,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
 
     import torch
     dist = None
@@ -212,7 +244,10 @@ def main():
     def new_batch():
         return ctx.batch(scans, first=lo, n_total=n_total) if strong else ctx.batch(scans)
 
-    bufs = [new_batch()] if args.resident else [new_batch(), new_batch()]
+    depth = args.pipeline if args.pipeline else (2 if B_local < 128 else 1)
+    # resident: `depth` batches hold the same scans; streaming: one more, so that the copy for step g+1 never lands in a batch
+    # that an alignment in flight (steps g, g-1) is reading
+    bufs = [new_batch() for _ in range(depth if args.resident else depth + 1)]
     scans_c = api.MarshalledScans(scans)  # the (pointer, count) arrays a C caller of locgpu_batch_upload_async already holds
     method = dict(p2plane=api.P2PLANE, p2line=api.P2LINE, p2p=api.P2P, ndt=-1)[args.method]
     opts = api.icp_opts(method=max(method, 0))  # every other field = reference default
@@ -228,18 +263,32 @@ def main():
     def align_batch(b):
         return ctx.ndt_align_batch(b, inits) if method < 0 else ctx.icp_align_batch(b, inits, opts)
 
-    step_no = [0]
+    g_step = [0]  # steps begun since the start of the process (selects the batch)
 
-    def step():
-        """One pass of the hot path over one batch. Streaming (default): start the host → HBM copy of the NEXT step's scans
-        (returns at once: a worker packs into pinned slots, a copy stream moves them), then align the batch whose copy was
-        started one step earlier. Every step issues exactly one upload and one alignment."""
-        i = step_no[0]
-        step_no[0] += 1
-        if args.resident:
-            return align_batch(bufs[0])
-        bufs[(i + 1) % 2].upload_async(scans_c)
-        return align_batch(bufs[i % 2])
+    def begin_step():
+        """Start one pass of the hot path over one batch. Streaming (default): first start the host → HBM copy of the NEXT step's
+        scans (returns at once: a worker packs into pinned slots, a copy stream moves them), then begin the alignment of the
+        batch whose copy was started one step earlier. Every step issues exactly one upload and one alignment."""
+        g = g_step[0]
+        g_step[0] += 1
+        b = bufs[g % len(bufs)]
+        if not args.resident:
+            bufs[(g + 1) % len(bufs)].upload_async(scans_c)
+        if method < 0:
+            ctx.ndt_align_batch_begin(b, inits)
+        else:
+            ctx.icp_align_batch_begin(b, inits, opts)
+        return b
+
+    def run_steps(n):
+        """Exactly n steps, begun and ended in here; at most `depth` alignments in flight."""
+        inflight, begun, res = [], 0, None
+        while begun < n or inflight:
+            while begun < n and len(inflight) < depth:
+                inflight.append(begin_step())
+                begun += 1
+            res = ctx.align_batch_end(inflight.pop(0))
+        return res
 
     def barrier():
         if dist is not None:
@@ -252,8 +301,9 @@ def main():
     vc = ctx.visit_count_read(reset=True)
     ctx.visit_count_enable(False)
 
-    for _ in range(args.warmup):
-        step()
+    if not args.resident:  # the copy for the first step (every later one is started by the step before it)
+        bufs[g_step[0] % len(bufs)].upload_async(scans_c)
+    run_steps(args.warmup)
 
     # ---- timed region: exactly `steps` steps; HIP events on the library's stream time each kernel launch
     ctx.profile_read(reset=True)
@@ -263,8 +313,7 @@ def main():
     ctx.profile_enable(prof_mode)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out_poses, stats = step()
+    out_poses, stats = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
@@ -331,6 +380,15 @@ def main():
                         algorithmic_bytes_per_launch=int(kbytes / max(launches_per_step, 1)), avg_launch_ms=round(kavg, 5),
                         launches_per_step=launches_per_step,
                         nodes_per_query=round(vc["nodes"] / max(q, 1), 2), leaves_per_query=round(vc["leaves"] / max(q, 1), 2))
+        # which BASELINE.json configuration the arguments amount to
+        if strong:
+            cfg_name = "BASELINE configs[3] (%d scans in all, sharded over %d GPU(s), RCCL all-reduce)" % (n_total, world)
+        elif args.map_points == 10_000_000:
+            cfg_name = "BASELINE configs[2]"
+        elif args.map_points == 1_000_000:
+            cfg_name = "BASELINE configs[1]"
+        else:
+            cfg_name = "%d-pt map (not a BASELINE configuration)" % args.map_points
         mode = "scans resident in HBM before the timed region (secondary number)" if args.resident else \
                "includes scan H2D: every step aligns a batch copied host->HBM for it (pinned double buffer, copy stream, overlapped with the previous step)"
         shard = ("strong scaling: %d scans in all sharded over %d rank(s), per-iteration RCCL all-reduce of the per-scan normal equations" % (n_total, world)) if strong \
@@ -338,10 +396,10 @@ def main():
         line = dict(metric="scans/sec (64x1800-pt scan vs 10M-pt map) + ICP iter ms", value=round(value, 3), unit="scans/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 4),
                     higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f64", search_dtype="f32", data="synthetic",
-                    config=dict(workload="BASELINE configs[2]: %d scans/GPU x %d pts (64x1800, cityblock-v1) vs one %d-pt map, "
-                                         "%s, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), %s; %s"
-                                         % (B_local, pts_per_scan, args.map_points, "direct NDT (voxel 1.0, NEARBY6)" if method < 0 else args.method.upper() + " ICP", shard, mode),
-                                scans_per_gpu=B_local, map_points=args.map_points, scan_h2d_in_timed_region=not args.resident,
+                    config=dict(workload="%s: %d scans/GPU x %d pts (64x1800, cityblock-v1) vs one %d-pt map, "
+                                         "%s, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), %s; %s; %d alignment(s) in flight"
+                                         % (cfg_name, B_local, pts_per_scan, args.map_points, "direct NDT (voxel 1.0, NEARBY6)" if method < 0 else args.method.upper() + " ICP", shard, mode, depth),
+                                scans_per_gpu=B_local, map_points=args.map_points, scan_h2d_in_timed_region=not args.resident, pipeline_depth=depth,
                                 search_mode=dict(tree="tree_faithful_ann", tree_exact="tree_faithful_exact", grid="grid_exact")[args.search], tree_depth=tinfo["depth"],
                                 tree_bytes=tinfo["bytes"]),
                     icp_iter_ms=round((t_search + t_accum + t_solve) / max(prof["search_n"] / args.steps, 1), 5),
@@ -353,6 +411,15 @@ def main():
                     median_translation_error_to_truth_m=round(err_t, 4),
                     setup_s=dict(map_gen=round(t_map, 2), tree_ingest=round(t_ingest, 2)),
                     roofline=roofline)
+        if method >= 0 and t_accum > 0:
+            # the second kernel (fit + accumulate): algorithmic bytes of SURVEY §8(d) against HBM, and — what actually bounds it —
+            # its FP64 instruction count (profiles/*pmc*: 407 per point for P2Plane) against the FP64 vector issue rate
+            # (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12 lane-instructions/s)
+            a_gbs = (accum_bytes / 1e9) / (t_accum / 1e3)
+            line["roofline_k2"] = dict(bound="hbm", kernel="icp_%s_accum_kernel" % args.method, achieved=round(a_gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                       frac=round(a_gbs / HBM_PEAK_GBS, 5), ms_per_step=round(t_accum, 4),
+                                       fp64_issue_frac=(round(q * 407 / (t_accum / 1e3) / 39.3e12, 4) if args.method == "p2plane" else None),
+                                       note="measured on two extra untimed steps" if prof_mode == 2 else "HIP events over the timed region")
         if world == 1 and not args.no_cpu_baseline and args.search == "tree":
             cb, cpu_poses = cpu_baseline(map_xyz, scans, inits, args.cpu_seconds, args.method)
             n = len(cpu_poses)

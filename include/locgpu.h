@@ -143,8 +143,9 @@ LOCGPU_API void locgpu_batch_destroy(locgpu_batch* b);
 /* The source deep copy of ScanMatch (SetSource, icp_registration.cpp:221,252-265) for a whole batch, overlapped with the GPU's work:
  * locgpu_batch_create_empty reserves room for n_scans scans of at most max_points_per_scan points; locgpu_batch_upload_async
  * replaces the batch's scans (counts[s] <= max_points_per_scan) and returns at once — a worker packs the strided host points
- * into pinned slots and streams them to HBM on a copy stream of the batch's own, under whatever the context's compute stream
- * is running (e.g. the align call of ANOTHER batch: two batches alternate as a double buffer). The host clouds must stay valid
+ * into pinned slots and streams them to HBM on the context's copy stream, under whatever its compute streams
+ * are running (e.g. the align call of ANOTHER batch: two batches alternate as a double buffer; one upload per context at a
+ * time — a second one waits for the first one's packing). The host clouds must stay valid
  * until locgpu_batch_upload_wait returns (it returns the upload's status); every align / hb call on the batch waits for its
  * pending upload first. */
 LOCGPU_API int locgpu_batch_create_empty(locgpu_ctx* ctx, int n_scans, size_t max_points_per_scan, locgpu_batch** out);
@@ -155,6 +156,17 @@ LOCGPU_API int locgpu_icp_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const do
                                       double* out_poses, locgpu_align_stats* stats);
 LOCGPU_API int locgpu_ndt_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, double* out_poses,
                                       locgpu_align_stats* stats);
+/* The same alignments in two halves, for a caller that keeps TWO batches in flight (no reference counterpart: the reference
+ * matches one scan at a time). The batches of a context are dealt to two compute streams in turn; *_begin copies the poses,
+ * enqueues the first eight Gauss–Newton iterations on the batch's stream and returns, locgpu_align_batch_end waits for them,
+ * enqueues further iterations while scans are still open and writes the results. Begun on batch B while batch A is not yet
+ * ended, B's first iterations fill the chip under A's last ones (which hold a handful of unconverged scans):
+ *     begin(A); loop { begin(B); end(A); swap(A, B); }
+ * One alignment per batch at a time; results are those of the blocking calls, bit for bit. The target must not change between
+ * begin and end. Sharded batches: every rank begins and ends its batches in the same order. */
+LOCGPU_API int locgpu_icp_align_batch_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const locgpu_icp_opts* opts);
+LOCGPU_API int locgpu_ndt_align_batch_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses);
+LOCGPU_API int locgpu_align_batch_end(locgpu_ctx* ctx, locgpu_batch* b, double* out_poses, locgpu_align_stats* stats);
 /* One H,B evaluation for every scan of the batch at the given poses (point-sharded multi-GPU mode: the caller
  * all-reduces hb over ranks, then calls locgpu_gn_update). hb: n_scans × 44 doubles = H36, B6, effective_num, ok. */
 LOCGPU_API int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* poses, const locgpu_icp_opts* opts, double* hb);
@@ -168,7 +180,7 @@ LOCGPU_API int locgpu_gn_update(const double hb[44], int method, int min_effecti
  * [first_scan, first_scan + n_local) — or, for one large alignment split by points, a slice of the points of every scan
  * (first_scan = 0, n_local = n_total). Poses, convergence flags and normal equations exist for all n_total scans on every rank:
  * in each Gauss–Newton iteration the per-scan sums (21 H + 6 B + effective_num; zeros for scans a rank does not hold) are
- * all-reduced over xGMI on the compute stream and every rank solves every scan, so all ranks take the same decisions.
+ * all-reduced over xGMI (on the context's communication stream, in host order) and every rank solves every scan, so all ranks take the same decisions.
  * The align / hb entry points are then COLLECTIVE (every rank calls them with the same poses and options; init_poses, out_poses
  * and stats have n_total entries) and scan-sharded results are bit-identical to the single-GPU ones. */
 #define LOCGPU_COMM_ID_BYTES 128

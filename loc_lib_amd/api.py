@@ -37,6 +37,7 @@ ABI_SYMBOLS = [
     "locgpu_submap_info", "locgpu_cloud_loam_extract", "locgpu_loam_extract",
     "locgpu_batch_create_empty", "locgpu_batch_upload_async", "locgpu_batch_upload_wait",
     "locgpu_bfnn_set_target", "locgpu_bfnn_knn",
+    "locgpu_icp_align_batch_begin", "locgpu_ndt_align_batch_begin", "locgpu_align_batch_end",
     "locgpu_comm_unique_id", "locgpu_comm_init", "locgpu_comm_info", "locgpu_batch_create_sharded", "locgpu_icp_set_target_bcast",
 ]
 COMM_ID_BYTES = 128
@@ -97,6 +98,8 @@ def lib():
             "locgpu_transform_cloud": (i32, [vp, vp, vp, sz, sz, vp, sz]),
             "locgpu_batch_create": (i32, [vp, vp, vp, sz, i32, vp]), "locgpu_batch_destroy": (None, [vp]),
             "locgpu_icp_align_batch": (i32, [vp, vp, vp, vp, vp, vp]), "locgpu_ndt_align_batch": (i32, [vp, vp, vp, vp, vp]),
+            "locgpu_icp_align_batch_begin": (i32, [vp, vp, vp, vp]), "locgpu_ndt_align_batch_begin": (i32, [vp, vp, vp]),
+            "locgpu_align_batch_end": (i32, [vp, vp, vp, vp]),
             "locgpu_icp_hb_batch": (i32, [vp, vp, vp, vp, vp]),
             "locgpu_gn_update": (i32, [vp, i32, i32, dbl, vp, vp, vp, vp]),
             "locgpu_ndt_set_target": (i32, [vp, vp, sz, sz, vp]), "locgpu_ndt_target_info": (i32, [vp, vp]),
@@ -354,6 +357,23 @@ class Context:
         out = np.zeros_like(ip)
         st = (AlignStats * batch.n_scans)()
         self._check(lib().locgpu_ndt_align_batch(self._h, batch._h, ip.ctypes.data, out.ctypes.data, st))
+        return out, [_stats_dict(s) for s in st]
+
+    # two batches in flight (locgpu.h: *_align_batch_begin / locgpu_align_batch_end)
+    def icp_align_batch_begin(self, batch, init_poses, opts):
+        batch.upload_wait()
+        ip = _pose(init_poses).reshape(batch.n_scans, 7)
+        self._check(lib().locgpu_icp_align_batch_begin(self._h, batch._h, ip.ctypes.data, ctypes.byref(opts)))
+
+    def ndt_align_batch_begin(self, batch, init_poses):
+        batch.upload_wait()
+        ip = _pose(init_poses).reshape(batch.n_scans, 7)
+        self._check(lib().locgpu_ndt_align_batch_begin(self._h, batch._h, ip.ctypes.data))
+
+    def align_batch_end(self, batch):
+        out = np.zeros((batch.n_scans, 7))
+        st = (AlignStats * batch.n_scans)()
+        self._check(lib().locgpu_align_batch_end(self._h, batch._h, out.ctypes.data, st))
         return out, [_stats_dict(s) for s in st]
 
     def icp_hb_batch(self, batch, poses, opts):

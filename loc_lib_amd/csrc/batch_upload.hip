@@ -26,60 +26,77 @@ void pack_points(const char* base, size_t stride, size_t n, float4* dst) {
 
 struct Unit { int scan; size_t off, len; };
 
-bool ensure_resources(locgpu_batch* b) {
-    BatchUploader& u = *b->up;
-    locgpu_ctx* ctx = b->ctx;
-    if (u.stream) return true;
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    u.n_threads = (int)std::min<unsigned>(8u, std::max(2u, hw / 4));
-    if (!hip_ok(ctx, hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking), "upload: hipStreamCreate") ||
-        !hip_ok(ctx, hipEventCreateWithFlags(&u.done, hipEventDisableTiming), "upload: hipEventCreate") ||
-        !hip_ok(ctx, hipHostMalloc((void**)&u.h_counts, (size_t)b->n_scans * sizeof(int)), "upload: hipHostMalloc counts"))
-        return false;
-    const int n_slots = u.n_threads * BatchUploader::kSlotsPerThread;
-    u.h_slots.assign(n_slots, nullptr);
-    u.slot_ev.assign(n_slots, nullptr);
-    u.slot_busy.assign(n_slots, 0);
-    for (int i = 0; i < n_slots; ++i)
-        if (!hip_ok(ctx, hipHostMalloc((void**)&u.h_slots[i], BatchUploader::kSlotPoints * sizeof(float4)), "upload: hipHostMalloc slot") ||
-            !hip_ok(ctx, hipEventCreateWithFlags(&u.slot_ev[i], hipEventDisableTiming), "upload: hipEventCreate"))
+void release_resources(Uploader& u) {
+    if (u.stream) (void)hipStreamSynchronize(u.stream);
+    for (float4* p : u.h_slots) if (p) (void)hipHostFree(p);
+    for (hipEvent_t e : u.slot_ev) if (e) (void)hipEventDestroy(e);
+    u.h_slots.clear(); u.slot_ev.clear(); u.slot_busy.clear();
+    if (u.stream) (void)hipStreamDestroy(u.stream);
+    u.stream = nullptr;
+}
+
+// Copy stream + at least `want_slots` pinned slots (capped by the thread count). All or nothing: on a failure everything that
+// was built is released again, so that the next call starts from scratch instead of finding a half-initialised uploader.
+bool ensure_resources(locgpu_ctx* ctx, size_t want_slots) {
+    Uploader& u = *ctx->up;
+    if (!u.stream) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        u.n_threads = (int)std::min<unsigned>(8u, std::max(2u, hw / 4));
+        if (!hip_ok(ctx, hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking), "upload: hipStreamCreate")) { u.stream = nullptr; return false; }
+    }
+    const size_t cap = (size_t)u.n_threads * Uploader::kSlotsPerThread;
+    const size_t want = std::min(cap, std::max<size_t>(1, want_slots));
+    while (u.h_slots.size() < want) {
+        float4* p = nullptr;
+        hipEvent_t ev = nullptr;
+        if (!hip_ok(ctx, hipHostMalloc((void**)&p, Uploader::kSlotPoints * sizeof(float4)), "upload: hipHostMalloc slot") ||
+            !hip_ok(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming), "upload: hipEventCreate")) {
+            if (p) (void)hipHostFree(p);
+            release_resources(u);
             return false;
+        }
+        u.h_slots.push_back(p);
+        u.slot_ev.push_back(ev);
+        u.slot_busy.push_back(0);
+    }
     return true;
 }
 
-void run_upload(locgpu_batch* b) {
-    BatchUploader& u = *b->up;
-    (void)hipSetDevice(b->ctx->device);
+void run_upload(locgpu_ctx* ctx) {
+    Uploader& u = *ctx->up;
+    locgpu_batch* b = u.current;
+    (void)hipSetDevice(ctx->device);
     // work units: every scan in slot-sized pieces
     std::vector<Unit> units;
     for (int s = 0; s < b->n_scans; ++s)
-        for (size_t o = 0; o < u.counts[s]; o += BatchUploader::kSlotPoints) units.push_back({s, o, std::min(BatchUploader::kSlotPoints, u.counts[s] - o)});
+        for (size_t o = 0; o < u.counts[s]; o += Uploader::kSlotPoints) units.push_back({s, o, std::min(Uploader::kSlotPoints, u.counts[s] - o)});
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
+    const int n_slots = (int)u.h_slots.size();
+    const int nt = (int)std::min<size_t>(std::min<size_t>((size_t)u.n_threads, (size_t)std::max(1, n_slots)), std::max<size_t>(1, units.size()));
     auto packer = [&](int t) {
-        (void)hipSetDevice(b->ctx->device);
-        int turn = 0;
+        (void)hipSetDevice(ctx->device);
+        // thread t owns slots t, t + nt, …
+        int slot = t;
         for (size_t i = next.fetch_add(1); i < units.size() && !failed.load(); i = next.fetch_add(1)) {
             const Unit& w = units[i];
-            const int slot = t * BatchUploader::kSlotsPerThread + turn;
-            // the slot's previous copy — of this upload or of the one before — has left it
+            // the slot's previous copy — of this upload or of an earlier one — has left it
             if (u.slot_busy[slot] && hipEventSynchronize(u.slot_ev[slot]) != hipSuccess) { failed = 1; break; }
             pack_points((const char*)u.srcs[w.scan] + w.off * u.stride, u.stride, w.len, u.h_slots[slot]);
             if (hipMemcpyAsync(b->d_src + (size_t)w.scan * b->max_n + w.off, u.h_slots[slot], w.len * sizeof(float4), hipMemcpyHostToDevice, u.stream) != hipSuccess ||
                 hipEventRecord(u.slot_ev[slot], u.stream) != hipSuccess) { failed = 1; break; }
             u.slot_busy[slot] = 1;
-            turn = (turn + 1) % BatchUploader::kSlotsPerThread;
+            slot = slot + nt < n_slots ? slot + nt : t;
         }
     };
-    const int nt = (int)std::min<size_t>((size_t)u.n_threads, std::max<size_t>(1, units.size()));
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(packer, t);
     packer(0);
     for (auto& t : th) t.join();
     bool ok = !failed.load();
-    for (int s = 0; s < b->n_scans; ++s) u.h_counts[s] = (int)u.counts[s];
-    ok = ok && hipMemcpyAsync(b->d_counts, u.h_counts, (size_t)b->n_scans * sizeof(int), hipMemcpyHostToDevice, u.stream) == hipSuccess &&
-         hipEventRecord(u.done, u.stream) == hipSuccess;
+    for (int s = 0; s < b->n_scans; ++s) b->upl.h_counts[s] = (int)u.counts[s];
+    ok = ok && hipMemcpyAsync(b->d_counts, b->upl.h_counts, (size_t)b->n_scans * sizeof(int), hipMemcpyHostToDevice, u.stream) == hipSuccess &&
+         hipEventRecord(b->upl.done, u.stream) == hipSuccess;
     if (!ok) { u.rc = LOCGPU_ERR_NO_DEVICE; u.err = std::string("batch upload: ") + hipGetErrorString(hipGetLastError()); }
 }
 
@@ -88,22 +105,27 @@ void run_upload(locgpu_batch* b) {
 int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts, size_t stride_bytes) {
     locgpu_ctx* ctx = b->ctx;
     if (!srcs || !counts || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "batch upload: bad arguments");
+    size_t pieces = 0;
     for (int s = 0; s < b->n_scans; ++s) {
         if (counts[s] > (size_t)b->max_n) return fail(ctx, LOCGPU_ERR_INVALID, "batch upload: a scan has more points than the batch was created for");
         if (counts[s] && !srcs[s]) return fail(ctx, LOCGPU_ERR_INVALID, "batch upload: NULL scan pointer");
+        pieces += (counts[s] + Uploader::kSlotPoints - 1) / Uploader::kSlotPoints;
     }
-    const int jrc = upload_join(b);  // one upload per batch at a time
+    const int jrc = upload_join(ctx);  // one upload per context at a time
     if (jrc != LOCGPU_OK) return jrc;
-    if (!b->up) b->up = new BatchUploader();
-    if (!ensure_resources(b)) return LOCGPU_ERR_OOM;
-    BatchUploader& u = *b->up;
+    if (!ctx->up) ctx->up = new Uploader();
+    if (!ensure_resources(ctx, pieces)) return LOCGPU_ERR_OOM;
+    Uploader& u = *ctx->up;
+    BatchUploadState& st = b->upl;
+    if (!st.done && !hip_ok(ctx, hipEventCreateWithFlags(&st.done, hipEventDisableTiming), "upload: hipEventCreate")) { st.done = nullptr; return LOCGPU_ERR_OOM; }
+    if (!st.h_counts && !hip_ok(ctx, hipHostMalloc((void**)&st.h_counts, (size_t)b->n_scans * sizeof(int)), "upload: hipHostMalloc counts")) { st.h_counts = nullptr; return LOCGPU_ERR_OOM; }
     // One upload of a batch at a time, end to end: the previous one's copies (same destination, same pinned counts) have landed.
-    if (u.done_valid && !hip_ok(ctx, hipEventSynchronize(u.done), "batch upload: previous upload")) return LOCGPU_ERR_NO_DEVICE;
-    // The previous contents of the source array may still be read by kernels enqueued on the compute stream (an align call
-    // always synchronises before it returns, so in practice the stream is idle): order the copies behind them.
+    if (st.done_valid && !hip_ok(ctx, hipEventSynchronize(st.done), "batch upload: previous upload")) return LOCGPU_ERR_NO_DEVICE;
+    // The previous contents of the source array may still be read by kernels enqueued on the batch's compute stream (an alignment
+    // that was begun and not yet finished): order the copies behind them.
     hipEvent_t ev = nullptr;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
-        (void)hipEventRecord(ev, ctx->stream);
+        (void)hipEventRecord(ev, b->stream);
         (void)hipStreamWaitEvent(u.stream, ev, 0);
         (void)hipEventDestroy(ev);
     }
@@ -113,38 +135,56 @@ int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts,
     u.rc = LOCGPU_OK;
     u.err.clear();
     for (int s = 0; s < b->n_scans; ++s) b->counts[s] = (int)counts[s];
-    u.done_valid = true;
+    st.done_valid = true;
+    u.current = b;
     u.worker_active = true;
-    u.worker = std::thread(run_upload, b);
+    u.worker = std::thread(run_upload, ctx);
     return LOCGPU_OK;
 }
 
-int upload_join(locgpu_batch* b) {
-    if (!b->up || !b->up->worker_active) return LOCGPU_OK;
-    BatchUploader& u = *b->up;
+int upload_join(locgpu_ctx* ctx) {
+    if (!ctx->up || !ctx->up->worker_active) return LOCGPU_OK;
+    Uploader& u = *ctx->up;
     u.worker.join();
     u.worker_active = false;
-    if (u.rc != LOCGPU_OK) return fail(b->ctx, u.rc, u.err);
+    u.current = nullptr;
+    if (u.rc != LOCGPU_OK) return fail(ctx, u.rc, u.err);
     return LOCGPU_OK;
+}
+
+int upload_join_batch(locgpu_batch* b) {
+    locgpu_ctx* ctx = b->ctx;
+    if (!ctx->up || !ctx->up->worker_active || ctx->up->current != b) return LOCGPU_OK;
+    return upload_join(ctx);
 }
 
 hipError_t upload_order_after(locgpu_batch* b, hipStream_t s) {
-    if (!b->up || !b->up->done_valid) return hipSuccess;
-    return hipStreamWaitEvent(s, b->up->done, 0);
+    if (!b->upl.done_valid) return hipSuccess;
+    return hipStreamWaitEvent(s, b->upl.done, 0);
 }
 
-void upload_free(locgpu_batch* b) {
-    if (!b->up) return;
-    BatchUploader& u = *b->up;
+hipError_t upload_wait_landed(locgpu_batch* b) {
+    if (!b->upl.done_valid) return hipSuccess;
+    return hipEventSynchronize(b->upl.done);
+}
+
+void upload_free_batch(locgpu_batch* b) {
+    locgpu_ctx* ctx = b->ctx;
+    // a destroy while the worker still packs this batch's scans: let it finish, then let the copies land
+    if (ctx->up && ctx->up->worker_active && ctx->up->current == b) (void)upload_join(ctx);
+    if (b->upl.done_valid && b->upl.done) (void)hipEventSynchronize(b->upl.done);
+    if (b->upl.h_counts) (void)hipHostFree(b->upl.h_counts);
+    if (b->upl.done) (void)hipEventDestroy(b->upl.done);
+    b->upl = BatchUploadState();
+}
+
+void upload_free_ctx(locgpu_ctx* ctx) {
+    if (!ctx->up) return;
+    Uploader& u = *ctx->up;
     if (u.worker_active) { u.worker.join(); u.worker_active = false; }
-    if (u.stream) (void)hipStreamSynchronize(u.stream);
-    for (float4* p : u.h_slots) if (p) (void)hipHostFree(p);
-    for (hipEvent_t e : u.slot_ev) if (e) (void)hipEventDestroy(e);
-    if (u.h_counts) (void)hipHostFree(u.h_counts);
-    if (u.done) (void)hipEventDestroy(u.done);
-    if (u.stream) (void)hipStreamDestroy(u.stream);
-    delete b->up;
-    b->up = nullptr;
+    release_resources(u);
+    delete ctx->up;
+    ctx->up = nullptr;
 }
 
 }  // namespace locgpu

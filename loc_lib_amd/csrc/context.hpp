@@ -6,16 +6,25 @@
 #include <vector>
 
 #include "../../include/locgpu.h"
+#include "batch_upload.hpp"
 #include "device_math.hpp"
 #include "grid_kernels.hpp"
 #include "icp_kernels.hpp"
 
 struct NdtTable;  // ndt_kernels.hpp
-namespace locgpu { struct IncNdtState; struct FilterScratch; struct BatchUploader; }  // ndt_inc.hpp, cloud_filters.hpp
+namespace locgpu { struct IncNdtState; struct FilterScratch; }  // ndt_inc.hpp, cloud_filters.hpp
 
 struct locgpu_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // = slot_stream[0]: target ingest, clouds, single-scan calls
+    // Batches are dealt to kSlots compute streams in turn, so that an alignment begun on one batch (locgpu_*_align_batch_begin)
+    // runs under the tail of the one begun before it: late Gauss–Newton iterations hold a handful of scans and leave most of the
+    // chip idle.
+    static constexpr int kSlots = 2;
+    hipStream_t slot_stream[kSlots] = {nullptr, nullptr};
+    int next_slot = 0;
+    hipStream_t comm_stream = nullptr;  // every collective of the context, in host order (one communicator, one stream: no two at once)
+    locgpu::Uploader* up = nullptr;     // host → HBM staging shared by the context's batches (batch_upload.hpp)
     std::string err;
 
     // ICP target: packed KD-tree in HBM (kdtree_build.cpp layout)
@@ -54,7 +63,6 @@ struct locgpu_ctx {
 
     // measurement
     int profile = 0;  // 0 off, 1 = events around search / fit+accumulate / solve, 2 = around the search stage only
-    std::vector<hipEvent_t> events;
     double prof_ms[3] = {0, 0, 0};
     long long prof_n[3] = {0, 0, 0};
     bool use_graph = false;  // replay a captured hipGraph of all GN iterations instead of eager chunks
@@ -65,6 +73,8 @@ struct locgpu_ctx {
 
 struct locgpu_batch {
     locgpu_ctx* ctx = nullptr;
+    int slot = 0;
+    hipStream_t stream = nullptr;  // ctx->slot_stream[slot]: everything the batch's alignments enqueue
     int n_scans = 0, max_n = 0, blocks_per_scan = 0;  // n_scans: the scans whose points THIS rank holds
     // Sharded batch (locgpu_batch_create_sharded): the batch has n_total scans, this rank holds the points of scans
     // [first, first + n_scans) — or, point-sharded, a slice of the points of every scan (first = 0, n_scans = n_total). Poses, flags
@@ -97,7 +107,20 @@ struct locgpu_batch {
     locgpu::PoseState* h_state = nullptr;  // pinned
     double* h_hb = nullptr;                // pinned
     std::vector<int> counts;
-    locgpu::BatchUploader* up = nullptr;   // pinned slots + copy stream of locgpu_batch_upload_async (batch_upload.hpp)
+    locgpu::BatchUploadState upl;          // event + pinned counts of locgpu_batch_upload_async (batch_upload.hpp)
+    std::vector<hipEvent_t> events;        // profiling events of the batch's alignments (locgpu_profile_enable)
+    hipEvent_t ev_ready = nullptr, ev_reduced = nullptr;  // sharded batches: compute stream ⇄ comm stream hand-over
+    // an alignment begun with *_align_batch_begin and not yet finished
+    struct Pending {
+        bool active = false;
+        locgpu::GnParams prm{};
+        int k = 0;
+        float alpha_eff = 0.f;
+        bool ndt = false, graph = false;
+        int launched = 0;
+        size_t ev_used = 0;
+        std::vector<double> init_poses;
+    } pending;
 };
 
 namespace locgpu {

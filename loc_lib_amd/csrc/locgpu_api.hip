@@ -100,7 +100,10 @@ static int ensure_grid(locgpu_ctx* ctx) {
 
 static void free_batch(locgpu_batch* b) {
     if (!b) return;
-    upload_free(b);
+    upload_free_batch(b);
+    for (hipEvent_t ev : b->events) (void)hipEventDestroy(ev);
+    if (b->ev_ready) (void)hipEventDestroy(b->ev_ready);
+    if (b->ev_reduced) (void)hipEventDestroy(b->ev_reduced);
     if (b->d_src) (void)hipFree(b->d_src);
     if (b->d_counts) (void)hipFree(b->d_counts);
     if (b->d_state) (void)hipFree(b->d_state);
@@ -167,11 +170,14 @@ int locgpu_create(int device_id, locgpu_ctx** out) {
     auto* ctx = new locgpu_ctx();
     ctx->device = device_id;
     locgpu_ndt_opts_default(&ctx->ndt_opts);
-    if (!hip_ok(nullptr, hipSetDevice(device_id), "hipSetDevice") ||
-        !hip_ok(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate")) {
+    bool ok = hip_ok(nullptr, hipSetDevice(device_id), "hipSetDevice");
+    for (int i = 0; ok && i < locgpu_ctx::kSlots; ++i) ok = hip_ok(nullptr, hipStreamCreateWithFlags(&ctx->slot_stream[i], hipStreamNonBlocking), "hipStreamCreate");
+    if (!ok) {
+        for (hipStream_t st : ctx->slot_stream) if (st) (void)hipStreamDestroy(st);
         delete ctx;
         return LOCGPU_ERR_NO_DEVICE;
     }
+    ctx->stream = ctx->slot_stream[0];
     *out = ctx;
     return LOCGPU_OK;
 }
@@ -179,9 +185,12 @@ int locgpu_create(int device_id, locgpu_ctx** out) {
 void locgpu_destroy(locgpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t st : ctx->slot_stream) if (st) (void)hipStreamSynchronize(st);
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
     free_batch(ctx->single);
+    upload_free_ctx(ctx);
     if (ctx->comm) { (void)rccl().CommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->d_tree) (void)hipFree(ctx->d_tree);
     if (ctx->d_leaf_slots) (void)hipFree(ctx->d_leaf_slots);
     if (ctx->d_bfnn) (void)hipFree(ctx->d_bfnn);
@@ -191,8 +200,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     ndt_free(ctx);
     filters_free(ctx);
     loam_free(ctx);
-    for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (hipStream_t st : ctx->slot_stream) if (st) (void)hipStreamDestroy(st);
     delete ctx;
 }
 
@@ -215,6 +223,7 @@ static int build_host_tree(locgpu_ctx* ctx, const void* pts, size_t n, size_t st
 // meta = {slots, leaves, nodes, points, depth, bounded}. The device buffers only ever grow: a streaming front-end re-ingests its
 // local map every keyframe (lio.cpp:296-305) and must not pay a hipMalloc/hipFree pair (≈100 µs each) per ingest.
 static int install_tree_meta(locgpu_ctx* ctx, const long long meta[6]) {
+    for (hipStream_t st : ctx->slot_stream) LOCGPU_HIP(ctx, hipStreamSynchronize(st));  // nobody reads the old tree any more (a begun alignment must be finished first)
     free_grid(ctx);
     const size_t slots = (size_t)meta[0], leaves = (size_t)meta[1];
     if (slots + 2 > ctx->tree_cap_slots) {  // + the sentinel leaf behind the tree (search_walk.hpp)
@@ -299,7 +308,19 @@ int locgpu_icp_set_target_bcast(locgpu_ctx* ctx, const void* pts, size_t n, size
     if (!ok) return fail(ctx, LOCGPU_ERR_NO_DEVICE, "icp_set_target_bcast: broadcast of the tree header failed");
     if (meta[6] != LOCGPU_OK) return ctx->comm_rank == root ? (int)meta[6] : fail(ctx, (int)meta[6], "icp_set_target_bcast: the root rank could not build the tree");
     rc = install_tree_meta(ctx, meta);
-    if (rc != LOCGPU_OK) return rc;
+    {
+        // collective error exit: a rank that could not make room for the tree must not leave the others waiting in the broadcast
+        int* d_rc = nullptr;
+        int all_rc = rc;
+        bool okc = hip_ok(ctx, hipMalloc((void**)&d_rc, sizeof(int)), "bcast status") &&
+                   hip_ok(ctx, hipMemcpyAsync(d_rc, &rc, sizeof(int), hipMemcpyHostToDevice, s), "bcast status H2D");
+        okc = okc && rccl().AllReduce(d_rc, d_rc, 1, ncclInt, ncclMin, comm, s) == ncclSuccess;  // status codes are <= 0
+        okc = okc && hip_ok(ctx, hipMemcpyAsync(&all_rc, d_rc, sizeof(int), hipMemcpyDeviceToHost, s), "bcast status D2H") && hip_ok(ctx, hipStreamSynchronize(s), "sync");
+        if (d_rc) (void)hipFree(d_rc);
+        if (!okc) return fail(ctx, LOCGPU_ERR_NO_DEVICE, "icp_set_target_bcast: status exchange failed");
+        if (rc != LOCGPU_OK) return rc;
+        if (all_rc != LOCGPU_OK) return fail(ctx, all_rc, "icp_set_target_bcast: another rank could not allocate the tree buffers");
+    }
     if (ctx->comm_rank == root) {
         LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_leaf_slots, t.leaf_slots.data(), t.leaf_slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
@@ -391,14 +412,19 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
     *out = nullptr;
     const bool sharded = n_total >= 0;
     if (!sharded) n_total = n_scans;
-    if (n_scans <= 0 || first < 0 || first + n_scans > n_total) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: bad arguments");
+    // a sharded batch may hold NO scan on this rank (more ranks than scans): it then only contributes zeros to the exchange
+    if (n_scans < 0 || (n_scans == 0 && !sharded) || first < 0 || first + n_scans > n_total) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: bad arguments");
     if (n_total > 65535) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: at most 65535 scans per batch");
     if (n_scans > 65535) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: at most 65535 scans per batch");
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_scans == 0) max_n = 1;
     if (max_n == 0 || max_n > 0x7FFFFF00u || (size_t)n_scans * max_n > 0xFFFFFFF0ull)
         return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: scans are empty or the batch exceeds 2^32 points");
     auto* b = new locgpu_batch();
     b->ctx = ctx;
+    b->slot = ctx->next_slot;
+    ctx->next_slot = (ctx->next_slot + 1) % locgpu_ctx::kSlots;
+    b->stream = ctx->slot_stream[b->slot];
     b->n_scans = n_scans;
     b->n_total = n_total;
     b->first = first;
@@ -407,19 +433,19 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
     b->blocks_per_scan = (int)((max_n + kBlock - 1) / kBlock);
     b->pitch = (size_t)n_scans * max_n;
     b->counts.assign(n_scans, 0);
-    bool ok = hip_ok(ctx, hipMalloc((void**)&b->d_src, b->pitch * sizeof(float4)), "hipMalloc src") &&
-              hip_ok(ctx, hipMalloc((void**)&b->d_counts, n_scans * sizeof(int)), "hipMalloc counts") &&
+    bool ok = hip_ok(ctx, hipMalloc((void**)&b->d_src, std::max<size_t>(b->pitch, 1) * sizeof(float4)), "hipMalloc src") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_counts, std::max(n_scans, 1) * sizeof(int)), "hipMalloc counts") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_state, n_total * sizeof(PoseState)), "hipMalloc state") &&
               (!sharded || hip_ok(ctx, hipMalloc((void**)&b->d_acc, (size_t)n_total * kAccW * sizeof(double)), "hipMalloc acc")) &&
-              hip_ok(ctx, hipMalloc((void**)&b->d_nn, 5 * b->pitch * sizeof(uint32_t)), "hipMalloc nn") &&
-              hip_ok(ctx, hipMalloc((void**)&b->d_partials, (size_t)n_scans * b->blocks_per_scan * kAccW * sizeof(double)), "hipMalloc partials") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_nn, 5 * std::max<size_t>(b->pitch, 1) * sizeof(uint32_t)), "hipMalloc nn") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_partials, (size_t)std::max(n_scans, 1) * b->blocks_per_scan * kAccW * sizeof(double)), "hipMalloc partials") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_hb, (size_t)n_total * 44 * sizeof(double)), "hipMalloc hb") &&
-              hip_ok(ctx, hipMalloc((void**)&b->d_redo_list, (getenv("LOCGPU_STAMP") ? 2 : 1) * b->pitch * sizeof(uint32_t)), "hipMalloc redo") &&  // diagnostic build: + per-query trip counts
-              hip_ok(ctx, hipMalloc((void**)&b->d_redo_list2, b->pitch * sizeof(uint32_t)), "hipMalloc redo2") &&  // deep pass / grid search: second work list
+              hip_ok(ctx, hipMalloc((void**)&b->d_redo_list, (getenv("LOCGPU_STAMP") ? 2 : 1) * std::max<size_t>(b->pitch, 1) * sizeof(uint32_t)), "hipMalloc redo") &&  // diagnostic build: + per-query trip counts
+              hip_ok(ctx, hipMalloc((void**)&b->d_redo_list2, std::max<size_t>(b->pitch, 1) * sizeof(uint32_t)), "hipMalloc redo2") &&  // deep pass / grid search: second work list
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, 2 * sizeof(unsigned int)), "hipMalloc redo") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_total * sizeof(PoseState)), "hipHostMalloc state") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_total * 44 * sizeof(double)), "hipHostMalloc hb") &&
-              hip_ok(ctx, hipMemset(b->d_counts, 0, n_scans * sizeof(int)), "hipMemset counts") &&
+              hip_ok(ctx, hipMemset(b->d_counts, 0, std::max(n_scans, 1) * sizeof(int)), "hipMemset counts") &&
               hip_ok(ctx, hipMemset(b->d_redo_count, 0, 2 * sizeof(unsigned int)), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
     if (!ok) { free_batch(b); return LOCGPU_ERR_OOM; }
     *out = b;
@@ -431,7 +457,7 @@ static int make_batch(locgpu_ctx* ctx, const void* const* srcs, const size_t* co
                       int first = 0, int n_total = -1) {
     if (!ctx || !out) return LOCGPU_ERR_INVALID;
     *out = nullptr;
-    if (n_scans <= 0 || !srcs || !counts || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: bad arguments");
+    if (n_scans < 0 || (n_scans > 0 && (!srcs || !counts)) || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create: bad arguments");
     size_t max_n = 0;
     for (int s = 0; s < n_scans; ++s) max_n = std::max(max_n, counts[s]);
     for (int s = 0; s < n_scans; ++s)
@@ -439,9 +465,11 @@ static int make_batch(locgpu_ctx* ctx, const void* const* srcs, const size_t* co
     locgpu_batch* b = nullptr;
     int rc = alloc_batch(ctx, n_scans, max_n, &b, first, n_total);
     if (rc != LOCGPU_OK) return rc;
-    rc = upload_start(b, srcs, counts, stride_bytes);
-    if (rc == LOCGPU_OK) rc = upload_join(b);
-    if (rc == LOCGPU_OK && !hip_ok(ctx, hipStreamSynchronize(b->up->stream), "batch_create: H2D")) rc = LOCGPU_ERR_NO_DEVICE;
+    if (n_scans > 0) {
+        rc = upload_start(b, srcs, counts, stride_bytes);
+        if (rc == LOCGPU_OK) rc = upload_join(ctx);
+        if (rc == LOCGPU_OK && !hip_ok(ctx, upload_wait_landed(b), "batch_create: H2D")) rc = LOCGPU_ERR_NO_DEVICE;
+    }
     if (rc != LOCGPU_OK) { free_batch(b); return rc; }
     *out = b;
     return LOCGPU_OK;
@@ -463,15 +491,26 @@ int locgpu_batch_upload_async(locgpu_batch* b, const void* const* srcs, const si
 
 int locgpu_batch_upload_wait(locgpu_batch* b) {
     if (!b) return LOCGPU_ERR_INVALID;
-    return upload_join(b);
+    return upload_join_batch(b);
 }
 
 int locgpu_batch_create_sharded(locgpu_ctx* ctx, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_local, int first_scan,
                                 int n_total, locgpu_batch** out) {
     if (!ctx) return LOCGPU_ERR_INVALID;
     if (n_total <= 0) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create_sharded: n_total must be positive");
-    if (ctx->comm_world > 1 && !ctx->comm) return fail(ctx, LOCGPU_ERR_INVALID, "batch_create_sharded: locgpu_comm_init has not been called");
-    return make_batch(ctx, srcs, counts, stride_bytes, n_local, out, first_scan, n_total);
+    // Without a communicator nobody else can contribute the scans this rank does not hold: their sums would silently stay zero.
+    if (!ctx->comm && !(first_scan == 0 && n_local == n_total))
+        return fail(ctx, LOCGPU_ERR_INVALID, "batch_create_sharded: this rank holds only part of the batch and locgpu_comm_init has not been called");
+    const int rc = make_batch(ctx, srcs, counts, stride_bytes, n_local, out, first_scan, n_total);
+    if (rc != LOCGPU_OK) return rc;
+    locgpu_batch* b = *out;
+    if (!hip_ok(ctx, hipEventCreateWithFlags(&b->ev_ready, hipEventDisableTiming), "batch_create_sharded: hipEventCreate") ||
+        !hip_ok(ctx, hipEventCreateWithFlags(&b->ev_reduced, hipEventDisableTiming), "batch_create_sharded: hipEventCreate")) {
+        free_batch(b);
+        *out = nullptr;
+        return LOCGPU_ERR_OOM;
+    }
+    return LOCGPU_OK;
 }
 
 int locgpu_comm_unique_id(void* id_out) {
@@ -494,6 +533,11 @@ int locgpu_comm_init(locgpu_ctx* ctx, int rank, int world, const void* id) {
     ncclComm_t comm = nullptr;
     const ncclResult_t nr = rccl().CommInitRank(&comm, world, uid, rank);
     if (nr != ncclSuccess) return fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclCommInitRank: ") + rccl().GetErrorString(nr));
+    if (!ctx->comm_stream && !hip_ok(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking), "comm_init: hipStreamCreate")) {
+        (void)rccl().CommDestroy(comm);
+        ctx->comm_stream = nullptr;
+        return LOCGPU_ERR_NO_DEVICE;
+    }
     ctx->comm = comm;
     ctx->comm_rank = rank;
     ctx->comm_world = world;
@@ -510,7 +554,8 @@ int locgpu_comm_info(const locgpu_ctx* ctx, int* rank, int* world) {
 void locgpu_batch_destroy(locgpu_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipStreamSynchronize(b->stream);
+    if (b->sharded && b->ctx->comm_stream) (void)hipStreamSynchronize(b->ctx->comm_stream);
     free_batch(b);
 }
 
@@ -529,13 +574,13 @@ static void init_states(locgpu_batch* b, const double* poses) {
     }
 }
 
-static hipEvent_t get_event(locgpu_ctx* ctx, size_t i) {
-    while (ctx->events.size() <= i) {
+static hipEvent_t get_event(locgpu_batch* b, size_t i) {
+    while (b->events.size() <= i) {
         hipEvent_t ev;
         if (hipEventCreate(&ev) != hipSuccess) return nullptr;
-        ctx->events.push_back(ev);
+        b->events.push_back(ev);
     }
-    return ctx->events[i];
+    return b->events[i];
 }
 
 struct IterLauncher {
@@ -561,17 +606,19 @@ struct IterLauncher {
 namespace locgpu {
 
 bool IterLauncher::launch(int do_update) {
-    hipStream_t s = ctx->stream;
+    hipStream_t s = b->stream;
     const int prof = capturing ? 0 : ctx->profile;
     auto mark = [&](bool search_edge = false) {
         if (!prof || (prof == 2 && !search_edge)) return;
-        hipEvent_t ev = get_event(ctx, ev_used);
+        hipEvent_t ev = get_event(b, ev_used);
         if (ev) { (void)hipEventRecord(ev, s); ev_used++; }
     };
     mark(true);
     int n_partial_blocks = b->blocks_per_scan;
     PoseState* st_local = b->d_state + b->first;  // kernels index the scans this rank holds: 0..n_scans-1
-    if (!ndt) {
+    if (b->n_scans == 0) {
+        mark(true);  // nothing local: this rank only takes part in the exchange below
+    } else if (!ndt) {
         SearchArgs sa{ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ctx->depth, b->d_src, b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, k, alpha_eff,
                       prm.method == LOCGPU_P2P ? 1 : 0, ctx->count_visits ? ctx->d_visits : nullptr, b->d_redo_list, b->d_redo_count,
                       b->d_redo_list2, b->d_redo_count + 1, ctx->d_search_stats};
@@ -602,8 +649,14 @@ bool IterLauncher::launch(int do_update) {
         // same convergence flags and stay in lock-step.
         launch_sum_partials(b->d_partials, n_partial_blocks, b->d_state, b->first, b->n_scans, b->n_total, b->d_acc, s);
         if (ctx->comm) {
-            const ncclResult_t nr = rccl().AllReduce(b->d_acc, b->d_acc, (size_t)b->n_total * kAccW, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
+            // Every collective of the context goes through ONE stream in host order — the order is the same on every rank because
+            // every rank sees the same convergence flags — so two batches in flight never have two collectives of the one
+            // communicator racing each other. Under stream capture the hand-over events become graph dependencies.
+            hipStream_t cs = ctx->comm_stream;
+            if (!hip_ok(ctx, hipEventRecord(b->ev_ready, s), "sharded: hipEventRecord") || !hip_ok(ctx, hipStreamWaitEvent(cs, b->ev_ready, 0), "sharded: hipStreamWaitEvent")) return false;
+            const ncclResult_t nr = rccl().AllReduce(b->d_acc, b->d_acc, (size_t)b->n_total * kAccW, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, cs);
             if (nr != ncclSuccess) { fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr)); return false; }
+            if (!hip_ok(ctx, hipEventRecord(b->ev_reduced, cs), "sharded: hipEventRecord") || !hip_ok(ctx, hipStreamWaitEvent(s, b->ev_reduced, 0), "sharded: hipStreamWaitEvent")) return false;
         }
         launch_gn_solve(b->d_acc, 1, b->d_state, b->n_total, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s);
     } else {
@@ -618,7 +671,7 @@ void IterLauncher::collect_profile() {
     if (ctx->profile == 2) {
         for (size_t i = 0; i + 1 < ev_used; i += 2) {
             float ms = 0.f;
-            if (!ndt && hipEventElapsedTime(&ms, ctx->events[i], ctx->events[i + 1]) == hipSuccess) {
+            if (!ndt && hipEventElapsedTime(&ms, b->events[i], b->events[i + 1]) == hipSuccess) {
                 ctx->prof_ms[0] += ms;
                 ctx->prof_n[0] += 1;
             }
@@ -628,7 +681,7 @@ void IterLauncher::collect_profile() {
             for (int j = 0; j < 3; ++j) {
                 if (ndt && j == 0) continue;  // NDT has no search kernel
                 float ms = 0.f;
-                if (hipEventElapsedTime(&ms, ctx->events[i + j], ctx->events[i + j + 1]) == hipSuccess) {
+                if (hipEventElapsedTime(&ms, b->events[i + j], b->events[i + j + 1]) == hipSuccess) {
                     ctx->prof_ms[j] += ms;
                     ctx->prof_n[j] += 1;
                 }
@@ -643,9 +696,9 @@ static void write_results(locgpu_batch* b, const double* init_poses, double* out
 // grid search on `b`, BEFORE any launch: launch() can run under hipStreamBeginCapture, where hipMalloc is not allowed.
 // A pending locgpu_batch_upload_async of `b`: wait until the host side is through, then order the compute stream behind the copies.
 static int batch_ready(locgpu_ctx* ctx, locgpu_batch* b) {
-    const int rc = upload_join(b);
+    const int rc = upload_join_batch(b);
     if (rc != LOCGPU_OK) return rc;
-    LOCGPU_HIP(ctx, upload_order_after(b, ctx->stream));
+    LOCGPU_HIP(ctx, upload_order_after(b, b->stream));
     return LOCGPU_OK;
 }
 
@@ -664,7 +717,7 @@ static int ensure_grid_lists(locgpu_ctx* ctx, locgpu_batch* b, float alpha_eff) 
 // open (capturing all max_iteration iterations in one graph made every call pay a dozen empty iterations).
 static int capture_chunk(locgpu_ctx* ctx, locgpu_batch* b, const GnParams& prm, int k, float alpha_eff, bool ndt, int iters, bool with_h2d,
                          hipGraphExec_t* out) {
-    hipStream_t s = ctx->stream;
+    hipStream_t s = b->stream;
     hipGraph_t graph = nullptr;
     LOCGPU_HIP(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     bool ok = !with_h2d || hip_ok(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, s), "capture H2D");
@@ -681,69 +734,99 @@ static int capture_chunk(locgpu_ctx* ctx, locgpu_batch* b, const GnParams& prm, 
     return LOCGPU_OK;
 }
 
-static int run_align_graph(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt,
-                           double* out_poses, locgpu_align_stats* stats) {
-    hipStream_t s = ctx->stream;
-    init_states(b, init_poses);
+// An alignment in two halves, so that a caller can have two batches in flight (their streams differ): align_begin enqueues the
+// first chunk of iterations and returns; align_finish waits for it, enqueues further chunks while scans are still open, and
+// writes the results. The blocking entry points are begin + finish back to back.
+static int ensure_graphs(locgpu_ctx* ctx, locgpu_batch* b, const GnParams& prm, int k, float alpha_eff, bool ndt) {
     const void* target = !ndt ? (const void*)ctx->d_tree : (prm.method == 4 ? inc_ndt_table_ptr(ctx->inc) : (const void*)ctx->ndt->d_keys);
     const bool same = b->graph_exec && b->graph_k == k && b->graph_alpha == alpha_eff && b->graph_ndt == ndt && b->graph_target == target &&
                       b->graph_epoch == ctx->target_epoch &&
                       b->graph_prm == prm;
+    if (same) return LOCGPU_OK;
     const int first = std::min(kFirstChunk, prm.max_iteration);
-    if (!same) {
-        if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
-        if (b->graph_exec_next) { (void)hipGraphExecDestroy(b->graph_exec_next); b->graph_exec_next = nullptr; }
-        int rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, first, true, &b->graph_exec);
-        if (rc == LOCGPU_OK && prm.max_iteration > first) rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, kNextChunk, false, &b->graph_exec_next);
-        if (rc != LOCGPU_OK) return rc;
-        b->graph_prm = prm; b->graph_k = k; b->graph_alpha = alpha_eff; b->graph_ndt = ndt; b->graph_target = target;
-        b->graph_epoch = ctx->target_epoch;
+    if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
+    if (b->graph_exec_next) { (void)hipGraphExecDestroy(b->graph_exec_next); b->graph_exec_next = nullptr; }
+    int rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, first, true, &b->graph_exec);
+    if (rc == LOCGPU_OK && prm.max_iteration > first) rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, kNextChunk, false, &b->graph_exec_next);
+    if (rc != LOCGPU_OK) return rc;
+    b->graph_prm = prm; b->graph_k = k; b->graph_alpha = alpha_eff; b->graph_ndt = ndt; b->graph_target = target;
+    b->graph_epoch = ctx->target_epoch;
+    return LOCGPU_OK;
+}
+
+// One chunk of iterations + the read-back of the per-scan states behind it, on the batch's stream.
+static int enqueue_chunk(locgpu_ctx* ctx, locgpu_batch* b, bool first_chunk) {
+    locgpu_batch::Pending& P = b->pending;
+    hipStream_t s = b->stream;
+    if (P.graph) {
+        // kernels of a finished scan return at once and the solve kernel stops at max_iteration, so a whole chunk is always safe
+        LOCGPU_HIP(ctx, hipGraphLaunch(first_chunk ? b->graph_exec : b->graph_exec_next, s));
+        P.launched += first_chunk ? std::min(kFirstChunk, P.prm.max_iteration) : kNextChunk;
+        return LOCGPU_OK;
     }
-    LOCGPU_HIP(ctx, hipGraphLaunch(b->graph_exec, s));
-    LOCGPU_HIP(ctx, hipStreamSynchronize(s));
-    int launched = first;
-    for (;;) {
+    if (first_chunk) LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, s));
+    IterLauncher it{ctx, b, P.prm, P.k, P.alpha_eff};
+    it.ndt = P.ndt;
+    it.ev_used = P.ev_used;
+    const int todo = std::min(first_chunk ? kFirstChunk : kNextChunk, P.prm.max_iteration - P.launched);
+    for (int c = 0; c < todo; ++c)
+        if (!it.launch(1)) return LOCGPU_ERR_NO_DEVICE;
+    P.ev_used = it.ev_used;
+    P.launched += todo;
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_total * sizeof(PoseState), hipMemcpyDeviceToHost, s));
+    return LOCGPU_OK;
+}
+
+static int align_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt) {
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    locgpu_batch::Pending& P = b->pending;
+    if (P.active) return fail(ctx, LOCGPU_ERR_INVALID, "align: an alignment of this batch has been begun and not finished");
+    if (!ndt) { const int grc = ensure_grid_lists(ctx, b, alpha_eff); if (grc != LOCGPU_OK) return grc; }
+    { const int urc = batch_ready(ctx, b); if (urc != LOCGPU_OK) return urc; }
+    P.prm = prm; P.k = k; P.alpha_eff = alpha_eff; P.ndt = ndt;
+    P.graph = ctx->use_graph && !ctx->count_visits && !b->sharded && prm.max_iteration > 0;
+    P.launched = 0;
+    P.ev_used = 0;
+    P.init_poses.assign(init_poses, init_poses + 7 * (size_t)b->n_total);
+    init_states(b, init_poses);
+    // the search stage's work-list counters: zero once per alignment, whatever an earlier call that failed between a search and
+    // its solve kernel left behind (the solve kernel re-zeroes them after every search)
+    if (!ndt) LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 2 * sizeof(unsigned int), b->stream));
+    if (P.graph) { const int rc = ensure_graphs(ctx, b, prm, k, alpha_eff, ndt); if (rc != LOCGPU_OK) return rc; }
+    if (prm.max_iteration > 0) { const int rc = enqueue_chunk(ctx, b, true); if (rc != LOCGPU_OK) return rc; }
+    P.active = true;
+    return LOCGPU_OK;
+}
+
+static int align_finish(locgpu_ctx* ctx, locgpu_batch* b, double* out_poses, locgpu_align_stats* stats) {
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    locgpu_batch::Pending& P = b->pending;
+    if (!P.active) return fail(ctx, LOCGPU_ERR_INVALID, "align: no alignment of this batch has been begun");
+    P.active = false;
+    while (P.prm.max_iteration > 0) {
+        LOCGPU_HIP(ctx, hipStreamSynchronize(b->stream));
+        if (!P.graph) {
+            IterLauncher it{ctx, b, P.prm, P.k, P.alpha_eff};
+            it.ndt = P.ndt;
+            it.ev_used = P.ev_used;
+            it.collect_profile();
+            P.ev_used = 0;
+        }
         bool all_done = true;
         for (int i = 0; i < b->n_total; ++i)
             if (!b->h_state[i].done) { all_done = false; break; }
-        if (all_done || launched >= prm.max_iteration) break;
-        // kernels of a finished scan return at once and the solve kernel stops at max_iteration, so a whole chunk is always safe
-        LOCGPU_HIP(ctx, hipGraphLaunch(b->graph_exec_next, s));
-        LOCGPU_HIP(ctx, hipStreamSynchronize(s));
-        launched += kNextChunk;
+        if (all_done || P.launched >= P.prm.max_iteration) break;
+        const int rc = enqueue_chunk(ctx, b, false);
+        if (rc != LOCGPU_OK) return rc;
     }
-    write_results(b, init_poses, out_poses, stats);
+    write_results(b, P.init_poses.data(), out_poses, stats);
     return LOCGPU_OK;
 }
 
 static int run_align(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt,
                      double* out_poses, locgpu_align_stats* stats) {
-    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ndt) { const int grc = ensure_grid_lists(ctx, b, alpha_eff); if (grc != LOCGPU_OK) return grc; }
-    { const int urc = batch_ready(ctx, b); if (urc != LOCGPU_OK) return urc; }
-    if (ctx->use_graph && !ctx->count_visits && !b->sharded && prm.max_iteration > 0) return run_align_graph(ctx, b, init_poses, prm, k, alpha_eff, ndt, out_poses, stats);
-    init_states(b, init_poses);
-    hipStream_t s = ctx->stream;
-    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, s));
-    IterLauncher it{ctx, b, prm, k, alpha_eff};
-    it.ndt = ndt;
-    int launched = 0;
-    bool all_done = prm.max_iteration <= 0;
-    while (!all_done) {
-        const int todo = std::min(launched == 0 ? kFirstChunk : kNextChunk, prm.max_iteration - launched);
-        for (int c = 0; c < todo; ++c)
-            if (!it.launch(1)) return LOCGPU_ERR_NO_DEVICE;
-        launched += todo;
-        LOCGPU_HIP(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_total * sizeof(PoseState), hipMemcpyDeviceToHost, s));
-        LOCGPU_HIP(ctx, hipStreamSynchronize(s));
-        it.collect_profile();
-        all_done = true;
-        for (int i = 0; i < b->n_total; ++i)
-            if (!b->h_state[i].done) { all_done = false; break; }
-        if (launched >= prm.max_iteration) all_done = true;
-    }
-    write_results(b, init_poses, out_poses, stats);
-    return LOCGPU_OK;
+    const int rc = align_begin(ctx, b, init_poses, prm, k, alpha_eff, ndt);
+    return rc != LOCGPU_OK ? rc : align_finish(ctx, b, out_poses, stats);
 }
 
 static void write_results(locgpu_batch* b, const double* init_poses, double* out_poses, locgpu_align_stats* stats) {
@@ -803,6 +886,8 @@ static int single_reserve(locgpu_ctx* ctx, size_t n, locgpu_batch** out) {
         const int rc = alloc_batch(ctx, 1, cap, &ctx->single);
         if (rc != LOCGPU_OK) return rc;
         b = ctx->single;
+        b->slot = 0;  // single-scan calls share the stream of the clouds and of the target ingest
+        b->stream = ctx->stream;
         if (!hip_ok(ctx, hipHostMalloc((void**)&b->h_src, cap * sizeof(float4)), "hipHostMalloc src")) { free_batch(b); ctx->single = nullptr; return LOCGPU_ERR_OOM; }
     }
     *out = b;
@@ -820,8 +905,8 @@ static int single_batch(locgpu_ctx* ctx, const void* src, size_t n, size_t strid
     const char* base = (const char*)src;
     for (size_t i = 0; i < n; ++i) { b->h_src[i] = float4{0.f, 0.f, 0.f, 0.f}; std::memcpy(&b->h_src[i], base + i * stride_bytes, 12); }
     b->counts[0] = (int)n;
-    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_src, b->h_src, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_counts, b->counts.data(), sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_src, b->h_src, n * sizeof(float4), hipMemcpyHostToDevice, b->stream));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_counts, b->counts.data(), sizeof(int), hipMemcpyHostToDevice, b->stream));
     *out = b;
     return LOCGPU_OK;
 }
@@ -832,8 +917,8 @@ static int single_batch_dev(locgpu_ctx* ctx, const float4* d_src, size_t n, locg
     const int rc = single_reserve(ctx, n, &b);
     if (rc != LOCGPU_OK) return rc;
     b->counts[0] = (int)n;
-    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_src, d_src, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_counts, b->counts.data(), sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_src, d_src, n * sizeof(float4), hipMemcpyDeviceToDevice, b->stream));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_counts, b->counts.data(), sizeof(int), hipMemcpyHostToDevice, b->stream));
     *out = b;
     return LOCGPU_OK;
 }
@@ -851,6 +936,22 @@ int locgpu_icp_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_
     if (rc != LOCGPU_OK) return rc;
     if (!b || b->ctx != ctx || !init_poses || !out_poses) return fail(ctx, LOCGPU_ERR_INVALID, "icp_align_batch: bad arguments");
     return run_align(ctx, b, init_poses, prm, k, alpha_eff, false, out_poses, stats);
+}
+
+int locgpu_icp_align_batch_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const locgpu_icp_opts* opts) {
+    GnParams prm{};
+    int k;
+    float alpha_eff;
+    const int rc = check_icp(ctx, opts, prm, k, alpha_eff);
+    if (rc != LOCGPU_OK) return rc;
+    if (!b || b->ctx != ctx || !init_poses) return fail(ctx, LOCGPU_ERR_INVALID, "icp_align_batch_begin: bad arguments");
+    return align_begin(ctx, b, init_poses, prm, k, alpha_eff, false);
+}
+
+int locgpu_align_batch_end(locgpu_ctx* ctx, locgpu_batch* b, double* out_poses, locgpu_align_stats* stats) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!b || b->ctx != ctx || !out_poses) return fail(ctx, LOCGPU_ERR_INVALID, "align_batch_end: bad arguments");
+    return align_finish(ctx, b, out_poses, stats);
 }
 
 int locgpu_icp_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7], const locgpu_icp_opts* opts,
@@ -877,12 +978,14 @@ int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* poses, c
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     { const int grc = ensure_grid_lists(ctx, b, alpha_eff); if (grc != LOCGPU_OK) return grc; }
     { const int urc = batch_ready(ctx, b); if (urc != LOCGPU_OK) return urc; }
+    if (b->pending.active) return fail(ctx, LOCGPU_ERR_INVALID, "icp_hb_batch: an alignment of this batch has been begun and not finished");
     init_states(b, poses);
-    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, ctx->stream));
+    LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 2 * sizeof(unsigned int), b->stream));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, b->stream));
     IterLauncher it{ctx, b, prm, k, alpha_eff};
     if (!it.launch(0)) return LOCGPU_ERR_NO_DEVICE;
-    LOCGPU_HIP(ctx, hipMemcpyAsync(b->h_hb, b->d_hb, (size_t)b->n_total * 44 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(b->h_hb, b->d_hb, (size_t)b->n_total * 44 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    LOCGPU_HIP(ctx, hipStreamSynchronize(b->stream));
     it.collect_profile();
     std::memcpy(hb, b->h_hb, (size_t)b->n_total * 44 * sizeof(double));
     return LOCGPU_OK;
@@ -895,9 +998,9 @@ int locgpu_debug_batch_nn(locgpu_ctx* ctx, locgpu_batch* b, int k, int32_t* out)
     const size_t nq = (size_t)b->n_scans * b->max_n;
     int32_t* d_out = nullptr;
     LOCGPU_HIP(ctx, hipMalloc((void**)&d_out, nq * k * sizeof(int32_t)));
-    launch_nn_to_index(ctx->d_tree, b->d_nn, b->pitch, nq, k, d_out, ctx->stream);
-    const hipError_t e = hipMemcpyAsync(out, d_out, nq * k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
-    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    launch_nn_to_index(ctx->d_tree, b->d_nn, b->pitch, nq, k, d_out, b->stream);
+    const hipError_t e = hipMemcpyAsync(out, d_out, nq * k * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream);
+    const hipError_t e2 = hipStreamSynchronize(b->stream);
     (void)hipFree(d_out);
     LOCGPU_HIP(ctx, e);
     LOCGPU_HIP(ctx, e2);
@@ -1018,7 +1121,7 @@ int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset) {
         LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_search_stats, kSearchStatSlots * sizeof(unsigned long long)));
         LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, kSearchStatSlots * sizeof(unsigned long long)));
     }
-    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t st : ctx->slot_stream) LOCGPU_HIP(ctx, hipStreamSynchronize(st));
     unsigned long long h[kSearchStatSlots];
     LOCGPU_HIP(ctx, hipMemcpy(h, ctx->d_search_stats, sizeof(h), hipMemcpyDeviceToHost));
     out[0] = h[0]; out[1] = h[1]; out[2] = getenv("LOCGPU_STAMP") ? 0 : h[2]; out[3] = getenv("LOCGPU_STAMP") ? h[15] : 0;
@@ -1055,7 +1158,7 @@ int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset) {
     out[0] = out[1] = out[2] = 0;
     if (!ctx->d_visits) return LOCGPU_OK;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
-    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t st : ctx->slot_stream) LOCGPU_HIP(ctx, hipStreamSynchronize(st));
     unsigned long long h[3];
     LOCGPU_HIP(ctx, hipMemcpy(h, ctx->d_visits, sizeof(h), hipMemcpyDeviceToHost));
     out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
@@ -1070,7 +1173,7 @@ int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset) {
 extern "C" __attribute__((visibility("default"))) int locgpu_debug_stamp_trips(locgpu_ctx* ctx, locgpu_batch* b, uint32_t* out) {
     if (!ctx || !b || !out || !getenv("LOCGPU_STAMP")) return LOCGPU_ERR_INVALID;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
-    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LOCGPU_HIP(ctx, hipStreamSynchronize(b->stream));
     LOCGPU_HIP(ctx, hipMemcpy(out, b->d_redo_list + b->pitch, b->pitch * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return LOCGPU_OK;
 }
@@ -1208,6 +1311,14 @@ int locgpu_ndt_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_
     if (rc != LOCGPU_OK) return rc;
     if (!b || b->ctx != ctx || !init_poses || !out_poses) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_batch: bad arguments");
     return run_align(ctx, b, init_poses, prm, 0, 1.0f, true, out_poses, stats);
+}
+
+int locgpu_ndt_align_batch_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses) {
+    GnParams prm{};
+    const int rc = check_ndt(ctx, prm);
+    if (rc != LOCGPU_OK) return rc;
+    if (!b || b->ctx != ctx || !init_poses) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_batch_begin: bad arguments");
+    return align_begin(ctx, b, init_poses, prm, 0, 1.0f, true);
 }
 
 int locgpu_ndt_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7], double out_pose[7],

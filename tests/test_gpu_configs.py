@@ -511,3 +511,73 @@ def test_hot_search_kernel_lists_on_ties_duplicates_and_p2p():
                 assert np.array_equal(got, want), (len(cloud), method, int(np.sum(np.any(got != want, axis=1))))
             b.close()
         ctx.close() if hasattr(ctx, "close") else None
+
+
+# ----------------------------------------------------------------------------------------------- two alignments in flight
+def test_align_begin_end_two_batches_in_flight(gpu_ctx, api, small_world):
+    """locgpu_*_align_batch_begin / locgpu_align_batch_end: two batches (different scans, ragged counts) begun back to back and ended
+    in order give bit for bit the poses, iteration counts and stats of the blocking calls — ICP and direct NDT — also when the
+    uploads of the next round are started while both alignments are in flight; a second begin on a pending batch and an end
+    without a begin are refused."""
+    m = small_world["map"]
+    s = small_world["scan10k"]
+    pose = small_world["init_pose"]
+    gpu_ctx.icp_set_target(m)
+    gpu_ctx.ndt_set_target(m)
+    sets = [[s, s[:7000], s[100:4100]], [s[::2], s[:9000], s[50:8050]]]
+    poses = [np.stack([pose, pose, pose]), np.stack([pose, pose, pose])]
+    for p in poses:
+        p[1, 4] += 0.05
+        p[2, 5] -= 0.04
+    opts = api.icp_opts(method=api.P2PLANE)
+    ref = []
+    for scans, ip in zip(sets, poses):
+        b = gpu_ctx.batch(scans)
+        ref.append((gpu_ctx.icp_align_batch(b, ip, opts), gpu_ctx.ndt_align_batch(b, ip)))
+        b.close()
+    ba, bb = gpu_ctx.batch_empty(3, 10000), gpu_ctx.batch_empty(3, 10000)
+    for rnd in range(2):
+        ba.upload_async(api.MarshalledScans(sets[0]))
+        ba.upload_wait()
+        bb.upload_async(api.MarshalledScans(sets[1]))
+        gpu_ctx.icp_align_batch_begin(ba, poses[0], opts)
+        gpu_ctx.icp_align_batch_begin(bb, poses[1], opts)
+        with pytest.raises(RuntimeError):
+            gpu_ctx.icp_align_batch_begin(ba, poses[0], opts)
+        pa, sa = gpu_ctx.align_batch_end(ba)
+        pb, sb = gpu_ctx.align_batch_end(bb)
+        with pytest.raises(RuntimeError):
+            gpu_ctx.align_batch_end(ba)
+        assert np.array_equal(pa, ref[0][0][0]) and np.array_equal(pb, ref[1][0][0])
+        assert [x["iterations"] for x in sa] == [x["iterations"] for x in ref[0][0][1]]
+        assert [x["iterations"] for x in sb] == [x["iterations"] for x in ref[1][0][1]]
+        gpu_ctx.ndt_align_batch_begin(ba, poses[0])
+        gpu_ctx.ndt_align_batch_begin(bb, poses[1])
+        pb, sb = gpu_ctx.align_batch_end(bb)  # ended out of order
+        pa, sa = gpu_ctx.align_batch_end(ba)
+        assert np.array_equal(pa, ref[0][1][0]) and np.array_equal(pb, ref[1][1][0])
+        assert [x["iterations"] for x in sb] == [x["iterations"] for x in ref[1][1][1]]
+    ba.close()
+    bb.close()
+
+
+def test_upload_error_and_destroy_while_pending(gpu_ctx, api, small_world):
+    """the uploader is per context; a refused upload (scan larger than the batch) leaves it usable, a batch destroyed
+    while its upload is still being packed is waited for, and many small batches do not pin 64 MB each."""
+    m = small_world["map"]
+    s = small_world["scan10k"]
+    pose = small_world["init_pose"]
+    gpu_ctx.icp_set_target(m)
+    opts = api.icp_opts(method=api.P2PLANE)
+    want, _ = gpu_ctx.icp_align(s, pose, opts)
+    b = gpu_ctx.batch_empty(2, 5000)
+    with pytest.raises(RuntimeError):
+        b.upload_async(api.MarshalledScans([s, s[:100]]))  # 10 000 points into a 5 000-point batch
+    ok = api.MarshalledScans([s[:5000], s[:100]])
+    b.upload_async(ok)
+    b.close()  # destroy while the worker may still be packing
+    many = [gpu_ctx.batch([s]) for _ in range(24)]  # 24 x 64 MB of pinned slots would be 1.5 GB
+    got, _ = gpu_ctx.icp_align_batch(many[-1], pose[None], opts)
+    assert np.array_equal(got[0], want)
+    for x in many:
+        x.close()
