@@ -182,21 +182,23 @@ __device__ __forceinline__ bool walk_exact_in_wave(const uint2* __restrict__ tre
     return true;
 }
 
-template <int K, int DF, int MODE>
+// LANES = active lanes per wave = stack columns (64; 16 for launches that cannot fill the chip anyway: a wave's time is its
+// longest traversal, and with 128-byte rows every level fits in LDS — T = 0 — so that no query needs the deep pass).
+template <int K, int DF, int MODE, int LANES = 64>
 __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                              const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                              uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, float alpha_eff, int T,
                                                              unsigned int tree_bytes, uint32_t dummy, int skip_nonfinite, uint32_t* __restrict__ redo_list,
                                                              unsigned int* __restrict__ redo_count, uint32_t* __restrict__ deep_list,
-                                                             unsigned int* __restrict__ deep_count, unsigned long long* __restrict__ search_stats, int lanes) {
+                                                             unsigned int* __restrict__ deep_count, unsigned long long* __restrict__ search_stats) {
     extern __shared__ uint2 s_dyn[];
-    constexpr int ROWB = 64 * 8;
+    constexpr int ROWB = LANES * 8;
     static_assert(DF * ROWB >= 64 * 2 * 8, "exact stack columns do not fit");
     const int scan = blockIdx.y;
     if (st[scan].done) return;
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * lanes + tid;
-    if (tid >= lanes || i >= counts[scan]) return;
+    const int i = blockIdx.x * LANES + tid;
+    if (tid >= LANES || i >= counts[scan]) return;
     const size_t gi = (size_t)scan * max_n + i;
     const float4 p = load_once(&src[gi]);
     if (skip_nonfinite && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {  // pcl::isFinite, icp cpp:64 (P2P only)
@@ -236,9 +238,11 @@ __global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* _
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0 && search_stats) atomicAdd(&search_stats[2], (unsigned long long)n);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
-    for (unsigned int r0 = blockIdx.x * 64u; r0 < n; r0 += gridDim.x * 64u) {
+    // a short list is spread thin: these are the long traversals, and a wave's time is the longest among its lanes
+    const unsigned int per_wave = min(64u, max(1u, (n + gridDim.x - 1) / gridDim.x));
+    for (unsigned int r0 = blockIdx.x * per_wave; r0 < n; r0 += gridDim.x * per_wave) {
         const unsigned int r = r0 + (unsigned int)tid;
-        const bool valid = r < n;
+        const bool valid = (unsigned int)tid < per_wave && r < n;
         const uint32_t gi = valid ? list[r] : 0u;
         Walk<K> w;
         w.qx = w.qy = w.qz = 0.f;
@@ -871,16 +875,25 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         // round-3 traversal (search_walk.hpp): rows 0/1 of the DF stored rows hold the candidates of the un-stored levels, the other
         // DF-2 rows one level each — T is chosen so that the stack cannot outgrow them. Queries whose un-stored levels need more than
         // two candidates go through a.redo_list2 to the deep pass (every level stored), ties to the exact redo kernel as before.
-        const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
-        static const int small_lanes = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); const int v = e ? atoi(e) : 16; return (v == 16 || v == 32) ? v : 64; }();
-        const int lanes = ((size_t)((a.max_n + 63) / 64) * a.n_scans <= 2048) ? small_lanes : 64;
         const uint32_t dummy = (uint32_t)(a.tree_bytes / 8);
-        dim3 g2((a.max_n + lanes - 1) / lanes, a.n_scans);
         static const int wpad = [] { const char* e = getenv("LOCGPU_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiment: extra dynamic LDS lowers occupancy
         static const int mode = [] { const char* e = getenv("LOCGPU_WALK_MODE"); return e ? atoi(e) : 2; }();
+        static const int small = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); return e ? atoi(e) : 16; }();
+        if ((size_t)((a.max_n + 63) / 64) * a.n_scans <= 2048 && small == 16 && mode == 2) {
+            // fewer than 2048 full waves (one or two scans): quarter-filled waves with every level stored — no deep pass
+            dim3 g1((a.max_n + 15) / 16, a.n_scans);
+            hipLaunchKernelGGL((icp_search_walk_kernel<K, D + 2, 2, 16>), g1, dim3(64), (D + 2) * 16 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+                               a.alpha_eff, 0, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
+                               a.search_stats);
+            hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
+                               a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
+            return;
+        }
+        const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
+        dim3 g2((a.max_n + 63) / 64, a.n_scans);
 #define LOCGPU_WALK_LAUNCH(M) hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, M>), g2, dim3(64), DF * 64 * 8 + wpad, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, \
                                                  a.max_n, a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count,       \
-                                                 a.redo_list2, a.redo_count2, a.search_stats, lanes)
+                                                 a.redo_list2, a.redo_count2, a.search_stats)
         if (mode == 2) LOCGPU_WALK_LAUNCH(2);
         else LOCGPU_WALK_LAUNCH(0);
 #undef LOCGPU_WALK_LAUNCH
