@@ -49,15 +49,21 @@ int upload(locgpu_cloud* c, const void* pts, size_t n, size_t stride, size_t iof
     if (e != hipSuccess) return hip_fail(ctx, e, "cloud_upload: hipHostMalloc");
     const char* base = (const char*)pts;
     const bool has_i = ioff != LOCGPU_NO_INTENSITY;
-    for (size_t i = 0; i < n; ++i) {
-        float4 p{0.f, 0.f, 0.f, 0.f};
-        std::memcpy(&p, base + i * stride, 12);
-        if (has_i) std::memcpy(&p.w, base + i * stride + ioff, 4);
-        stage[i] = p;
+    if (stride == sizeof(float4) && ioff == 12) {
+        std::memcpy(stage, base, n * sizeof(float4));  // already {x, y, z, intensity} records (pcl::PointXYZI without its padding)
+    } else {
+        for (size_t i = 0; i < n; ++i) {
+            float4 p{0.f, 0.f, 0.f, 0.f};
+            std::memcpy(&p, base + i * stride, 12);
+            if (has_i) std::memcpy(&p.w, base + i * stride + ioff, 4);
+            stage[i] = p;
+        }
     }
     if (n) {
+        // The caller's points have been deep-copied (they may be freed now); the copy to HBM is only enqueued — whatever uses the
+        // cloud next is ordered behind it on the same stream, and the next user of the staging buffer waits for it.
         e = hipMemcpyAsync(c->d, stage, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging buffer is reused by the next call
+        if (e == hipSuccess) e = cloud_stage_release(ctx);
         if (e != hipSuccess) return hip_fail(ctx, e, "cloud_upload: H2D");
     }
     c->n = n;

@@ -164,9 +164,13 @@ __global__ __launch_bounds__(kFB) void voxel_starts_kernel(const uint32_t* __res
 
 // One thread per voxel: CentroidPoint's float32 running sums in sorted (= input) order, then one division each. The gathers
 // of a run do not depend on the sums, so they are issued four at a time.
+// n_voxels_dev (optional): the number of voxels as the device knows it — the launch is then sized by an upper bound and the host
+// learns the count only from the single read-back at the end of the filter.
 __global__ __launch_bounds__(kFB) void voxel_centroid_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ vals,
-                                                             const uint32_t* __restrict__ start, uint32_t n_voxels, float4* __restrict__ out) {
+                                                             const uint32_t* __restrict__ start, uint32_t n_voxels, float4* __restrict__ out,
+                                                             const VoxelParams* __restrict__ n_voxels_dev) {
     const uint32_t v = blockIdx.x * kFB + threadIdx.x;
+    if (n_voxels_dev) n_voxels = n_voxels_dev->status == 0 ? n_voxels_dev->n_out : 0u;
     if (v >= n_voxels) return;
     const uint32_t b = start[v], e = start[v + 1];
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
@@ -370,6 +374,7 @@ void filters_free(locgpu_ctx* ctx) {
     if (S->h_params) (void)hipHostFree(S->h_params);
     if (S->d_partial) (void)hipFree(S->d_partial);
     if (S->d_tmp) (void)hipFree(S->d_tmp);
+    if (S->stage_ev) { (void)hipEventSynchronize(S->stage_ev); (void)hipEventDestroy(S->stage_ev); }
     if (S->h_stage) (void)hipHostFree(S->h_stage);
     delete S;
     ctx->filt = nullptr;
@@ -393,6 +398,10 @@ hipError_t cloud_reserve(locgpu_cloud* c, size_t n, bool keep) {
 
 hipError_t cloud_stage(locgpu_ctx* ctx, size_t n, float4** out) {
     FilterScratch* S = scratch(ctx);
+    if (S->stage_busy) {  // an upload returned with its copy still in flight (cloud_stage_release)
+        LOCGPU_TRY(hipEventSynchronize(S->stage_ev));
+        S->stage_busy = false;
+    }
     if (n > S->stage_cap || !S->h_stage) {
         if (S->h_stage) (void)hipHostFree(S->h_stage);
         S->h_stage = nullptr; S->stage_cap = 0;
@@ -401,6 +410,15 @@ hipError_t cloud_stage(locgpu_ctx* ctx, size_t n, float4** out) {
         S->stage_cap = cap;
     }
     *out = S->h_stage;
+    return hipSuccess;
+}
+
+// The staging buffer has been handed to an asynchronous copy on the context's stream: the next cloud_stage() waits for it.
+hipError_t cloud_stage_release(locgpu_ctx* ctx) {
+    FilterScratch* S = scratch(ctx);
+    if (!S->stage_ev) LOCGPU_TRY(hipEventCreateWithFlags(&S->stage_ev, hipEventDisableTiming));
+    LOCGPU_TRY(hipEventRecord(S->stage_ev, ctx->stream));
+    S->stage_busy = true;
     return hipSuccess;
 }
 
@@ -417,12 +435,21 @@ hipError_t voxel_filter_dev(locgpu_ctx* ctx, const locgpu_cloud* in, float leaf,
     hipLaunchKernelGGL(minmax_kernel, dim3(n_partial), dim3(kFB), 0, s, in->d, n, dense, S->d_partial);
     hipLaunchKernelGGL(voxel_setup_kernel, dim3(1), dim3(64), 0, s, S->d_params, S->d_partial, n_partial, inv);
     LOCGPU_TRY(hipGetLastError());
-    LOCGPU_TRY(read_params(ctx));
-    const VoxelParams hp = *S->h_params;
-    if (hp.status == 2) { *status = 2; out->n = 0; out->is_dense = 1; return hipSuccess; }
-    if (hp.status == 1) { *status = 1; return copy_through(ctx, in, out); }  // "Leaf size is too small…": output = *input_
-    int end_bit = 1;
-    while (end_bit < 32 && (1ull << end_bit) <= (unsigned long long)hp.invalid_key) ++end_bit;
+    // A scan-sized cloud is filtered with ONE host read-back (the output size, at the end) instead of two: the per-scan path of the
+    // front-ends is latency-bound, and each read-back is a stream synchronisation. The sort then covers all 32 key bits (the grid
+    // size is only known on the device), the centroid launch is sized by the input, and the two rare outcomes the set-up kernel
+    // reports — no finite point, leaf too small — are acted on after the fact (the kernels in between ran on stale parameters,
+    // within their buffers). A map-sized cloud keeps the early read-back: there the sort's key width matters.
+    const bool one_readback = n < (1u << 20);
+    int end_bit = 32;
+    if (!one_readback) {
+        LOCGPU_TRY(read_params(ctx));
+        const VoxelParams hp = *S->h_params;
+        if (hp.status == 2) { *status = 2; out->n = 0; out->is_dense = 1; return hipSuccess; }
+        if (hp.status == 1) { *status = 1; return copy_through(ctx, in, out); }  // "Leaf size is too small…": output = *input_
+        end_bit = 1;
+        while (end_bit < 32 && (1ull << end_bit) <= (unsigned long long)hp.invalid_key) ++end_bit;
+    }
     hipLaunchKernelGGL(voxel_key_kernel, dim3(blocks_for(n)), dim3(kFB), 0, s, in->d, n, dense, S->d_params, S->keys[0], S->vals[0]);
     size_t tb = S->temp_bytes;
     LOCGPU_TRY(hipcub::DeviceRadixSort::SortPairs(S->temp, tb, S->keys[0], S->keys[1], S->vals[0], S->vals[1], (int)n, 0, end_bit, s));
@@ -432,11 +459,22 @@ hipError_t voxel_filter_dev(locgpu_ctx* ctx, const locgpu_cloud* in, float leaf,
     uint32_t* start = S->keys[0];  // free again after the sort; capacity ≥ n + 1 (ensure_scratch above)
     hipLaunchKernelGGL(voxel_starts_kernel, dim3(blocks_for(n)), dim3(kFB), 0, s, S->keys[1], S->head, S->rank, n, dense, start, S->d_params);
     LOCGPU_TRY(hipGetLastError());
+    if (one_readback) {
+        LOCGPU_TRY(ensure_tmp(ctx, n));
+        hipLaunchKernelGGL(voxel_centroid_kernel, dim3(blocks_for(n)), dim3(kFB), 0, s, in->d, S->vals[1], start, 0u, S->d_tmp, S->d_params);
+        LOCGPU_TRY(hipGetLastError());
+        LOCGPU_TRY(read_params(ctx));
+        const VoxelParams hp = *S->h_params;
+        if (hp.status == 2) { *status = 2; out->n = 0; out->is_dense = 1; return hipSuccess; }
+        if (hp.status == 1) { *status = 1; return copy_through(ctx, in, out); }  // "Leaf size is too small…": output = *input_
+        swap_in(ctx, out, hp.n_out, 1);  // applyFilter: output.is_dense = true
+        return hipSuccess;
+    }
     LOCGPU_TRY(read_params(ctx));
     const uint32_t n_voxels = S->h_params->n_out;
     LOCGPU_TRY(ensure_tmp(ctx, n_voxels));
     if (n_voxels)
-        hipLaunchKernelGGL(voxel_centroid_kernel, dim3(blocks_for(n_voxels)), dim3(kFB), 0, s, in->d, S->vals[1], start, n_voxels, S->d_tmp);
+        hipLaunchKernelGGL(voxel_centroid_kernel, dim3(blocks_for(n_voxels)), dim3(kFB), 0, s, in->d, S->vals[1], start, n_voxels, S->d_tmp, (const VoxelParams*)nullptr);
     LOCGPU_TRY(hipGetLastError());
     swap_in(ctx, out, S->h_params->n_out, 1);  // applyFilter: output.is_dense = true
     return hipSuccess;

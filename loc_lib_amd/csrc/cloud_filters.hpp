@@ -41,12 +41,15 @@ struct FilterScratch {
     float4* d_tmp = nullptr;          // staging for in-place filters
     size_t tmp_cap = 0;
     float4* h_stage = nullptr;        // pinned host staging for upload/download
+    hipEvent_t stage_ev = nullptr;  // recorded behind an upload's H2D: the staging buffer is free again once it has fired
+    bool stage_busy = false;
     size_t stage_cap = 0;
 };
 
 void filters_free(locgpu_ctx* ctx);
 hipError_t cloud_reserve(locgpu_cloud* c, size_t n, bool keep);
-hipError_t cloud_stage(locgpu_ctx* ctx, size_t n, float4** out);  // pinned staging of at least n points
+hipError_t cloud_stage(locgpu_ctx* ctx, size_t n, float4** out);
+hipError_t cloud_stage_release(locgpu_ctx* ctx);  // pinned staging of at least n points
 
 // All run on ctx->stream and return after the result size is known (one small D2H + sync each).
 // `out` may alias `in`'s owner (in-place): results are produced in scratch and swapped in.

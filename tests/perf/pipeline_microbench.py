@@ -111,8 +111,9 @@ def stream_section(ctx, locref, n_scans, kf_every, num_kfs, scan_leaf, map_leaf,
         raw.upload(scan, is_dense=False)
         stage["upload"] += clock() - t
         t = clock()
-        raw.remove_nan(out=filt)
-        filt.voxel_filter(scan_leaf, out=filt)
+        # RemoveNanPoint + VoxelFilter::Filter (lio.cpp:236): pcl::VoxelGrid skips the non-finite points of a non-dense cloud itself, so
+        # the filter applied to the raw scan gives the cloud of the two calls (tests/test_gpu_filters.py) with one host read-back
+        raw.voxel_filter(scan_leaf, out=filt)
         stage["filter"] += clock() - t
         if s == 0:
             pose, kf_src, kf_dense = truth, filt, True  # first frame (lio.cpp:238-256): the FILTERED scan at last_kf_pose_ seeds the map
@@ -154,6 +155,7 @@ def main():
     ap.add_argument("--map-leaf", type=float, default=0.5)
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--only", choices=["filters", "stream"])
+    ap.add_argument("--graph", action="store_true", help="stream section: replay the captured hipGraph of the Gauss–Newton iterations (BASELINE configs[4])")
     a = ap.parse_args()
     from oracle import locref  # timed CPU baseline and checker only
     api.build()
@@ -161,11 +163,16 @@ def main():
     if a.only != "stream":
         print(json.dumps({"filters": filters_section(ctx, locref, a.map_points, a.reps)}))
     if a.only != "filters":
-        # a host-latency-bound loop on a shared box: the fastest of three passes is the least disturbed one
-        runs = [stream_section(ctx, locref, a.scans, a.kf_every, a.num_kfs, a.scan_leaf, a.map_leaf, not a.no_check) for _ in range(3)]
-        best = max(runs, key=lambda r: r["scans_per_s"])
-        best["scans_per_s_all_passes"] = [round(r["scans_per_s"], 1) for r in runs]
-        print(json.dumps({"stream": best}))
+        ctx.graph_enable(a.graph)
+        # a host-latency-bound loop on a shared box: five passes, the MEDIAN is reported and every pass is kept
+        runs = [stream_section(ctx, locref, a.scans, a.kf_every, a.num_kfs, a.scan_leaf, a.map_leaf, not a.no_check and i == 0) for i in range(5)]
+        ranked = sorted(runs, key=lambda r: r["scans_per_s"])
+        mid = ranked[len(ranked) // 2]
+        mid["scans_per_s_all_passes"] = [round(r["scans_per_s"], 1) for r in runs]
+        mid["checked_against_oracle"] = runs[0]["checked_against_oracle"]  # the first pass carries the oracle check
+        mid["max_pose_abs_diff"] = runs[0]["max_pose_abs_diff"]
+        mid["reported"] = "median of 5 passes"
+        print(json.dumps({"stream": mid}))
     ctx.close()
 
 

@@ -280,3 +280,29 @@ def test_golden_filter_fixture_gpu(gpu_ctx, api):
         assert np.array_equal(sub.cloud().download(), g["local_map_%d" % s])
     edge, surf = api.Cloud(gpu_ctx, g["loam_cloud"]).loam_extract(g["loam_ring"], 16)
     assert np.array_equal(edge.download(), g["loam_edge"]) and np.array_equal(surf.download(), g["loam_surf"])
+
+
+def test_voxel_filter_of_a_non_dense_cloud_equals_remove_nan_then_filter(gpu_ctx, api, locref):
+    """The per-scan path of the front-ends (RemoveNanPoint, then VoxelFilter::Filter; lio.cpp:236) as ONE call: pcl::VoxelGrid skips
+    non-finite points of a cloud that is not flagged dense, in getMinMax3D and in its key pass alike, so filtering the raw scan gives
+    the same cloud bit for bit — with one host read-back (scan-sized clouds) instead of three. Also the two rare outcomes that are
+    now detected after the fact: no finite point at all, and a leaf so small that PCL passes the input through."""
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-40, 40, size=(60000, 4)).astype(np.float32)
+    bad = rng.choice(len(pts), 900, replace=False)
+    pts[bad[:300], 0] = np.nan
+    pts[bad[300:600], 2] = np.inf
+    pts[bad[600:], 1] = -np.inf
+    raw = api.Cloud(gpu_ctx, pts, is_dense=False)
+    one = raw.voxel_filter(0.5)
+    two = raw.remove_nan().voxel_filter(0.5)
+    assert np.array_equal(one.download(), two.download()) and one.is_dense
+    want = locref.voxel_grid(locref.remove_nan(pts, False), True, 0.5, order=locref.SORT_STABLE)
+    assert np.array_equal(one.download(), want)
+    empty = api.Cloud(gpu_ctx, np.full((100, 4), np.nan, np.float32), is_dense=False).voxel_filter(0.5)
+    assert len(empty) == 0
+    wide = np.zeros((4, 4), np.float32)
+    wide[1, :3] = 3.0e5
+    wide[2, :3] = -3.0e5
+    through = api.Cloud(gpu_ctx, wide, is_dense=True).voxel_filter(0.01)  # 6e7 cells per axis: "leaf size is too small"
+    assert np.array_equal(through.download(), wide)
