@@ -359,7 +359,7 @@ def main():
         t_accum = prof["accum_ms"] * prof["accum_n"] / args.steps
         t_solve = prof["solve_ms"] * prof["solve_n"] / args.steps
         if t_search >= t_accum:
-            kname, kbytes, kt, kn, kavg = ("icp_search_grid_kernel(+pass2+redo)" if args.search == "grid" else "icp_search_fast_kernel(+redo)"), search_bytes, t_search, prof["search_n"], prof["search_ms"]
+            kname, kbytes, kt, kn, kavg = ("icp_search_grid_kernel(+pass2+redo)" if args.search == "grid" else "icp_search_walk_kernel(+deep pass+redo)"), search_bytes, t_search, prof["search_n"], prof["search_ms"]
         else:
             kname, kbytes, kt, kn, kavg = ("ndt_accum_kernel" if method < 0 else "icp_%s_accum_kernel" % args.method), accum_bytes, t_accum, prof["accum_n"], prof["accum_ms"]
         launches_per_step = kn / args.steps

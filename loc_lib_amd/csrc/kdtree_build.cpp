@@ -16,6 +16,8 @@
 // A 16-byte load at a leaf's slot therefore returns the whole point.
 #include "kdtree_build.hpp"
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -124,9 +126,31 @@ struct Piece {  // a node of the level-parallel top of the tree, or a deferred s
 
 // A small persistent pool: target ingest is called once per keyframe by the streaming front-end (≈35 k points), where spawning
 // threads per call would cost more than the build. run(n, fn) calls fn(i) for i in [0, n) on the pool and the caller's thread.
+// Threads the pool may have: the host's, capped at 48, divided by the ranks that share the host when the process was started by
+// a launcher (LOCAL_WORLD_SIZE / WORLD_SIZE: eight ranks must not spin 8 × 47 idle threads), or LOCGPU_BUILD_THREADS.
+inline unsigned pool_thread_budget() {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 48) nt = 48;
+    const char* lw = std::getenv("LOCAL_WORLD_SIZE");
+    if (!lw) lw = std::getenv("WORLD_SIZE");
+    const int ranks = lw ? std::atoi(lw) : 1;
+    if (ranks > 1) nt = std::max(2u, nt / (unsigned)ranks);
+    if (const char* e = std::getenv("LOCGPU_BUILD_THREADS")) { const int v = std::atoi(e); if (v >= 1) nt = (unsigned)std::min(v, 256); }
+    return nt;
+}
+
 class Pool {
 public:
-    static Pool& get() { static Pool p; return p; }
+    // A forked child (Python multiprocessing after an ingest in the parent) inherits the object but none of its threads: a pool
+    // that belongs to another process is abandoned — its mutexes may have been held at the fork — and a fresh one is built.
+    static Pool& get() {
+        static std::mutex mu;
+        static Pool* p = nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!p || p->pid_ != ::getpid()) p = new Pool();
+        return *p;
+    }
     unsigned size() const { return (unsigned)workers_.size() + 1; }
     // fn(i) for i in [0, n) on the caller's thread and at most max_threads − 1 pool threads. Only as many workers as can be useful
     // are woken: waking (and waiting for) every thread of a 256-thread host costs more than a 35 k-point build.
@@ -148,10 +172,8 @@ public:
     }
 
 private:
-    Pool() {
-        unsigned nt = std::thread::hardware_concurrency();
-        if (nt == 0) nt = 4;
-        if (nt > 48) nt = 48;
+    Pool() : pid_(::getpid()) {
+        const unsigned nt = pool_thread_budget();
         for (unsigned t = 1; t < nt; ++t) workers_.emplace_back([this] { loop(); });
     }
     ~Pool() {
@@ -175,6 +197,7 @@ private:
             if (--pending_ == 0) done_cv_.notify_one();
         }
     }
+    const pid_t pid_;
     std::vector<std::thread> workers_;
     std::mutex mu_, run_mu_;
     std::condition_variable cv_, done_cv_;

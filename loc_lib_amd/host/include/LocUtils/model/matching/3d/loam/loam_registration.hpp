@@ -11,6 +11,7 @@
 #include "LocUtils/model/feature_extract/loam_feature_extract.hpp"  // LoamFeatureOptions
 
 struct locgpu_ctx;
+struct locgpu_batch;
 
 namespace LocUtils {
 
@@ -46,6 +47,10 @@ private:
     LoamOption options_;
     locgpu_ctx* edge_ctx_ = nullptr;  // icp_edge_ptr_ (P2Line)
     locgpu_ctx* surf_ctx_ = nullptr;  // icp_surf_ptr_ (P2Plane)
+    // one-scan source batches, kept across ScanMatch calls (device buffers of a batch are a dozen hipMalloc/hipFree pairs)
+    locgpu_batch* edge_batch_ = nullptr;
+    locgpu_batch* surf_batch_ = nullptr;
+    size_t edge_cap_ = 0, surf_cap_ = 0;
     int device_id_ = 0;
     bool has_edge_ = false, has_surf_ = false;
 };

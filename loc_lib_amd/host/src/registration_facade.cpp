@@ -135,7 +135,12 @@ float NdtRegistration::GetFitnessScore() { return 0.0f; }  // ndt_registration.c
 // ------------------------------------------------------------------------------------------------ LOAM
 LoamRegistration::LoamRegistration() {}
 LoamRegistration::LoamRegistration(LoamOption option) : options_(option) {}
-LoamRegistration::~LoamRegistration() { locgpu_destroy(edge_ctx_); locgpu_destroy(surf_ctx_); }
+LoamRegistration::~LoamRegistration() {
+    locgpu_batch_destroy(edge_batch_);
+    locgpu_batch_destroy(surf_batch_);
+    locgpu_destroy(edge_ctx_);
+    locgpu_destroy(surf_ctx_);
+}
 void LoamRegistration::SetDevice(int device_id) { device_id_ = device_id; }
 float LoamRegistration::GetFitnessScore() { return 0.0f; }  // loam_registration.cpp:101-104
 
@@ -152,9 +157,9 @@ bool LoamRegistration::ScanMatch(const CloudPtr& edge_input, const CloudPtr& sur
     // Sources stay resident for the whole loop; each iteration = one H/B evaluation per feature class (loam_registration.cpp:53-71),
     // the sum H = H_edge + H_surf, B = B_edge + B_surf (:76-77), dx = H⁻¹·B with NO effective-count or determinant test (:79),
     // update, stop at |dx| < eps_ (:85). A failed sub-evaluation aborts with `return false` before result_pose is written (:56-70).
-    struct Side { locgpu_ctx* ctx; locgpu_batch* batch; locgpu_icp_opts opts; bool use; };
-    Side sides[2] = {{surf_ctx_, nullptr, to_c(options_.surf_icp_option_), options_.use_surf_points_},
-                     {edge_ctx_, nullptr, to_c(options_.edge_icp_option_), options_.use_edge_points_}};
+    struct Side { locgpu_ctx* ctx; locgpu_batch** batch; size_t* cap; locgpu_icp_opts opts; bool use; };
+    Side sides[2] = {{surf_ctx_, &surf_batch_, &surf_cap_, to_c(options_.surf_icp_option_), options_.use_surf_points_},
+                     {edge_ctx_, &edge_batch_, &edge_cap_, to_c(options_.edge_icp_option_), options_.use_edge_points_}};
     const CloudPtr* inputs[2] = {&surf_input, &edge_input};
     const bool have[2] = {has_surf_, has_edge_};
     bool ok = true;
@@ -163,7 +168,15 @@ bool LoamRegistration::ScanMatch(const CloudPtr& edge_input, const CloudPtr& sur
         if (!have[i] || !*inputs[i] || (*inputs[i])->points.empty()) { ok = false; break; }
         const void* src[1] = {(*inputs[i])->points.data()};
         const size_t cnt[1] = {(*inputs[i])->points.size()};
-        ok = locgpu_batch_create(sides[i].ctx, src, cnt, sizeof(PointType), 1, &sides[i].batch) == LOCGPU_OK;
+        // the batch of the previous call is reused (deep copy of the new source into its buffers); it only grows
+        if (!*sides[i].batch || *sides[i].cap < cnt[0]) {
+            locgpu_batch_destroy(*sides[i].batch);
+            *sides[i].batch = nullptr;
+            *sides[i].cap = cnt[0] + cnt[0] / 4 + 1024;
+            ok = locgpu_batch_create_empty(sides[i].ctx, 1, *sides[i].cap, sides[i].batch) == LOCGPU_OK;
+        }
+        ok = ok && locgpu_batch_upload_async(*sides[i].batch, src, cnt, sizeof(PointType)) == LOCGPU_OK &&
+             locgpu_batch_upload_wait(*sides[i].batch) == LOCGPU_OK;
     }
     SE3 pose = predict_pose;
     for (int iter = 0; ok && iter < options_.max_iteration_; ++iter) {
@@ -171,7 +184,7 @@ bool LoamRegistration::ScanMatch(const CloudPtr& edge_input, const CloudPtr& sur
         for (int i = 0; i < 2 && ok; ++i) {
             if (!sides[i].use) continue;
             double hb[44];
-            ok = locgpu_icp_hb_batch(sides[i].ctx, sides[i].batch, pose.data(), &sides[i].opts, hb) == LOCGPU_OK && hb[43] != 0.0;
+            ok = locgpu_icp_hb_batch(sides[i].ctx, *sides[i].batch, pose.data(), &sides[i].opts, hb) == LOCGPU_OK && hb[43] != 0.0;
             for (int k = 0; k < 42; ++k) sum[k] += hb[k];
         }
         if (!ok) break;
@@ -181,7 +194,6 @@ bool LoamRegistration::ScanMatch(const CloudPtr& edge_input, const CloudPtr& sur
         locgpu_gn_update(sum, LOCGPU_P2PLANE, 0, options_.eps_, pose.data(), dx, &applied, &stop);
         if (stop) break;
     }
-    for (auto& sd : sides) locgpu_batch_destroy(sd.batch);
     if (!ok) return false;
     result_pose = pose;
     // *cloud += *edge; *cloud += *surf; transformPointCloud (loam_registration.cpp:93-96)

@@ -203,3 +203,27 @@ def test_host_ingest_is_clean_under_asan_ubsan(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "asan harness ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_host_tree_build_pool_under_thread_sanitizer(tmp_path):
+    """the persistent pool of the host tree build (kdtree_build.cpp) with four concurrent callers — what two
+    contexts ingesting at once amount to — under ThreadSanitizer, every result equal to the single-caller build; then a forked
+    child builds with a pool of its own (the parent's threads do not exist there). GPU sanitizers do not exist on this
+    pool, the host side is where the threads are."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    csrc = os.path.join(ROOT, "loc_lib_amd", "csrc")
+    exe = str(tmp_path / "host_build_tsan")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-I", csrc,
+           os.path.join(ROOT, "tests", "cpp", "host_build_tsan.cpp"), os.path.join(csrc, "kdtree_build.cpp"), "-o", exe, "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and ("sanitize" in r.stderr or "tsan" in r.stderr):
+        pytest.skip("ThreadSanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1 die_after_fork=0", LOCGPU_BUILD_THREADS="6")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    if r.returncode != 0 and "unexpected memory mapping" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
+    assert r.returncode == 0 and "tsan harness ok" in r.stdout, r.stdout[-1000:] + r.stderr[-4000:]
