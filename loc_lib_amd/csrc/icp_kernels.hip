@@ -141,19 +141,21 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
 // K1, round 3: the traversal of search_walk.hpp. One-wave workgroups; dynamic LDS = DF rows x 64 lanes x 8 B (the stack is the
 // ONLY LDS of the kernel: a row below its bottom must lie outside the allocation). `dummy` = slot of the sentinel leaf.
 // Every lane of the wave must call walk_query (wave-wide ballots inside); a lane without a query passes valid = false.
-template <int K, int ROWB, int MODE>  // MODE 0: flat trips, 2: rounds
-__device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, bool valid, float alpha_eff, int T, uint32_t dummy, uint32_t col_addr) {
+template <int K, int ROWB, int MODE>  // MODE 0: flat trips, 2: rounds, 12..14: rounds capped at 2..4 internal steps
+__device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const uint2* __restrict__ tree, Walk<K>& w, bool valid, float alpha_eff, int T, uint32_t dummy,
+                                           uint32_t col_addr) {
 #pragma unroll
     for (int j = 0; j < K; ++j) { w.d[j] = __builtin_inff(); w.id[j] = kInvalidSlot; }
     w.slow = 0;
     // finite-arithmetic precondition of the traversal (the tree is `bounded`): anything else goes to the exact kernel
     const bool sane = fabsf(w.qx) < 1e18f && fabsf(w.qy) < 1e18f && fabsf(w.qz) < 1e18f;
     if (valid && sane) {
-        walk_descend<K, ROWB>(rsrc, w, T, col_addr);
+        walk_descend<K, ROWB>(rsrc, tree, w, T, col_addr);
     } else {
         w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = valid ? 1u : 0u;
     }
     if (MODE == 2) walk_rounds<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr);
+    else if (MODE >= 12 && MODE <= 14) walk_rounds_capped<K, ROWB, MODE - 10>(rsrc, w, alpha_eff, dummy, col_addr);
     else do walk_trip<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr); while (__ballot(w.cur != dummy || w.avail > 0) != 0ull);
 #pragma unroll
     for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;  // equal distances in the final set: heap pop order is layout-dependent
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
     Walk<K> w;
     w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
-    walk_query<K, ROWB, MODE>(rsrc, w, true, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]));
+    walk_query<K, ROWB, MODE>(rsrc, tree, w, true, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]));
     const bool deep = w.c3n == 1u;
     const bool slow = !deep && w.slow != 0u;
     if (!deep && !slow) {
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* _
             const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
             w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
         }
-        walk_query<K, ROWB, 2>(rsrc, w, valid, alpha_eff, 0, dummy, (uint32_t)(size_t)(&s_dyn[tid]));
+        walk_query<K, ROWB, 12>(rsrc, tree, w, valid, alpha_eff, 0, dummy, (uint32_t)(size_t)(&s_dyn[tid]));
         const bool slow = valid && w.slow != 0u;
         if (valid && !slow) {
 #pragma unroll
@@ -877,12 +879,12 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         // two candidates go through a.redo_list2 to the deep pass (every level stored), ties to the exact redo kernel as before.
         const uint32_t dummy = (uint32_t)(a.tree_bytes / 8);
         static const int wpad = [] { const char* e = getenv("LOCGPU_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiment: extra dynamic LDS lowers occupancy
-        static const int mode = [] { const char* e = getenv("LOCGPU_WALK_MODE"); return e ? atoi(e) : 2; }();
+        static const int mode = [] { const char* e = getenv("LOCGPU_WALK_MODE"); return e ? atoi(e) : 12; }();
         static const int small = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); return e ? atoi(e) : 16; }();
-        if ((size_t)((a.max_n + 63) / 64) * a.n_scans <= 2048 && small == 16 && mode == 2) {
+        if ((size_t)((a.max_n + 63) / 64) * a.n_scans <= 2048 && small == 16) {
             // fewer than 2048 full waves (one or two scans): quarter-filled waves with every level stored — no deep pass
             dim3 g1((a.max_n + 15) / 16, a.n_scans);
-            hipLaunchKernelGGL((icp_search_walk_kernel<K, D + 2, 2, 16>), g1, dim3(64), (D + 2) * 16 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+            hipLaunchKernelGGL((icp_search_walk_kernel<K, D + 2, 12, 16>), g1, dim3(64), (D + 2) * 16 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                                a.alpha_eff, 0, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
                                a.search_stats);
             hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
@@ -895,6 +897,9 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
                                                  a.max_n, a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count,       \
                                                  a.redo_list2, a.redo_count2, a.search_stats)
         if (mode == 2) LOCGPU_WALK_LAUNCH(2);
+        else if (mode == 12) LOCGPU_WALK_LAUNCH(12);
+        else if (mode == 13) LOCGPU_WALK_LAUNCH(13);
+        else if (mode == 14) LOCGPU_WALK_LAUNCH(14);
         else LOCGPU_WALK_LAUNCH(0);
 #undef LOCGPU_WALK_LAUNCH
         hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(1024), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,

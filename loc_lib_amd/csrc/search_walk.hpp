@@ -55,13 +55,45 @@ __device__ __forceinline__ lds_u32* lds_ptr(uint32_t byte_addr) { return reinter
 // Every lane still in the loop is on the same level (one level per trip from the root), so "is this level stored" is a scalar
 // question: two loops — candidates only, then stores only — instead of one body that carries both (the kernel is VALU-bound).
 template <int K, int ROWB>
-__device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, int T, uint32_t col_addr) {
+__device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, const uint2* __restrict__ tree, Walk<K>& w, int T, uint32_t col_addr) {
     float c1 = __builtin_inff(), c2 = __builtin_inff(), c3 = __builtin_inff();
     uint32_t f1 = 0, f2 = 0, c1_younger = 0;
     uint32_t cur = 0;
     const float qx = w.qx, qy = w.qy, qz = w.qz;  // values, not lvalues: `c ? w.qx : w.qy` is a select of ADDRESSES and pins w in scratch
     bool at_leaf = false;
-    for (int l = 0; l < T; ++l) {  // un-stored levels: sorted insertion of d² into (c1 ≤ c2 ≤ c3), far slots of the first two
+    int l = 0;
+    // The lanes of a wave are neighbours on a scan ring: they share the top ≈10–14 levels of the tree. While every lane takes the
+    // same turn, the node is read ONCE with a scalar load and its axis, threshold and children are wave-uniform — per lane only
+    // d² and the candidate update remain (the kernel is VALU-bound, the scalar unit idles).
+    {
+        uint32_t cur_s = 0;
+        for (; l < T; ++l) {
+            const uint2 hd = tree[__builtin_amdgcn_readfirstlane(cur_s)];
+            const uint32_t meta = __builtin_amdgcn_readfirstlane(hd.y);
+            if (meta >= 0xC0000000u) break;  // a leaf above level T: the per-lane loop below sees it
+            const float th = as_f32(__builtin_amdgcn_readfirstlane(hd.x));
+            const float qa = meta < 0x40000000u ? qx : (meta < 0x80000000u ? qy : qz);
+            const bool go_left = qa < th;
+            const unsigned long long m = __ballot(go_left);
+            if (m != 0ull && m != __ballot(true)) break;  // the lanes part here: this level is handled per lane
+            const uint32_t right = meta & 0x3FFFFFFFu, cur1 = cur_s + 1u;
+            const uint32_t far_slot = m != 0ull ? right : cur1;
+            const float dd = qa - th;
+            const float d2 = dd * dd;
+            const bool lt1 = d2 < c1, lt2 = d2 < c2;
+            c3 = __builtin_amdgcn_fmed3f(c2, d2, c3);
+            c2 = __builtin_amdgcn_fmed3f(c1, d2, c2);
+            c1 = __builtin_fminf(c1, d2);
+            const uint32_t f2n = lt2 ? far_slot : f2;
+            f2 = lt1 ? f1 : f2n;
+            f1 = lt1 ? far_slot : f1;
+            const uint32_t yn = lt2 ? 0u : c1_younger;
+            c1_younger = lt1 ? 1u : yn;
+            cur_s = m != 0ull ? cur1 : right;
+        }
+        cur = cur_s;
+    }
+    for (; l < T; ++l) {  // un-stored levels: sorted insertion of d² into (c1 ≤ c2 ≤ c3), far slots of the first two
         const u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
         const uint32_t meta = n.y;
         if (meta >= 0xC0000000u) { at_leaf = true; break; }
@@ -286,6 +318,89 @@ __device__ __forceinline__ void walk_rounds(__amdgpu_buffer_rsrc_t rsrc, Walk<K>
             avail += (int)nd2 < nb ? 1 : 0;
             cur = go_left ? cur1 : right;
             n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
+        }
+    } while (__ballot(cur != dummy || avail > 0) != 0ull);
+#pragma unroll
+    for (int j = 0; j < K; ++j) { w.d[j] = d[j]; w.id[j] = id[j]; }
+    w.slow = slow; w.c3n = c3n; w.cur = cur; w.avail = avail;
+}
+
+// Capped rounds: like walk_rounds, but a round runs at most C internal steps; a lane that has not reached its leaf by then sits
+// out the next leaf stage (x = +inf, pop switched off) and keeps descending after it. Between the flat loop (C = 1, both blocks
+// every trip) and the rounds loop (C = ∞: every round waits for the wave's longest descent).
+template <int K, int ROWB, int C>
+__device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr) {
+    const float qx = w.qx, qy = w.qy, qz = w.qz;
+    uint32_t cur = w.cur;
+    int avail = w.avail;
+    float d[K];
+    uint32_t id[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { d[j] = w.d[j]; id[j] = w.id[j]; }
+    uint32_t slow = w.slow, c3n = w.c3n;
+    u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
+    do {
+        const bool is_leaf = n.y >= 0xC0000000u;
+        const uint32_t a4 = col_addr + (uint32_t)(avail - 4) * ROWB;
+        const u32x2 r3 = *reinterpret_cast<lds_u32x2*>(a4), r2 = *reinterpret_cast<lds_u32x2*>(a4 + ROWB),
+                    r1 = *reinterpret_cast<lds_u32x2*>(a4 + 2u * ROWB), r0 = *reinterpret_cast<lds_u32x2*>(a4 + 3u * ROWB);
+        const float dx = qx - as_f32(n.x), dy = qy - as_f32(n.z), dz = qz - as_f32(n.w);
+        const float dis2 = dx * dx + (dy * dy + dz * dz);
+        const float x = is_leaf ? dis2 : __builtin_inff();
+        bool c[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) c[j] = x < d[j];
+        if (K >= 2) {
+            const float gap = d[K - 1] - d[K - 2];
+            const float xt = gap == 0.0f ? x : __builtin_inff();
+            slow = xt < d[K - 1] ? 1u : slow;
+        }
+#pragma unroll
+        for (int j = K - 1; j >= 1; --j) {
+            const uint32_t below = id[j - 1], here = id[j];
+            const uint32_t t = c[j] ? cur : here;
+            id[j] = c[j - 1] ? below : t;
+            d[j] = __builtin_amdgcn_fmed3f(d[j - 1], x, d[j]);
+        }
+        {
+            const uint32_t here = id[0];
+            id[0] = c[0] ? cur : here;
+            d[0] = __builtin_fminf(d[0], x);
+        }
+        const int nbound = (int)__float_as_uint(-(d[K - 1] * alpha));
+        const int nb = is_leaf ? nbound : (int)0x80000000u;
+        int hit = 4;
+        uint32_t nxt = is_leaf ? dummy : cur;
+        hit = (int)r3.y < nb ? 3 : hit; nxt = (int)r3.y < nb ? r3.x : nxt;
+        hit = (int)r2.y < nb ? 2 : hit; nxt = (int)r2.y < nb ? r2.x : nxt;
+        hit = (int)r1.y < nb ? 1 : hit; nxt = (int)r1.y < nb ? r1.x : nxt;
+        hit = (int)r0.y < nb ? 0 : hit; nxt = (int)r0.y < nb ? r0.x : nxt;
+        const int avail_eff = is_leaf ? avail : 0;
+        const int used = min(min(hit + 1, 4), avail_eff);
+        const int low = avail_eff - 1 - min(hit, 3);
+        const uint32_t c3sel = low < 2 ? c3n : 0u;
+        c3n = (int)c3sel < nb ? 1u : c3n;
+        const bool moved = nxt != cur;
+        cur = nxt;
+        avail -= used;
+        // a lane that popped loads its new node; one that was not on a leaf still holds its internal node in n
+        if (moved) n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
+#pragma unroll
+        for (int step = 0; step < C; ++step) {
+            if (n.y < 0xC0000000u) {
+                const uint32_t meta = n.y;
+                const float th = as_f32(n.x);
+                const float qa = meta < 0x40000000u ? qx : (meta < 0x80000000u ? qy : qz);
+                const float dd = qa - th;
+                const uint32_t nd2 = __float_as_uint(-(dd * dd));
+                const uint32_t right = meta & 0x3FFFFFFFu;
+                const bool go_left = qa < th;
+                const uint32_t cur1 = cur + 1u;
+                *reinterpret_cast<lds_u32x2*>(col_addr + (uint32_t)avail * ROWB) = u32x2{go_left ? right : cur1, nd2};
+                avail += (int)nd2 < nbound ? 1 : 0;
+                cur = go_left ? cur1 : right;
+                n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
+            }
         }
     } while (__ballot(cur != dummy || avail > 0) != 0ull);
 #pragma unroll
