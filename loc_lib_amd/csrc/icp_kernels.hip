@@ -141,7 +141,7 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
 // K1, round 3: the traversal of search_walk.hpp. One-wave workgroups; dynamic LDS = DF rows x 64 lanes x 8 B (the stack is the
 // ONLY LDS of the kernel: a row below its bottom must lie outside the allocation). `dummy` = slot of the sentinel leaf.
 // Every lane of the wave must call walk_query (wave-wide ballots inside); a lane without a query passes valid = false.
-template <int K, int ROWB, int MODE>  // MODE 0: flat trips, 2: rounds, 12..14: rounds capped at 2..4 internal steps
+template <int K, int ROWB, int MODE>  // MODE 0: flat trips, 2: rounds, 12: rounds capped at two internal steps (default)
 __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const uint2* __restrict__ tree, Walk<K>& w, bool valid, float alpha_eff, int T, uint32_t dummy,
                                            uint32_t col_addr) {
 #pragma unroll
@@ -155,7 +155,7 @@ __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const ui
         w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = valid ? 1u : 0u;
     }
     if (MODE == 2) walk_rounds<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr);
-    else if (MODE >= 12 && MODE <= 14) walk_rounds_capped<K, ROWB, MODE - 10>(rsrc, w, alpha_eff, dummy, col_addr);
+    else if (MODE == 12) walk_rounds_capped<K, ROWB, 2>(rsrc, w, alpha_eff, dummy, col_addr);
     else do walk_trip<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr); while (__ballot(w.cur != dummy || w.avail > 0) != 0ull);
 #pragma unroll
     for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;  // equal distances in the final set: heap pop order is layout-dependent
@@ -847,13 +847,13 @@ static bool launch_search_k(const SearchArgs& a, hipStream_t s) {
 // un-stored entry that can still pass is expanded without a replay, the un-stored levels are cheap and the balance is between
 // occupancy and the (rare) paths deeper than DF that go to the exact traversal — measured on the bench workload (search ms per
 // 256-scan step): 12 → 30.0, 13 → 28.2, 14 → 26.2, 15 → 25.5, 16 → 27.2, 20 → 29.0, 24 → 35.9.
-// LOCGPU_FAST_STACK=12..16|20|24 and LOCGPU_FAST_BLOCK=128|256 select other shapes for experiments.
+// LOCGPU_FAST_STACK=12|24 selects other depths (parity tests); LOCGPU_FAST_BLOCK=128|256 other block shapes of the round-2 kernel.
 static int fast_stack_depth() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("LOCGPU_FAST_STACK");
         v = e ? atoi(e) : 15;
-        if (!((v >= 12 && v <= 16) || v == 20 || v == 24)) v = 15;
+        if (v != 12 && v != 24) v = 15;  // 12 and 24 exist for the parity tests at other stack depths
     }
     return v;
 }
@@ -898,8 +898,6 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
                                                  a.redo_list2, a.redo_count2, a.search_stats)
         if (mode == 2) LOCGPU_WALK_LAUNCH(2);
         else if (mode == 12) LOCGPU_WALK_LAUNCH(12);
-        else if (mode == 13) LOCGPU_WALK_LAUNCH(13);
-        else if (mode == 14) LOCGPU_WALK_LAUNCH(14);
         else LOCGPU_WALK_LAUNCH(0);
 #undef LOCGPU_WALK_LAUNCH
         hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(1024), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
@@ -934,10 +932,6 @@ template <int K, int D>
 static void launch_fast_d(const SearchArgs& a, hipStream_t s) {
     switch (fast_stack_depth()) {
         case 12: launch_fast_kd<K, D, 12>(a, s); break;
-        case 13: launch_fast_kd<K, D, 13>(a, s); break;
-        case 14: launch_fast_kd<K, D, 14>(a, s); break;
-        case 16: launch_fast_kd<K, D, 16>(a, s); break;
-        case 20: launch_fast_kd<K, D, 20>(a, s); break;
         case 24: launch_fast_kd<K, D, 24>(a, s); break;
         default: launch_fast_kd<K, D, 15>(a, s); break;
     }
