@@ -45,6 +45,9 @@ struct BatchUploadState {  // per batch
     int* h_counts = nullptr;    // pinned copy of the per-scan point counts
 };
 
+// n strided points (x, y, z as float32 at the start of each record) → float4 {x, y, z, 0}.
+void pack_points(const char* base, size_t stride, size_t n, float4* dst);
+
 // Starts packing + copying `srcs` into b's source array. Returns a locgpu_status; on LOCGPU_OK the work continues on a worker thread.
 int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts, size_t stride_bytes);
 // Waits until the context's worker has read every host cloud and enqueued every copy (of whatever batch it was working for);
