@@ -436,7 +436,7 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
     bool ok = hip_ok(ctx, hipMalloc((void**)&b->d_src, std::max<size_t>(b->pitch, 1) * sizeof(float4)), "hipMalloc src") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_counts, std::max(n_scans, 1) * sizeof(int)), "hipMalloc counts") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_state, n_total * sizeof(PoseState)), "hipMalloc state") &&
-              (!sharded || hip_ok(ctx, hipMalloc((void**)&b->d_acc, (size_t)n_total * kAccW * sizeof(double)), "hipMalloc acc")) &&
+              (!sharded || hip_ok(ctx, hipMalloc((void**)&b->d_acc, (size_t)kFirstChunk * n_total * kAccW * sizeof(double)), "hipMalloc acc")) &&  // one slot per iteration of a chunk
               hip_ok(ctx, hipMalloc((void**)&b->d_nn, 5 * std::max<size_t>(b->pitch, 1) * sizeof(uint32_t)), "hipMalloc nn") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_partials, (size_t)std::max(n_scans, 1) * b->blocks_per_scan * kAccW * sizeof(double)), "hipMalloc partials") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_hb, (size_t)n_total * 44 * sizeof(double)), "hipMalloc hb") &&
@@ -594,6 +594,8 @@ struct IterLauncher {
     // One GN iteration = search + accumulate + solve. Returns false on a launch error.
     bool ndt = false;
     bool capturing = false;  // inside hipStreamBeginCapture: no event records
+    int slot = 0;            // sharded batches: which of the chunk's exchange buffers this iteration uses
+    bool replicated_on_comm_stream = false;  // the chunk's read-back must wait for the communication stream as well
     bool launch(int do_update);
     void collect_profile();
 };
@@ -647,11 +649,38 @@ bool IterLauncher::launch(int do_update) {
         // The exchange step of the sharded mode: per scan 28 sums (21 H + 6 B + effective_num), zeros from the
         // ranks that do not hold the scan, summed over xGMI on this stream; then every rank solves every scan, so all ranks see the
         // same convergence flags and stay in lock-step.
-        launch_sum_partials(b->d_partials, n_partial_blocks, b->d_state, b->first, b->n_scans, b->n_total, b->d_acc, s);
+        double* acc = b->d_acc + (size_t)(slot % kFirstChunk) * b->n_total * kAccW;
+        slot++;
+        launch_sum_partials(b->d_partials, n_partial_blocks, b->d_state, b->first, b->n_scans, b->n_total, acc, s);
+        // Scan-sharded over several ranks: a scan's sums are complete on the rank that holds it (everybody else adds zeros), so the
+        // OWNER solves its scans at once and goes on to the next search, while the all-reduce — on the context's communication
+        // stream — only replicates: behind it every rank solves the scans it does not hold, from the reduced sums, and ends up with
+        // the same poses and flags as their owners. The network is off the Gauss–Newton loop's critical path; the host looks at the
+        // flags of ALL scans only between chunks (both streams joined), which keeps the ranks' collective counts in lock-step.
+        // Point-sharded batches (every rank holds a slice of every scan) and H/B evaluations need the sum itself: they wait.
+        static const int decouple_env = [] { const char* e = getenv("LOCGPU_SHARD_DECOUPLED"); return e ? atoi(e) : -1; }();
+        const bool scan_sharded = b->n_scans != b->n_total;
+        const bool decoupled = ctx->comm && do_update && scan_sharded && (decouple_env >= 0 ? decouple_env != 0 : ctx->comm_world > 1);
+        if (decoupled) {
+            hipStream_t cs = ctx->comm_stream;
+            if (b->n_scans > 0)
+                launch_gn_solve(acc + (size_t)b->first * kAccW, 1, b->d_state + b->first, b->n_scans, prm, do_update, b->d_hb + (size_t)b->first * 44,
+                                ndt ? nullptr : b->d_redo_count, s);
+            if (!hip_ok(ctx, hipEventRecord(b->ev_ready, s), "sharded: hipEventRecord") || !hip_ok(ctx, hipStreamWaitEvent(cs, b->ev_ready, 0), "sharded: hipStreamWaitEvent")) return false;
+            const ncclResult_t nr = rccl().AllReduce(acc, acc, (size_t)b->n_total * kAccW, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, cs);
+            if (nr != ncclSuccess) { fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr)); return false; }
+            const int after = b->first + b->n_scans;
+            if (b->first > 0) launch_gn_solve(acc, 1, b->d_state, b->first, prm, do_update, b->d_hb, nullptr, cs);
+            if (after < b->n_total)
+                launch_gn_solve(acc + (size_t)after * kAccW, 1, b->d_state + after, b->n_total - after, prm, do_update, b->d_hb + (size_t)after * 44, nullptr, cs);
+            replicated_on_comm_stream = true;
+            mark();
+            return hip_ok(ctx, hipGetLastError(), "kernel launch");
+        }
         if (ctx->comm) {
             // Every collective of the context goes through ONE stream in host order — the order is the same on every rank because
             // every rank sees the same convergence flags — so two batches in flight never have two collectives of the one
-            // communicator racing each other. Under stream capture the hand-over events become graph dependencies.
+            // communicator racing each other.
             // (A one-rank communicator has nobody to disagree with about the order: its collective stays on the batch's own stream —
             // 32 scans per step, two in flight: 8500 scans/s against 5700 through the comm stream, whose in-order queue makes the
             // second batch's first exchange wait for the first batch's whole chunk. LOCGPU_COMM_DIRECT=0/1 forces either way.)
@@ -659,11 +688,11 @@ bool IterLauncher::launch(int do_update) {
             const bool direct = force >= 0 ? force != 0 : ctx->comm_world == 1;
             hipStream_t cs = direct ? s : ctx->comm_stream;
             if (!direct && (!hip_ok(ctx, hipEventRecord(b->ev_ready, s), "sharded: hipEventRecord") || !hip_ok(ctx, hipStreamWaitEvent(cs, b->ev_ready, 0), "sharded: hipStreamWaitEvent"))) return false;
-            const ncclResult_t nr = rccl().AllReduce(b->d_acc, b->d_acc, (size_t)b->n_total * kAccW, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, cs);
+            const ncclResult_t nr = rccl().AllReduce(acc, acc, (size_t)b->n_total * kAccW, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, cs);
             if (nr != ncclSuccess) { fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr)); return false; }
             if (!direct && (!hip_ok(ctx, hipEventRecord(b->ev_reduced, cs), "sharded: hipEventRecord") || !hip_ok(ctx, hipStreamWaitEvent(s, b->ev_reduced, 0), "sharded: hipStreamWaitEvent"))) return false;
         }
-        launch_gn_solve(b->d_acc, 1, b->d_state, b->n_total, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s);
+        launch_gn_solve(acc, 1, b->d_state, b->n_total, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s);
     } else {
         launch_gn_solve(b->d_partials, n_partial_blocks, b->d_state, b->n_scans, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s);
     }
@@ -778,6 +807,10 @@ static int enqueue_chunk(locgpu_ctx* ctx, locgpu_batch* b, bool first_chunk) {
         if (!it.launch(1)) return LOCGPU_ERR_NO_DEVICE;
     P.ev_used = it.ev_used;
     P.launched += todo;
+    if (it.replicated_on_comm_stream) {  // the states of the scans other ranks hold are written on the communication stream
+        LOCGPU_HIP(ctx, hipEventRecord(b->ev_reduced, ctx->comm_stream));
+        LOCGPU_HIP(ctx, hipStreamWaitEvent(s, b->ev_reduced, 0));
+    }
     LOCGPU_HIP(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_total * sizeof(PoseState), hipMemcpyDeviceToHost, s));
     return LOCGPU_OK;
 }

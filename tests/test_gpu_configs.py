@@ -584,3 +584,49 @@ def test_upload_error_and_destroy_while_pending(gpu_ctx, api, small_world):
     assert np.array_equal(got[0], want)
     for x in many:
         x.close()
+
+
+def test_sharded_batches_with_the_owner_solving_ahead_of_the_exchange():
+    """With several ranks a scan-sharded batch lets the rank that holds a scan solve it at once and uses the all-reduce — on the
+    communication stream — only to replicate the other ranks' scans. One GPU cannot form a two-rank communicator, but
+    LOCGPU_SHARD_DECOUPLED=1 forces that path on the one-rank communicator: the sharded parity test above must pass unchanged (a
+    batch held completely, one held partially whose foreign scan is solved from the reduced zeros), and two partially held batches
+    in flight at once must give the poses of the blocking calls."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LOCGPU_SHARD_DECOUPLED="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_configs.py"), "-q", "-m", "gpu", "-x", "-k",
+                          "sharded_batch_over_rccl or decoupled_two_in_flight"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2500:] + out.stderr[-1000:]
+
+
+def test_decoupled_two_in_flight(api, small_world):
+    """Helper of the test above (also valid on the default path): two sharded batches begun back to back."""
+    from loc_lib_amd import multi_gpu
+    m = small_world["map"]
+    scans = [small_world["scan10k"], small_world["scan2k"], small_world["scan10k"][::3], small_world["scan10k"][::2]]
+    init = small_world["init_pose"]
+    inits = np.stack([init] * 4)
+    inits[2, 4:] += [0.03, 0.02, -0.01]
+    ctx = api.Context(0)
+    try:
+        multi_gpu.init_comm(ctx, None)
+        ctx.icp_set_target_bcast(m, root=0)
+        opts = api.icp_opts(method=api.P2PLANE)
+        plain = ctx.batch(scans)
+        want, wst = ctx.icp_align_batch(plain, inits, opts)
+        a = ctx.batch(scans[1:3], first=1, n_total=4)   # holds scans 1, 2
+        b = ctx.batch(scans[0:2], first=0, n_total=4)   # holds scans 0, 1
+        ctx.icp_align_batch_begin(a, inits, opts)
+        ctx.icp_align_batch_begin(b, inits, opts)
+        pa, sa = ctx.align_batch_end(a)
+        pb, sb = ctx.align_batch_end(b)
+        np.testing.assert_array_equal(pa[1:3], want[1:3])
+        np.testing.assert_array_equal(pb[0:2], want[0:2])
+        np.testing.assert_array_equal(pa[[0, 3]], inits[[0, 3]])  # nobody holds them in this one-rank world: no residuals
+        assert [s["iterations"] for s in sa[1:3]] == [s["iterations"] for s in wst[1:3]] and sa[0]["iterations"] == 20
+        plain.close(); a.close(); b.close()
+    finally:
+        ctx.close()
