@@ -81,13 +81,19 @@ def main():
     rows.append(row_from_bench("2: 115200-pt scans vs 1M-pt map, P2Plane (64 scans per step)", run_bench("--map-points", "1000000", "--scans-per-gpu", "64", "--traffic", "none", *steps)))
     rows.append(row_from_bench("3a: vs 10M-pt map, P2Plane (64 scans per step)", run_bench("--scans-per-gpu", "64", "--traffic", "none", *steps)))
     rows.append(row_from_bench("3b: vs 10M-pt map, direct NDT (64 scans per step)", run_bench("--scans-per-gpu", "64", "--method", "ndt", "--traffic", "none", *steps)))
-    rows.append(row_from_bench("4: 256 scans vs 10M-pt map, P2Plane, 1 GPU of the 8 (scan-sharded, no data-path collective)", run_bench(*steps)))
+    rows.append(row_from_bench("3c: vs 10M-pt map, P2Plane (32 scans per step: what one of eight ranks holds of configs[3])", run_bench("--scans-per-gpu", "32", "--traffic", "none", *steps)))
+    rows.append(row_from_bench("4: 256 scans vs 10M-pt map, P2Plane, one GPU (the default bench line)", run_bench(*steps)))
+    fast = ["--no-cpu-baseline", "--traffic", "none"]
+    rows.append(row_from_bench("4p: the same with two alignments in flight (--pipeline 2)", run_bench("--pipeline", "2", *fast, *steps)))
+    for n in (256, 64, 32):
+        rows.append(row_from_bench("4s: configs[3] as written on ONE rank: %d scans in all, sharded batch, RCCL all-reduce every iteration" % n,
+                                   run_bench("--scaling", "strong", "--total-scans", str(n), *fast, "--steps", str(max(10, 640 // n)), "--warmup", "2")))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "perf", "pipeline_microbench.py"), "--only", "stream"], capture_output=True, text=True, timeout=900)
     st = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])["stream"]
     rows.append(dict(config="5: streaming loop (upload, removeNaN, voxel filter, P2Plane vs local map, keyframe every 5th: submap + re-ingest)",
                      gpu_scans_s=st["scans_per_s"], ms_per_scan=st["ms_per_scan"], pose_delta_m=st["max_pose_abs_diff"], local_map_points=st["local_map_points"]))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
-    json.dump(dict(rows=rows, host_cores=os.cpu_count()), open(a.out, "w"), indent=1)
+    json.dump(dict(rows=rows, host_threads=os.cpu_count(), usable_cores=len(os.sched_getaffinity(0))), open(a.out, "w"), indent=1)
     print("| config | CPU R1 scans/s (1 thread) | CPU R2 scans/s (1 thread) | CPU R3 scans/s (cores) | GPU×1 scans/s | GPU ms per scan-iteration | search roofline frac (algorithmic / HBM traffic) | pose Δ vs oracle [m] |")
     print("|---|---|---|---|---|---|---|---|")
     f = lambda v, p="%.3g": "—" if v is None else p % v
