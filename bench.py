@@ -264,6 +264,7 @@ def main():
         return ctx.ndt_align_batch(b, inits) if method < 0 else ctx.icp_align_batch(b, inits, opts)
 
     g_step = [0]  # steps begun since the start of the process (selects the batch)
+    debug_times = [] if os.environ.get("LOCGPU_BENCH_DEBUG") else None  # host seconds per step: (upload_async call, align begin call)
 
     def begin_step():
         """Start one pass of the hot path over one batch. Streaming (default): first start the host → HBM copy of the NEXT step's
@@ -272,12 +273,16 @@ def main():
         g = g_step[0]
         g_step[0] += 1
         b = bufs[g % len(bufs)]
+        t_a = time.perf_counter()
         if not args.resident:
             bufs[(g + 1) % len(bufs)].upload_async(scans_c)
+        t_b = time.perf_counter()
         if method < 0:
             ctx.ndt_align_batch_begin(b, inits)
         else:
             ctx.icp_align_batch_begin(b, inits, opts)
+        if debug_times is not None:
+            debug_times.append((t_b - t_a, time.perf_counter() - t_b))
         return b
 
     def run_steps(n):
@@ -316,6 +321,8 @@ def main():
     out_poses, stats = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    if debug_times is not None:
+        sys.stderr.write("host ms per step (upload_async, begin): %s\n" % [(round(1e3 * a, 2), round(1e3 * b, 2)) for a, b in debug_times[-args.steps:]])
     ctx.profile_enable(False)
     prof = ctx.profile_read(reset=True)
     for b in bufs:

@@ -3,6 +3,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #if defined(__SSE2__)
 #include <emmintrin.h>
@@ -44,8 +47,7 @@ void release_resources(Uploader& u) {
     for (float4* p : u.h_slots) if (p) (void)hipHostFree(p);
     for (hipEvent_t e : u.slot_ev) if (e) (void)hipEventDestroy(e);
     u.h_slots.clear(); u.slot_ev.clear(); u.slot_busy.clear();
-    if (u.stream) (void)hipStreamDestroy(u.stream);
-    u.stream = nullptr;
+    u.stream = nullptr;  // the stream belongs to the context
 }
 
 // Copy stream + at least `want_slots` pinned slots (capped by the thread count). All or nothing: on a failure everything that
@@ -55,7 +57,7 @@ bool ensure_resources(locgpu_ctx* ctx, size_t want_slots) {
     if (!u.stream) {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         u.n_threads = (int)std::min<unsigned>(8u, std::max(2u, hw / 4));
-        if (!hip_ok(ctx, hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking), "upload: hipStreamCreate")) { u.stream = nullptr; return false; }
+        u.stream = ctx->copy_stream;  // created with the context (see locgpu_create)
     }
     const size_t cap = (size_t)u.n_threads * Uploader::kSlotsPerThread;
     const size_t want = std::min(cap, std::max<size_t>(1, want_slots));
@@ -78,13 +80,21 @@ bool ensure_resources(locgpu_ctx* ctx, size_t want_slots) {
 void run_upload(locgpu_ctx* ctx) {
     Uploader& u = *ctx->up;
     locgpu_batch* b = u.current;
+    const auto t_entry = std::chrono::steady_clock::now();
     (void)hipSetDevice(ctx->device);
+    if (getenv("LOCGPU_UPLOAD_DEBUG"))
+        fprintf(stderr, "[upload worker] started %.2f ms after upload_start, hipSetDevice took %.2f ms\n",
+                std::chrono::duration<double, std::milli>(t_entry - u.t_start).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
     // work units: every scan in slot-sized pieces
     std::vector<Unit> units;
     for (int s = 0; s < b->n_scans; ++s)
         for (size_t o = 0; o < u.counts[s]; o += Uploader::kSlotPoints) units.push_back({s, o, std::min(Uploader::kSlotPoints, u.counts[s] - o)});
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
+    static const bool dbg = getenv("LOCGPU_UPLOAD_DEBUG") != nullptr;
+    std::atomic<long long> wait_us{0}, pack_us{0};
+    const auto t_begin = std::chrono::steady_clock::now();
     const int n_slots = (int)u.h_slots.size();
     const int nt = (int)std::min<size_t>(std::min<size_t>((size_t)u.n_threads, (size_t)std::max(1, n_slots)), std::max<size_t>(1, units.size()));
     auto packer = [&](int t) {
@@ -94,8 +104,14 @@ void run_upload(locgpu_ctx* ctx) {
         for (size_t i = next.fetch_add(1); i < units.size() && !failed.load(); i = next.fetch_add(1)) {
             const Unit& w = units[i];
             // the slot's previous copy — of this upload or of an earlier one — has left it
+            const auto ta = std::chrono::steady_clock::now();
             if (u.slot_busy[slot] && hipEventSynchronize(u.slot_ev[slot]) != hipSuccess) { failed = 1; break; }
+            const auto tb = std::chrono::steady_clock::now();
             pack_points((const char*)u.srcs[w.scan] + w.off * u.stride, u.stride, w.len, u.h_slots[slot]);
+            if (dbg) {
+                wait_us += std::chrono::duration_cast<std::chrono::microseconds>(tb - ta).count();
+                pack_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tb).count();
+            }
             if (hipMemcpyAsync(b->d_src + (size_t)w.scan * b->max_n + w.off, u.h_slots[slot], w.len * sizeof(float4), hipMemcpyHostToDevice, u.stream) != hipSuccess ||
                 hipEventRecord(u.slot_ev[slot], u.stream) != hipSuccess) { failed = 1; break; }
             u.slot_busy[slot] = 1;
@@ -106,6 +122,9 @@ void run_upload(locgpu_ctx* ctx) {
     for (int t = 1; t < nt; ++t) th.emplace_back(packer, t);
     packer(0);
     for (auto& t : th) t.join();
+    if (dbg)
+        fprintf(stderr, "[upload worker] %d threads, %zu pieces: %.2f ms wall, per thread %.2f ms waiting for slots + %.2f ms packing\n", nt, units.size(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), wait_us.load() / 1e3 / nt, pack_us.load() / 1e3 / nt);
     bool ok = !failed.load();
     for (int s = 0; s < b->n_scans; ++s) b->upl.h_counts[s] = (int)u.counts[s];
     ok = ok && hipMemcpyAsync(b->d_counts, b->upl.h_counts, (size_t)b->n_scans * sizeof(int), hipMemcpyHostToDevice, u.stream) == hipSuccess &&
@@ -124,8 +143,11 @@ int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts,
         if (counts[s] && !srcs[s]) return fail(ctx, LOCGPU_ERR_INVALID, "batch upload: NULL scan pointer");
         pieces += (counts[s] + Uploader::kSlotPoints - 1) / Uploader::kSlotPoints;
     }
+    static const bool dbg = getenv("LOCGPU_UPLOAD_DEBUG") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     const int jrc = upload_join(ctx);  // one upload per context at a time
     if (jrc != LOCGPU_OK) return jrc;
+    const auto t1 = std::chrono::steady_clock::now();
     if (!ctx->up) ctx->up = new Uploader();
     if (!ensure_resources(ctx, pieces)) return LOCGPU_ERR_OOM;
     Uploader& u = *ctx->up;
@@ -134,10 +156,18 @@ int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts,
     if (!st.h_counts && !hip_ok(ctx, hipHostMalloc((void**)&st.h_counts, (size_t)b->n_scans * sizeof(int)), "upload: hipHostMalloc counts")) { st.h_counts = nullptr; return LOCGPU_ERR_OOM; }
     // One upload of a batch at a time, end to end: the previous one's copies (same destination, same pinned counts) have landed.
     if (st.done_valid && !hip_ok(ctx, hipEventSynchronize(st.done), "batch upload: previous upload")) return LOCGPU_ERR_NO_DEVICE;
+    if (dbg) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[upload] join %.2f ms, previous upload of this batch landed %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
     // The previous contents of the source array may still be read by kernels enqueued on the batch's compute stream (an alignment
     // that was begun and not yet finished): order the copies behind them.
+    // (Only then: every finished alignment ends with its stream synchronised, and an idle stream needs no ordering — an event
+    // recorded on it can still inherit waits a library queued there: with an RCCL communicator on the context, uploads into every
+    // second batch started ≈12 ms late.)
     hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+    if (b->pending.active && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
         (void)hipEventRecord(ev, b->stream);
         (void)hipStreamWaitEvent(u.stream, ev, 0);
         (void)hipEventDestroy(ev);
@@ -151,6 +181,7 @@ int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts,
     st.done_valid = true;
     u.current = b;
     u.worker_active = true;
+    u.t_start = std::chrono::steady_clock::now();
     u.worker = std::thread(run_upload, ctx);
     return LOCGPU_OK;
 }

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -37,6 +38,7 @@ struct Uploader {  // per context
     std::vector<const void*> srcs;
     std::vector<size_t> counts;
     size_t stride = 0;
+    std::chrono::steady_clock::time_point t_start;  // diagnostics (LOCGPU_UPLOAD_DEBUG)
 };
 
 struct BatchUploadState {  // per batch

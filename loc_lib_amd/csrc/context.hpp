@@ -23,6 +23,7 @@ struct locgpu_ctx {
     static constexpr int kSlots = 2;
     hipStream_t slot_stream[kSlots] = {nullptr, nullptr};
     int next_slot = 0;
+    hipStream_t copy_stream = nullptr;  // host → HBM copies of the batch uploader
     hipStream_t comm_stream = nullptr;  // every collective of the context, in host order (one communicator, one stream: no two at once)
     locgpu::Uploader* up = nullptr;     // host → HBM staging shared by the context's batches (batch_upload.hpp)
     std::string err;

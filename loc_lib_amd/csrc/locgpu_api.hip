@@ -172,8 +172,17 @@ int locgpu_create(int device_id, locgpu_ctx** out) {
     locgpu_ndt_opts_default(&ctx->ndt_opts);
     bool ok = hip_ok(nullptr, hipSetDevice(device_id), "hipSetDevice");
     for (int i = 0; ok && i < locgpu_ctx::kSlots; ++i) ok = hip_ok(nullptr, hipStreamCreateWithFlags(&ctx->slot_stream[i], hipStreamNonBlocking), "hipStreamCreate");
+    // The copy stream and the communication stream are created HERE, right behind the compute streams: HIP deals streams to its
+    // (four) hardware queues in creation order, and a copy stream that lands in the queue of a compute stream gets its H2D chunks
+    // in between that stream's kernels only. (Seen with an RCCL communicator on the context: its internal streams shifted the
+    // lazily created copy stream onto the first compute stream's queue — every upload that ran beside an alignment on that stream took
+    // 31 ms instead of 14.)
+    ok = ok && hip_ok(nullptr, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+    ok = ok && hip_ok(nullptr, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking), "hipStreamCreate");
     if (!ok) {
         for (hipStream_t st : ctx->slot_stream) if (st) (void)hipStreamDestroy(st);
+        if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
         delete ctx;
         return LOCGPU_ERR_NO_DEVICE;
     }
@@ -191,6 +200,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     upload_free_ctx(ctx);
     if (ctx->comm) { (void)rccl().CommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->d_tree) (void)hipFree(ctx->d_tree);
     if (ctx->d_leaf_slots) (void)hipFree(ctx->d_leaf_slots);
     if (ctx->d_bfnn) (void)hipFree(ctx->d_bfnn);
@@ -531,13 +541,13 @@ int locgpu_comm_init(locgpu_ctx* ctx, int rank, int world, const void* id) {
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof(uid));
     ncclComm_t comm = nullptr;
+    // RCCL may narrow the calling thread's CPU affinity while it initialises, and threads created afterwards (the uploader's
+    // packers, the tree-build pool) inherit what it leaves behind: put the caller's mask back.
+    cpu_set_t saved_affinity;
+    const bool have_affinity = sched_getaffinity(0, sizeof(saved_affinity), &saved_affinity) == 0;
     const ncclResult_t nr = rccl().CommInitRank(&comm, world, uid, rank);
+    if (have_affinity) (void)sched_setaffinity(0, sizeof(saved_affinity), &saved_affinity);
     if (nr != ncclSuccess) return fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclCommInitRank: ") + rccl().GetErrorString(nr));
-    if (!ctx->comm_stream && !hip_ok(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking), "comm_init: hipStreamCreate")) {
-        (void)rccl().CommDestroy(comm);
-        ctx->comm_stream = nullptr;
-        return LOCGPU_ERR_NO_DEVICE;
-    }
     ctx->comm = comm;
     ctx->comm_rank = rank;
     ctx->comm_world = world;
