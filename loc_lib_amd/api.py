@@ -600,6 +600,10 @@ class Batch:
             self.max_points = int(max_points)
             ctx._check(lib().locgpu_batch_create_empty(ctx._h, self.n_scans, int(max_points), ctypes.byref(self._h)))
             return
+        if n_total is not None and len(scans) == 0:  # a rank that holds none of the batch's scans still takes part in its collectives
+            self.n_local, self.max_points, self.n_scans = 0, 0, int(n_total)
+            ctx._check(lib().locgpu_batch_create_sharded(ctx._h, None, None, 16, 0, int(first or 0), self.n_scans, ctypes.byref(self._h)))
+            return
         scans, ptrs, cnts, stride = self._marshal(scans)
         self.n_local = len(scans)
         self.max_points = max(s.shape[0] for s in scans)

@@ -41,8 +41,12 @@ struct Rccl {
 Rccl& rccl() {
     static Rccl r = [] {
         Rccl x;
-        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);  // a copy already mapped by the host process (e.g. PyTorch's) is reused
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        // LOCGPU_RCCL_LIB names another library with the same six entry points: a site's own RCCL build, or the loopback double the
+        // tests use to run two ranks as two threads on one GPU (tests/cpp/loopback_rccl.hip).
+        const char* named = getenv("LOCGPU_RCCL_LIB");
+        void* h = (named && *named) ? dlopen(named, RTLD_NOW | RTLD_LOCAL)
+                                    : dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);  // a copy already mapped by the host process (e.g. PyTorch's) is reused
+        if (!h && !(named && *named)) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h) { x.err = std::string("cannot load librccl: ") + dlerror(); return x; }
         x.GetUniqueId = (decltype(x.GetUniqueId))dlsym(h, "ncclGetUniqueId");
         x.CommInitRank = (decltype(x.CommInitRank))dlsym(h, "ncclCommInitRank");
