@@ -8,10 +8,11 @@ One "step" = one pass of the hot path over one batch: every rank aligns `--scans
 mode). The map and its tree are in HBM before the timed region starts. The SCANS are not: scans/sec includes the source deep
 copy of every ScanMatch call (SetSource, icp_registration.cpp:221,252-265) — every step aligns a batch that
 was copied host → HBM for it through pinned staging on a copy stream, while the previous step's Gauss–Newton loop ran
-(three batches rotate: one is being copied, two are being aligned; `--resident` keeps the scans in HBM instead and is reported as
-the secondary number). Two alignments are in flight at any time (`locgpu_*_align_batch_begin` / `locgpu_align_batch_end`): the
-first Gauss–Newton iterations of step i+1 run under the last ones of step i, which hold a handful of unconverged scans
-(`--pipeline 1` = one at a time, for A/B). Every step still begins and ends inside the timed region.
+(depth + 1 batches rotate: one is being copied, the others are being aligned; `--resident` keeps the scans in HBM instead and is
+reported as the secondary number). Up to `--pipeline` alignments are in flight (`locgpu_*_align_batch_begin` /
+`locgpu_align_batch_end`): the first Gauss–Newton iterations of step i+1 run under the last ones of step i, which hold a handful of
+unconverged scans (`--pipeline 1` = one at a time, the default at 256 scans per GPU). Every step still begins and ends inside the
+timed region.
 One GPU: BASELINE.json configs[2], every step aligns `--scans-per-gpu` (256) scans. Several GPUs, default (`--scaling strong`):
 configs[3] as written — `--total-scans` (256) scans in all, sharded contiguously over the ranks, per-iteration RCCL all-reduce of
 the per-scan normal equations inside liblocgpu.so (every rank solves every scan and holds all poses). `--scaling weak`: every
@@ -177,11 +178,12 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
                     help="strong (default with several GPUs): --total-scans in all, sharded over the ranks with the per-iteration RCCL "
                          "all-reduce (BASELINE configs[3]); weak (default with one GPU): --scans-per-gpu scans on every rank, no collective")
-    ap.add_argument("--pipeline", type=int, choices=[0, 1, 2], default=0,
-                    help="alignments in flight: 2 = step i+1 is begun before step i is ended, 1 = one at a time, 0 (default) = 2 when a "
-                         "rank holds fewer than 128 scans (the shards of the multi-GPU runs), else 1 — at 256 scans per GPU two in flight "
-                         "give +6 %% scans/s but every kernel's launch duration then includes the other batch's share of the chip, and "
-                         "`roofline` is defined on launch durations")
+    ap.add_argument("--pipeline", type=int, choices=[0, 1, 2, 3], default=0,
+                    help="alignments in flight (the library has three compute streams): k = step i+k-1 is begun before step i is ended, "
+                         "1 = one at a time, 0 (default) = 3 when a rank holds fewer than 128 scans (the shards of the multi-GPU runs: "
+                         "+14 %% over two in flight at 32 and 64 scans), else 1 — at 256 scans per GPU two in flight give +6 %% scans/s "
+                         "but every kernel's launch duration then includes the other batches' share of the chip, and `roofline` is "
+                         "defined on launch durations")
     ap.add_argument("--total-scans", type=int, default=256)
     ap.add_argument("--traffic", choices=["live", "profiles", "none"], default="live",
                     help="roofline.traffic: live = two rocprofv3 --pmc child runs now (1 GPU only), profiles = newest committed collection")
@@ -244,7 +246,7 @@ def main():
     def new_batch():
         return ctx.batch(scans, first=lo, n_total=n_total) if strong else ctx.batch(scans)
 
-    depth = args.pipeline if args.pipeline else (2 if B_local < 128 else 1)
+    depth = args.pipeline if args.pipeline else (3 if B_local < 128 else 1)
     # resident: `depth` batches hold the same scans; streaming: one more, so that the copy for step g+1 never lands in a batch
     # that an alignment in flight (steps g, g-1) is reading
     bufs = [new_batch() for _ in range(depth if args.resident else depth + 1)]

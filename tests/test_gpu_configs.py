@@ -400,9 +400,9 @@ def test_bench_line_contract(mode):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 2  # algorithmic bytes over launch time: most node reads are cache hits, so this can pass 1
     assert abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-3 * d["value"]
     assert d["median_translation_error_to_truth_m"] < 0.1
-    # the workload label follows the arguments (a 1 M-pt map is configs[1], the sharded mode configs[3]); small shards run two in flight
+    # the workload label follows the arguments (a 1 M-pt map is configs[1], the sharded mode configs[3]); small shards run three in flight
     assert ("configs[3]" if mode == "strong" else "configs[1]") in d["config"]["workload"]
-    assert d["config"]["pipeline_depth"] == 2 and "roofline_k2" in d
+    assert d["config"]["pipeline_depth"] == 3 and "roofline_k2" in d
 
 
 # ----------------------------------------------------------------------------------------------- other LDS stack depths
@@ -562,6 +562,34 @@ def test_align_begin_end_two_batches_in_flight(gpu_ctx, api, small_world):
         assert [x["iterations"] for x in sb] == [x["iterations"] for x in ref[1][1][1]]
     ba.close()
     bb.close()
+
+
+def test_four_alignments_in_flight_over_three_streams(gpu_ctx, api, small_world):
+    """Batches are dealt to the context's three compute streams in turn; a fourth shares a stream with the first. Four alignments
+    begun back to back (ICP, ragged scans, different poses) and ended in a scrambled order give the blocking calls' poses bit for bit."""
+    m = small_world["map"]
+    s = small_world["scan10k"]
+    pose = small_world["init_pose"]
+    gpu_ctx.icp_set_target(m)
+    opts = api.icp_opts(method=api.P2PLANE)
+    sets = [[s, s[:7000]], [s[::2], s[:9000]], [s[100:4100], s[::3]], [s[5:8005], s[:2500]]]
+    inits = []
+    for i in range(4):
+        ip = np.stack([pose, pose])
+        ip[0, 4] += 0.01 * i
+        ip[1, 5] -= 0.015 * i
+        inits.append(ip)
+    batches = [gpu_ctx.batch(x) for x in sets]
+    want = [gpu_ctx.icp_align_batch(b, ip, opts) for b, ip in zip(batches, inits)]
+    for order in ((0, 1, 2, 3), (3, 1, 0, 2), (2, 3, 1, 0)):
+        for b, ip in zip(batches, inits):
+            gpu_ctx.icp_align_batch_begin(b, ip, opts)
+        for i in order:
+            got, st = gpu_ctx.align_batch_end(batches[i])
+            assert np.array_equal(got, want[i][0])
+            assert [x["iterations"] for x in st] == [x["iterations"] for x in want[i][1]]
+    for b in batches:
+        b.close()
 
 
 def test_upload_error_and_destroy_while_pending(gpu_ctx, api, small_world):

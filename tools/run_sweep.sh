@@ -1,6 +1,6 @@
-b="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --traffic none"
-$b 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('weak stream', d['value'], d['ms_per_step'], d['kernel_ms_per_step'])"
-$b --scaling strong 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('strong stream', d['value'], d['ms_per_step'], d['kernel_ms_per_step'])"
-$b --scaling strong --resident 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('strong resident', d['value'], d['ms_per_step'], d['kernel_ms_per_step'])"
-LOCGPU_COMM_DIRECT=0 $b --scaling strong 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('strong stream commstream', d['value'], d['ms_per_step'], d['kernel_ms_per_step'])"
-LOCGPU_BENCH_PROFILE=0 $b --scaling strong 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('strong stream noprofile', d['value'], d['ms_per_step'])"
+for rep in 1 2; do
+for cfg in "A 2" "B 3"; do set -- $cfg
+for sc in 32 64; do
+LOCGPU_LIB=build_variants/liblocgpu_$1.so python bench.py --total-scans $sc --scaling strong --steps 40 --warmup 4 --no-cpu-baseline --traffic none --pipeline $2 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1 depth $2 total $sc strong', d['value'])"
+done; done
+done
