@@ -143,7 +143,7 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
 // Every lane of the wave must call walk_query (wave-wide ballots inside); a lane without a query passes valid = false.
 template <int K, int ROWB, int MODE>  // MODE 0: flat trips, 2: rounds, 12: rounds capped at two internal steps (default)
 __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const uint2* __restrict__ tree, Walk<K>& w, bool valid, float alpha_eff, int T, uint32_t dummy,
-                                           uint32_t col_addr) {
+                                           uint32_t col_addr, int cap) {
 #pragma unroll
     for (int j = 0; j < K; ++j) { w.d[j] = __builtin_inff(); w.id[j] = kInvalidSlot; }
     w.slow = 0;
@@ -154,9 +154,9 @@ __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const ui
     } else {
         w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = valid ? 1u : 0u;
     }
-    if (MODE == 2) walk_rounds<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr);
-    else if (MODE == 12) walk_rounds_capped<K, ROWB, 2>(rsrc, w, alpha_eff, dummy, col_addr);
-    else do walk_trip<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr); while (__ballot(w.cur != dummy || w.avail > 0) != 0ull);
+    if (MODE == 2) walk_rounds<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr, cap);
+    else if (MODE == 12) walk_rounds_capped<K, ROWB, 2>(rsrc, w, alpha_eff, dummy, col_addr, cap);
+    else do walk_trip<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr, cap); while (__ballot(w.cur != dummy || w.avail > 0) != 0ull);
 #pragma unroll
     for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;  // equal distances in the final set: heap pop order is layout-dependent
 }
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
     Walk<K> w;
     w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
-    walk_query<K, ROWB, MODE>(rsrc, tree, w, true, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]));
+    walk_query<K, ROWB, MODE>(rsrc, tree, w, true, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]), DF);  // DF rows: a stack that outgrows them → deep pass
     const bool deep = w.c3n == 1u;
     const bool slow = !deep && w.slow != 0u;
     if (!deep && !slow) {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* _
             const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
             w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
         }
-        walk_query<K, ROWB, 12>(rsrc, tree, w, valid, alpha_eff, 0, dummy, (uint32_t)(size_t)(&s_dyn[tid]));
+        walk_query<K, ROWB, 12>(rsrc, tree, w, valid, alpha_eff, 0, dummy, (uint32_t)(size_t)(&s_dyn[tid]), 0x7fffffff);  // D + 2 rows ≥ depth: cannot overflow
         const bool slow = valid && w.slow != 0u;
         if (valid && !slow) {
 #pragma unroll

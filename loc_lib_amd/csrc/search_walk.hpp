@@ -17,7 +17,8 @@
 //     descent — older below younger, which is the recursion's order — so the drain to them is an ordinary pop; only the third
 //     smallest d² stays in a register. A query for which it could pass as well (≈1e-3 of them) is marked and recomputed by the
 //     DEEP PASS: the same traversal with every level stored, over a device-side list. The other DF−2 rows hold one level each and
-//     T (the number of un-stored levels) is chosen so that the stack cannot outgrow them: there is no overflow case;
+//     T (the number of un-stored levels) is chosen so that the first descent and everything below a stored level fit; only the
+//     descent from a candidate, which starts on an un-stored level, can outgrow the rows — such a query goes to the deep pass too;
 //   * a pop only happens on a leaf, and a lane on a leaf pushes nothing: the four youngest rows are read at the top of the trip,
 //     next to the node load, not behind it;
 //   * the result set is updated with v_med3_f32: inserting x into ascending d[0..K) and dropping the largest is
@@ -157,7 +158,7 @@ __device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, const 
 // Latency: a pop only happens on a leaf, and a lane on a leaf pushes nothing — so the four youngest stack rows are read at the TOP
 // of the trip, next to the node load, instead of behind it (two LDS round trips less on the dependent chain).
 template <int K, int ROWB>
-__device__ __forceinline__ void walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr) {
+__device__ __forceinline__ void walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr, int cap) {
     // every field is copied to a value first: a conditional between two members is an lvalue (a select of addresses) and would pin w in scratch
     const float qx = w.qx, qy = w.qy, qz = w.qz;
     const uint32_t cur = w.cur;
@@ -240,7 +241,8 @@ __device__ __forceinline__ void walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& 
     const int low = avail_eff - 1 - min(hit, 3);
     const uint32_t c3n = w.c3n;
     const uint32_t c3sel = low < 2 ? c3n : 0u;
-    w.c3n = (int)c3sel < nb ? 1u : c3n;  // 1 = "deep pass" (a positive value never passes this test again)
+    const bool deep = ((int)c3sel < nb) | (avail > cap);  // the third candidate could pass, or a push fell off the stack (see walk_rounds_capped)
+    w.c3n = deep ? 1u : c3n;  // 1 = "deep pass" (a positive value never passes the first test again)
     w.cur = far_hit;
     w.avail = avail + pushed - used;
 }
@@ -253,7 +255,7 @@ __device__ __forceinline__ void walk_trip(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& 
 // of the small internal body only: search 21.9 -> 20.0 ms per 256-scan step. (Tried on top: an inner loop that keeps popping when
 // four rows failed instead of a sentinel round — 20.5 ms, not kept.)
 template <int K, int ROWB>
-__device__ __forceinline__ void walk_rounds(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr) {
+__device__ __forceinline__ void walk_rounds(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr, int cap) {
     const float qx = w.qx, qy = w.qy, qz = w.qz;
     uint32_t cur = w.cur;
     int avail = w.avail;
@@ -300,7 +302,8 @@ __device__ __forceinline__ void walk_rounds(__amdgpu_buffer_rsrc_t rsrc, Walk<K>
         const int used = min(min(hit + 1, 4), avail);
         const int low = avail - 1 - min(hit, 3);
         const uint32_t c3sel = low < 2 ? c3n : 0u;
-        c3n = (int)c3sel < nb ? 1u : c3n;
+        const bool deep = ((int)c3sel < nb) | (avail > cap);
+        c3n = deep ? 1u : c3n;
         cur = nxt;
         avail -= used;
         // ---- internal steps (Knn, kdtree.cpp:177-194) down to the next leaf; the bound does not change on the way
@@ -329,7 +332,7 @@ __device__ __forceinline__ void walk_rounds(__amdgpu_buffer_rsrc_t rsrc, Walk<K>
 // out the next leaf stage (x = +inf, pop switched off) and keeps descending after it. Between the flat loop (C = 1, both blocks
 // every trip) and the rounds loop (C = ∞: every round waits for the wave's longest descent).
 template <int K, int ROWB, int C>
-__device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr) {
+__device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr, int cap) {
     const float qx = w.qx, qy = w.qy, qz = w.qz;
     uint32_t cur = w.cur;
     int avail = w.avail;
@@ -379,7 +382,13 @@ __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, 
         const int used = min(min(hit + 1, 4), avail_eff);
         const int low = avail_eff - 1 - min(hit, 3);
         const uint32_t c3sel = low < 2 ? c3n : 0u;
-        c3n = (int)c3sel < nb ? 1u : c3n;
+        // Rows 2.. hold one stored level each on the first descent and cannot overflow there; but a CANDIDATE (rows 0/1) sits on an
+        // un-stored level, and the descent from it may push more survivors than there are rows (deep, unbalanced trees whose split
+        // planes hug the query: a map made of straight lines does it). A push beyond the last row falls off the LDS allocation and
+        // is lost, so a stack that stands higher than `cap` rows at a leaf stage — it only grows between two of them — sends the
+        // query to the deep pass as well. One compare and a scalar OR per stage.
+        const bool deep = ((int)c3sel < nb) | (avail > cap);
+        c3n = deep ? 1u : c3n;
         const bool moved = nxt != cur;
         cur = nxt;
         avail -= used;

@@ -164,14 +164,17 @@ def main():
         print(json.dumps({"filters": filters_section(ctx, locref, a.map_points, a.reps)}))
     if a.only != "filters":
         ctx.graph_enable(a.graph)
-        # a host-latency-bound loop on a shared box: five passes, the MEDIAN is reported and every pass is kept
-        runs = [stream_section(ctx, locref, a.scans, a.kf_every, a.num_kfs, a.scan_leaf, a.map_leaf, not a.no_check and i == 0) for i in range(5)]
+        # a host-latency-bound loop on a shared box: one untimed pass (it grows the library's buffers and carries the oracle check),
+        # then five passes: the MEDIAN is reported and every pass is kept
+        first = stream_section(ctx, locref, a.scans, a.kf_every, a.num_kfs, a.scan_leaf, a.map_leaf, not a.no_check)
+        runs = [stream_section(ctx, locref, a.scans, a.kf_every, a.num_kfs, a.scan_leaf, a.map_leaf, False) for i in range(5)]
         ranked = sorted(runs, key=lambda r: r["scans_per_s"])
         mid = ranked[len(ranked) // 2]
         mid["scans_per_s_all_passes"] = [round(r["scans_per_s"], 1) for r in runs]
-        mid["checked_against_oracle"] = runs[0]["checked_against_oracle"]  # the first pass carries the oracle check
-        mid["max_pose_abs_diff"] = runs[0]["max_pose_abs_diff"]
-        mid["reported"] = "median of 5 passes"
+        mid["scans_per_s_untimed_first_pass"] = round(first["scans_per_s"], 1)
+        mid["checked_against_oracle"] = first["checked_against_oracle"]  # the first pass carries the oracle check
+        mid["max_pose_abs_diff"] = first["max_pose_abs_diff"]
+        mid["reported"] = "median of 5 passes after one untimed pass"
         print(json.dumps({"stream": mid}))
     ctx.close()
 

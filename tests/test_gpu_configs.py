@@ -516,6 +516,46 @@ def test_hot_search_kernel_lists_on_ties_duplicates_and_p2p():
         ctx.close() if hasattr(ctx, "close") else None
 
 
+def _lines_cloud(rng, n):
+    """Eight straight lines through a 60 m box: a deep, unbalanced tree whose split planes pass within centimetres of most queries."""
+    t = rng.uniform(-100, 100, size=(n, 1))
+    d = rng.normal(size=(8, 3))
+    o = rng.uniform(-30, 30, size=(8, 3))
+    i = rng.integers(0, 8, n)
+    return (o[i] + t * d[i] / np.linalg.norm(d[i], axis=1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed,n", [(5, 100_000), (3, 1_000_000)])
+def test_hot_search_kernel_lists_when_a_candidate_descent_outgrows_the_stack(seed, n):
+    """Found by tools/fuzz_search.py on the batch kernel (round 3): the descent from a candidate of the un-stored levels starts above
+    the stored levels and, on a map of straight lines, can push more surviving rows than the stack has — pushes beyond the last row
+    fall off the LDS allocation. Such a query must go to the deep pass (every level stored), not keep a list that misses a
+    neighbour: 20 000 queries 3 m (σ) off the lines, eight copies so that the batch kernel runs (> 2048 waves), ANN lists index for
+    index. (n = 1 M trips it at the default 15 rows, n = 100 k at the 12 rows of test_search_parity_at_other_stack_depths.)"""
+    from loc_lib_amd import api
+    from oracle import locref
+    rng = np.random.default_rng(seed)
+    cloud = _lines_cloud(rng, n)
+    nq = 20000
+    scan = (cloud[rng.integers(0, n, nq)].astype(np.float64) + rng.normal(0, 3.0, size=(nq, 3))).astype(np.float32)
+    pose = np.array([0, 0, 0, 1, 0.3, -0.2, 0.1])
+    ctx = api.Context(0)
+    try:
+        ctx.icp_set_target(cloud)
+        tree = locref.KdTree(cloud)
+        b = ctx.batch([scan] * 8)
+        for method, k in ((api.P2PLANE, 5), (api.P2P, 1)):
+            opts = api.icp_opts(method=method)
+            ctx.icp_hb_batch(b, np.stack([pose] * 8), opts)
+            got = ctx.debug_batch_nn(b, k)
+            want = _oracle_lists(locref, tree, scan, pose, k, True)
+            for i in (0, 7):
+                assert np.array_equal(got[i, :nq], want), (k, i, int(np.sum(np.any(got[i, :nq] != want, axis=1))))
+        b.close()
+    finally:
+        ctx.close()
+
+
 # ----------------------------------------------------------------------------------------------- two alignments in flight
 def test_align_begin_end_two_batches_in_flight(gpu_ctx, api, small_world):
     """locgpu_*_align_batch_begin / locgpu_align_batch_end: two batches (different scans, ragged counts) begun back to back and ended

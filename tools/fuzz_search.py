@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity hunt for the hot search kernel (run ON the GPU box): random maps (uniform, clustered, planar sheets, lines, duplicated
 points, lattices), random scans and poses, ANN and exact pruning, k = 5 and 1 — the neighbour lists of icp_search_fast_kernel (read back with
-locgpu_debug_batch_nn) must equal the oracle's KdTree::GetClosestPoint lists index for index.
+locgpu_debug_batch_nn) must equal the oracle's KdTree::GetClosestPoint lists index for index. Odd cases run as a batch large enough for
+the batch kernel (walk + deep pass), even ones through the one-scan kernel; LOCGPU_FAST_STACK=12 makes the rare paths common.
 
     python tools/fuzz_search.py [--cases 200] [--seed 1]
 """
@@ -48,6 +49,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=-1, help="run only this case of the sequence (the random stream is still consumed case by case)")
+    ap.add_argument("--dump", type=str, default="", help="with --only: save the case (cloud, scan, pose) to this .npz")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     kinds = ["uniform", "clusters", "sheets", "lines", "dups", "lattice"]
@@ -59,6 +62,10 @@ def main():
         cloud = make_map(rng, kind, n).astype(np.float32)
         if len(cloud) < 1:
             continue
+        if a.only >= 0 and case != a.only:  # consume exactly what the case would have consumed
+            nq = int(10 ** rng.uniform(1.0, 4.7))
+            rng.integers(0, len(cloud), nq); rng.uniform(-3, 1); rng.normal(0, 1.0, size=(nq, 3)); rng.normal(size=4); rng.uniform(-3, 0.5); rng.normal(0, 1.0, size=3)
+            continue
         ctx = api.Context(0)
         ctx.icp_set_target(cloud)
         tree = locref.KdTree(cloud)
@@ -68,7 +75,12 @@ def main():
         q = rng.normal(size=4) * np.array([0.05, 0.05, 0.05, 1.0])
         q /= np.linalg.norm(q)
         pose = np.concatenate([q, rng.normal(0, 10 ** rng.uniform(-3, 0.5), size=3)])
-        b = ctx.batch([scan])
+        if a.dump and case == a.only:
+            np.savez(a.dump, cloud=cloud, scan=scan, pose=pose)
+        # every other case (when the scan is large enough) as a batch of copies that exceeds 2048 waves: the batch kernel (un-stored
+        # top levels, deep pass) instead of the one-scan kernel (every level stored)
+        copies = (2049 * 64 + nq - 1) // nq if (case % 2 == 1 and nq >= 2100) else 1
+        b = ctx.batch([scan] * copies)
         for method, k in ((api.P2PLANE, 5), (api.P2P, 1)):
             for approximate in (1, 0):
                 if k > tree.num_leaves:
@@ -76,10 +88,10 @@ def main():
                 opts = api.icp_opts(method=method)
                 opts.approximate = approximate
                 try:
-                    ctx.icp_hb_batch(b, pose[None], opts)
+                    ctx.icp_hb_batch(b, np.stack([pose] * copies), opts)
                 except api.LocGpuError:
                     continue
-                got = ctx.debug_batch_nn(b, k)[0, :nq]
+                got = ctx.debug_batch_nn(b, k)[copies - 1, :nq]
                 qq = locref.transform_points(pose, np.ascontiguousarray(scan[:, :3], dtype=np.float64)).astype(np.float32)
                 want = tree.knn(qq, k, approximate=bool(approximate), alpha=0.1)
                 if not np.array_equal(got, want):

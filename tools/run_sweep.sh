@@ -1,6 +1,7 @@
-for rep in 1 2; do
-for cfg in "A 2" "B 3"; do set -- $cfg
-for sc in 32 64; do
-LOCGPU_LIB=build_variants/liblocgpu_$1.so python bench.py --total-scans $sc --scaling strong --steps 40 --warmup 4 --no-cpu-baseline --traffic none --pipeline $2 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1 depth $2 total $sc strong', d['value'])"
-done; done
-done
+timeout 600 python tools/fuzz_search.py --cases 240 --seed 21 2>&1 | tail -4
+LOCGPU_FAST_STACK=12 timeout 600 python tools/fuzz_search.py --cases 240 --seed 22 2>&1 | tail -4
+LOCGPU_FAST_STACK=12 LOCGPU_WALK_MODE=0 timeout 600 python tools/fuzz_search.py --cases 120 --seed 23 2>&1 | tail -4
+LOCGPU_FAST_STACK=12 LOCGPU_WALK_MODE=2 timeout 600 python tools/fuzz_search.py --cases 120 --seed 24 2>&1 | tail -4
+LOCGPU_FAST_STACK=12 timeout 600 python tools/debug/lines_overflow_scan.py 2>&1 | grep -v "differing 0" | tail -5
+timeout 600 python -m pytest tests/test_gpu_configs.py -q -m gpu -x -k "hot_search or other_stack" 2>&1 | tail -3
+VARIANTS="A B" bash tools/run_ab.sh
