@@ -42,6 +42,15 @@ def make_map(rng, kind, n):
         m = max(2, int(round(n ** (1 / 3))))
         g = np.arange(m, dtype=np.float64) * rng.choice([0.25, 0.5, 1.0])
         return np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    if kind == "geometric":  # coordinates spread over many octaves: the mean split peels off a few points per level — very deep trees
+        e = rng.integers(0, int(rng.integers(8, 45)), size=(n, 3))
+        return rng.choice([-1.0, 1.0], size=(n, 3)) * 100.0 * 2.0 ** (-e.astype(np.float64)) * rng.uniform(1.0, 1.3, size=(n, 3))
+    if kind == "offset":  # a small box far from the origin: float32 has ≈1e-3 … 1e-2 m resolution there, distances tie all the time
+        return rng.uniform(-10, 10, size=(n, 3)) + rng.choice([1e4, 3e4, 1e5]) * rng.choice([-1.0, 1.0], size=3)
+    if kind == "rings":  # what a spinning LiDAR leaves on flat ground
+        r = rng.choice(np.linspace(2.0, 60.0, 16), n)
+        th = rng.uniform(0, 2 * np.pi, n)
+        return np.stack([r * np.cos(th), r * np.sin(th), rng.normal(0, 0.005, n)], axis=1)
     raise ValueError(kind)
 
 
@@ -53,7 +62,7 @@ def main():
     ap.add_argument("--dump", type=str, default="", help="with --only: save the case (cloud, scan, pose) to this .npz")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
-    kinds = ["uniform", "clusters", "sheets", "lines", "dups", "lattice"]
+    kinds = ["uniform", "clusters", "sheets", "lines", "dups", "lattice", "geometric", "offset", "rings"]  # an odd number: every kind meets both kernels
     bad = 0
     t0 = time.time()
     for case in range(a.cases):
@@ -67,11 +76,16 @@ def main():
             rng.integers(0, len(cloud), nq); rng.uniform(-3, 1); rng.normal(0, 1.0, size=(nq, 3)); rng.normal(size=4); rng.uniform(-3, 0.5); rng.normal(0, 1.0, size=3)
             continue
         ctx = api.Context(0)
-        ctx.icp_set_target(cloud)
-        tree = locref.KdTree(cloud)
         nq = int(10 ** rng.uniform(1.0, 4.7))
         src = cloud[rng.integers(0, len(cloud), nq)].astype(np.float64) + rng.normal(0, 10 ** rng.uniform(-3, 1), size=(nq, 3))
         scan = src.astype(np.float32)
+        try:
+            ctx.icp_set_target(cloud)
+        except api.LocGpuError as e:  # depth > 64: refused by design
+            print("case %d kind %s n %d: target refused (%s)" % (case, kind, n, str(e)[:80]), flush=True)
+            rng.normal(size=4); rng.uniform(-3, 0.5); rng.normal(0, 1.0, size=3)  # what the case would have consumed (--only stays aligned)
+            continue
+        tree = locref.KdTree(cloud)
         q = rng.normal(size=4) * np.array([0.05, 0.05, 0.05, 1.0])
         q /= np.linalg.norm(q)
         pose = np.concatenate([q, rng.normal(0, 10 ** rng.uniform(-3, 0.5), size=3)])
