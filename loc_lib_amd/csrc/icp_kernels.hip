@@ -875,8 +875,8 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
     static const int walk = [] { const char* e = getenv("LOCGPU_WALK"); return e ? atoi(e) : 1; }();  // 0 = the round-2 kernel (A/B runs)
     if (walk == 1 && a.redo_list2) {
         // round-3 traversal (search_walk.hpp): rows 0/1 of the DF stored rows hold the candidates of the un-stored levels, the other
-        // DF-2 rows one level each — T is chosen so that the stack cannot outgrow them. Queries whose un-stored levels need more than
-        // two candidates go through a.redo_list2 to the deep pass (every level stored), ties to the exact redo kernel as before.
+        // DF-2 rows one level each. Queries whose un-stored levels need more than two candidates, or whose candidate descent outgrows
+        // the rows, go through a.redo_list2 to the deep pass (every level stored), ties to the exact redo kernel as before.
         const uint32_t dummy = (uint32_t)(a.tree_bytes / 8);
         static const int wpad = [] { const char* e = getenv("LOCGPU_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiment: extra dynamic LDS lowers occupancy
         static const int mode = [] { const char* e = getenv("LOCGPU_WALK_MODE"); return e ? atoi(e) : 12; }();
@@ -900,7 +900,10 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         else if (mode == 12) LOCGPU_WALK_LAUNCH(12);
         else LOCGPU_WALK_LAUNCH(0);
 #undef LOCGPU_WALK_LAUNCH
-        hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(1024), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
+        // 2048 one-wave blocks of 17 KB LDS are all resident at once (nine fit a CU): the first iteration's ≈140 k deep queries take one
+        // traversal per wave instead of two or three in sequence (search 18.07 → 17.80 ms per 256-scan step; 4608: 17.96)
+        static const int deep_grid = [] { const char* e = getenv("LOCGPU_DEEP_GRID"); return e ? atoi(e) : 2048; }();
+        hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(deep_grid), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
                            a.alpha_eff, (unsigned int)a.tree_bytes + 16u, dummy, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count, a.search_stats);
         hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                            a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);

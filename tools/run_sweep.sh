@@ -1,2 +1,5 @@
-timeout 900 python tools/fuzz_search.py --cases 270 --seed 31 2>&1 | tail -12
-LOCGPU_FAST_STACK=12 timeout 900 python tools/fuzz_search.py --cases 270 --seed 32 2>&1 | tail -12
+for rep in 1 2; do
+for g in 1024 2048 2304 4608; do
+LOCGPU_DEEP_GRID=$g python bench.py --steps 10 --warmup 2 --resident --no-cpu-baseline --traffic none --pipeline 1 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('deep grid $g', d['value'], d['kernel_ms_per_step'])"
+done
+done
