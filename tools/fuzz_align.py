@@ -42,6 +42,17 @@ def main():
                 ref.set_target(m)
                 want = ref.align(scan, init)
                 got, st = ctx.icp_align(scan, init, api.icp_opts(method=method))
+                if case % 2 == 1:  # the same scan as a batch large enough for the batch search kernel (> 2048 waves)
+                    copies = (2049 * 64 + len(scan) - 1) // len(scan)
+                    b = ctx.batch([scan] * copies)
+                    bp, bst = ctx.icp_align_batch(b, np.stack([init] * copies), api.icp_opts(method=method))
+                    b.close()
+                    for j in (0, copies - 1):
+                        dtb, drb = pose_delta(bp[j], want["pose"])
+                        worst_t, worst_r = max(worst_t, dtb), max(worst_r, drb)
+                        if bst[j]["iterations"] != want["iters"]:
+                            it_bad += 1
+                            print("ITERATIONS differ (batch): case %d method %d gpu %d oracle %d" % (case, method, bst[j]["iterations"], want["iters"]), flush=True)
             else:
                 ref = locref.Ndt()
                 ref.set_target(m)
