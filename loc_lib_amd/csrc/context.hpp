@@ -108,6 +108,8 @@ struct locgpu_batch {
     float4* h_src = nullptr;               // pinned staging of the packed source (single-scan path only; reused across calls)
     locgpu::PoseState* h_state = nullptr;  // pinned
     double* h_hb = nullptr;                // pinned
+    int* h_active = nullptr;               // pinned, [n_scans]: local indices of the scans still open at the last chunk boundary
+    int* d_active = nullptr;               // its device copy (see SearchArgs::active)
     std::vector<int> counts;
     locgpu::BatchUploadState upl;          // event + pinned counts of locgpu_batch_upload_async (batch_upload.hpp)
     std::vector<hipEvent_t> events;        // profiling events of the batch's alignments (locgpu_profile_enable)

@@ -192,11 +192,12 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
                                                              uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, float alpha_eff, int T,
                                                              unsigned int tree_bytes, uint32_t dummy, int skip_nonfinite, uint32_t* __restrict__ redo_list,
                                                              unsigned int* __restrict__ redo_count, uint32_t* __restrict__ deep_list,
-                                                             unsigned int* __restrict__ deep_count, unsigned long long* __restrict__ search_stats) {
+                                                             unsigned int* __restrict__ deep_count, unsigned long long* __restrict__ search_stats,
+                                                             const int* __restrict__ active) {
     extern __shared__ uint2 s_dyn[];
     constexpr int ROWB = LANES * 8;
     static_assert(DF * ROWB >= 64 * 2 * 8, "exact stack columns do not fit");
-    const int scan = blockIdx.y;
+    const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;  // later chunks of an alignment launch only the scans still open
     if (st[scan].done) return;
     const int tid = threadIdx.x;
     const int i = blockIdx.x * LANES + tid;
@@ -473,10 +474,11 @@ __device__ __forceinline__ void R_hat(const double* R, const D3& q, double (&Rh)
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_plane_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
-                                                                 double max_plane_distance, double* __restrict__ partials, int kPlanePts) {
+                                                                 double max_plane_distance, double* __restrict__ partials, int kPlanePts,
+                                                                 const int* __restrict__ active) {
     __shared__ double s_row[8][kAccPad];
     __shared__ double s_slice[kBlock / 32][32];
-    const int scan = blockIdx.y;
+    const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;  // uniform per block
     const int tid = threadIdx.x;
     RowAccum ra;  // see there: the 28 sums are not kept per thread
@@ -535,8 +537,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 __global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
-                                                                 double max_nn_distance, double* __restrict__ partials, int pts) {
-    const int scan = blockIdx.y;
+                                                                 double max_nn_distance, double* __restrict__ partials, int pts,
+                                                                 const int* __restrict__ active) {
+    const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;
     double acc[28];
 #pragma unroll
@@ -575,10 +578,11 @@ __global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void icp_line_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                 const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                 const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
-                                                                double max_line_distance, double* __restrict__ partials, int pts) {
+                                                                double max_line_distance, double* __restrict__ partials, int pts,
+                                                                const int* __restrict__ active) {
     __shared__ double s_row[8][kAccPad];
     __shared__ double s_slice[kBlock / 32][32];
-    const int scan = blockIdx.y;
+    const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;
     RowAccum ra;
     ra.init();
@@ -881,21 +885,22 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         static const int wpad = [] { const char* e = getenv("LOCGPU_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiment: extra dynamic LDS lowers occupancy
         static const int mode = [] { const char* e = getenv("LOCGPU_WALK_MODE"); return e ? atoi(e) : 12; }();
         static const int small = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); return e ? atoi(e) : 16; }();
-        if ((size_t)((a.max_n + 63) / 64) * a.n_scans <= 2048 && small == 16) {
+        const int n_launch = a.active ? a.n_active : a.n_scans;  // grid.y: the scans still open (a.active) or all of them
+        if ((size_t)((a.max_n + 63) / 64) * n_launch <= 2048 && small == 16) {
             // fewer than 2048 full waves (one or two scans): quarter-filled waves with every level stored — no deep pass
-            dim3 g1((a.max_n + 15) / 16, a.n_scans);
+            dim3 g1((a.max_n + 15) / 16, n_launch);
             hipLaunchKernelGGL((icp_search_walk_kernel<K, D + 2, 12, 16>), g1, dim3(64), (D + 2) * 16 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                                a.alpha_eff, 0, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
-                               a.search_stats);
+                               a.search_stats, a.active);
             hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                                a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
             return;
         }
         const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
-        dim3 g2((a.max_n + 63) / 64, a.n_scans);
+        dim3 g2((a.max_n + 63) / 64, n_launch);
 #define LOCGPU_WALK_LAUNCH(M) hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, M>), g2, dim3(64), DF * 64 * 8 + wpad, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, \
                                                  a.max_n, a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count,       \
-                                                 a.redo_list2, a.redo_count2, a.search_stats)
+                                                 a.redo_list2, a.redo_count2, a.search_stats, a.active)
         if (mode == 2) LOCGPU_WALK_LAUNCH(2);
         else if (mode == 12) LOCGPU_WALK_LAUNCH(12);
         else LOCGPU_WALK_LAUNCH(0);
@@ -1019,16 +1024,16 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
     // The plane kernel's reduction is cheap (LDS rows, see there): 4 is as good as 8 and leaves a finer tail; the line and point
     // kernels still pay a 28-value wave reduction per block.
     static const int forced = [] { const char* e = getenv("LOCGPU_PLANE_PTS"); return e ? atoi(e) : 0; }();
-    const long total_blocks = (long)blocks * a.n_scans;
+    const long total_blocks = (long)blocks * a.n_scans;  // ALL scans of the batch, open or not: the split — hence the order of the sums — must not depend on a.active
     int pts = forced > 0 ? forced : (total_blocks >= 8192 ? (method == 2 ? 4 : 8) : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1)));
     if (pts > 8) pts = 8;
-    const dim3 grid((blocks + pts - 1) / pts, a.n_scans);
+    const dim3 grid((blocks + pts - 1) / pts, a.active ? a.n_active : a.n_scans);
     if (method == 2)
-        hipLaunchKernelGGL(icp_plane_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts);
+        hipLaunchKernelGGL(icp_plane_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
     else if (method == 1)
-        hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts);
+        hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
     else
-        hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts);
+        hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
     return (int)grid.x;
 }
 

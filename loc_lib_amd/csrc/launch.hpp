@@ -27,6 +27,11 @@ struct SearchArgs {
     uint32_t* redo_list2;              // grid mode: first pass → second pass
     unsigned int* redo_count2;
     unsigned long long* search_stats;  // [2] cumulative: queries searched, queries redone exactly (may be null)
+    // Later chunks of an alignment: the indices of the scans still open (device array) and their number. The hot search kernel and
+    // the accumulate kernels then run grid.y = n_active instead of n_scans blocks of early exits (a 256-scan step's last eight
+    // iterations hold a handful of scans: 460 k empty workgroups cost ≈96 µs per launch). nullptr = every scan.
+    const int* active = nullptr;
+    int n_active = 0;
 };
 
 struct AccumArgs {
@@ -39,6 +44,8 @@ struct AccumArgs {
     int max_n, n_scans;
     double gate;        // max_plane / max_line / max_nn distance
     double* partials;   // [n_scans][blocks_per_scan][kAccW]
+    const int* active = nullptr;  // see SearchArgs
+    int n_active = 0;
 };
 
 bool launch_icp_search(const SearchArgs& a, hipStream_t s);

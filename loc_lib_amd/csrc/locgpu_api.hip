@@ -125,6 +125,8 @@ static void free_batch(locgpu_batch* b) {
     if (b->h_src) (void)hipHostFree(b->h_src);
     if (b->h_state) (void)hipHostFree(b->h_state);
     if (b->h_hb) (void)hipHostFree(b->h_hb);
+    if (b->h_active) (void)hipHostFree(b->h_active);
+    if (b->d_active) (void)hipFree(b->d_active);
     delete b;
 }
 
@@ -459,6 +461,8 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, 2 * sizeof(unsigned int)), "hipMalloc redo") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_total * sizeof(PoseState)), "hipHostMalloc state") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_total * 44 * sizeof(double)), "hipHostMalloc hb") &&
+              hip_ok(ctx, hipHostMalloc((void**)&b->h_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipHostMalloc active") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipMalloc active") &&
               hip_ok(ctx, hipMemset(b->d_counts, 0, std::max(n_scans, 1) * sizeof(int)), "hipMemset counts") &&
               hip_ok(ctx, hipMemset(b->d_redo_count, 0, 2 * sizeof(unsigned int)), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
     if (!ok) { free_batch(b); return LOCGPU_ERR_OOM; }
@@ -610,6 +614,8 @@ struct IterLauncher {
     bool capturing = false;  // inside hipStreamBeginCapture: no event records
     int slot = 0;            // sharded batches: which of the chunk's exchange buffers this iteration uses
     bool replicated_on_comm_stream = false;  // the chunk's read-back must wait for the communication stream as well
+    const int* active = nullptr;  // later chunks: the local scans still open (SearchArgs::active); nullptr = all
+    int n_active = 0;
     bool launch(int do_update);
     void collect_profile();
 };
@@ -643,12 +649,14 @@ bool IterLauncher::launch(int do_update) {
         if (!ctx->tree_bounded) sa.redo_list = nullptr;                 // huge / non-finite map coordinates: exact tree kernel only
         if (grid_mode && !b->d_grid_qkey) { fail(ctx, LOCGPU_ERR_INVALID, "grid search: work list missing (ensure_grid_lists was not called)"); return false; }
         sa.redo_list2 = b->d_redo_list2;
+        sa.active = active; sa.n_active = n_active;
         const GridSearchScratch gsc{b->d_grid_qkey, b->d_grid_sorted};
         const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, gsc, s) : launch_icp_search(sa, s);
         if (!ok_search) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
         mark(true);
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
         AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
+        aa.active = active; aa.n_active = n_active;
         n_partial_blocks = launch_icp_accum(prm.method, aa, s);
     } else {
         mark(true);  // NDT has no separate search kernel: search slot stays empty
@@ -816,6 +824,21 @@ static int enqueue_chunk(locgpu_ctx* ctx, locgpu_batch* b, bool first_chunk) {
     IterLauncher it{ctx, b, P.prm, P.k, P.alpha_eff};
     it.ndt = P.ndt;
     it.ev_used = P.ev_used;
+    static const bool use_active = [] { const char* e = getenv("LOCGPU_ACTIVE_LIST"); return !e || atoi(e) != 0; }();  // 0: every chunk launches every scan (A/B)
+    if (!first_chunk && !P.ndt && b->n_scans > 1 && use_active) {
+        // The host has just read every scan's flags (align_finish): launch the search and accumulate kernels of this chunk over the
+        // local scans still open only. A 256-scan step's second and third chunk hold ≈60 and ≈5 scans; the rest used to be 1800
+        // early-exit workgroups per scan and kernel (≈96 µs per search launch for nothing). Results are the same bits: a scan's
+        // blocks do the same work wherever blockIdx.y finds it, and the accumulate kernels' split does not depend on the list.
+        int na = 0;
+        for (int i = 0; i < b->n_scans; ++i)
+            if (!b->h_state[b->first + i].done) b->h_active[na++] = i;
+        if (na > 0 && na < b->n_scans) {
+            LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_active, b->h_active, (size_t)na * sizeof(int), hipMemcpyHostToDevice, s));
+            it.active = b->d_active;
+            it.n_active = na;
+        }
+    }
     const int todo = std::min(first_chunk ? kFirstChunk : kNextChunk, P.prm.max_iteration - P.launched);
     for (int c = 0; c < todo; ++c)
         if (!it.launch(1)) return LOCGPU_ERR_NO_DEVICE;

@@ -556,6 +556,31 @@ def test_hot_search_kernel_lists_when_a_candidate_descent_outgrows_the_stack(see
         ctx.close()
 
 
+def test_later_chunks_launch_only_the_open_scans(tmp_path):
+    """After the first eight iterations the host knows which scans are still open; the following chunks launch the search and
+    accumulate kernels over those only (a device list of their indices) instead of whole grids of early exits. Same bits either way:
+    a ragged nine-scan batch whose scans need from 1 to more than 8 iterations, all three ICP methods, blocking and two in flight,
+    with the list (default) and without (LOCGPU_ACTIVE_LIST=0)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, val in (("list", "1"), ("all", "0")):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_active_list_case.py"), f], env=dict(os.environ, LOCGPU_ACTIVE_LIST=val),
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[tag] = np.load(f)
+    for name in ("plane", "line", "point"):
+        it = outs["list"][name + "_it"]
+        assert it.min() <= 8 < it.max(), (name, it)   # some scans closed in the first chunk, some did not: the list was shorter than the batch
+        assert np.array_equal(it, outs["all"][name + "_it"])
+        assert np.array_equal(outs["list"][name], outs["all"][name])
+        assert np.array_equal(outs["list"][name + "_flight"], outs["all"][name + "_flight"])
+        assert np.array_equal(outs["list"][name + "_flight"][:len(it)], outs["list"][name])
+
+
 # ----------------------------------------------------------------------------------------------- two alignments in flight
 def test_align_begin_end_two_batches_in_flight(gpu_ctx, api, small_world):
     """locgpu_*_align_batch_begin / locgpu_align_batch_end: two batches (different scans, ragged counts) begun back to back and ended
