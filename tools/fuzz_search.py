@@ -58,6 +58,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--grid", action="store_true", help="also run the exact grid search (search_mode = SEARCH_GRID_EXACT) against the exact oracle lists")
     ap.add_argument("--only", type=int, default=-1, help="run only this case of the sequence (the random stream is still consumed case by case)")
     ap.add_argument("--dump", type=str, default="", help="with --only: save the case (cloud, scan, pose) to this .npz")
     a = ap.parse_args()
@@ -108,6 +109,16 @@ def main():
                 got = ctx.debug_batch_nn(b, k)[copies - 1, :nq]
                 qq = locref.transform_points(pose, np.ascontiguousarray(scan[:, :3], dtype=np.float64)).astype(np.float32)
                 want = tree.knn(qq, k, approximate=bool(approximate), alpha=0.1)
+                if a.grid and not approximate:
+                    gopts = api.icp_opts(method=method, search_mode=api.SEARCH_GRID_EXACT)
+                    try:
+                        ctx.icp_hb_batch(b, np.stack([pose] * copies), gopts)
+                        gg = ctx.debug_batch_nn(b, k)[copies - 1, :nq]
+                        if not np.array_equal(gg, want):
+                            bad += 1
+                            print("MISMATCH (grid) case %d kind %s n %d nq %d k %d: %d lists differ" % (case, kind, n, nq, k, int(np.sum(np.any(gg != want, axis=1)))), flush=True)
+                    except api.LocGpuError as e:
+                        print("grid refused case %d kind %s: %s" % (case, kind, str(e)[:100]), flush=True)
                 if not np.array_equal(got, want):
                     bad += 1
                     print("MISMATCH case %d kind %s n %d leaves %d depth %d nq %d k %d approx %d: %d lists differ" % (
