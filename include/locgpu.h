@@ -156,7 +156,7 @@ LOCGPU_API int locgpu_icp_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const do
                                       double* out_poses, locgpu_align_stats* stats);
 LOCGPU_API int locgpu_ndt_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, double* out_poses,
                                       locgpu_align_stats* stats);
-/* The same alignments in two halves, for a caller that keeps TWO batches in flight (no reference counterpart: the reference
+/* The same alignments in two halves, for a caller that keeps several batches in flight — up to three pay — (no reference counterpart: the reference
  * matches one scan at a time). The batches of a context are dealt to three compute streams in turn; *_begin copies the poses,
  * enqueues the first eight Gauss–Newton iterations on the batch's stream and returns, locgpu_align_batch_end waits for them,
  * enqueues further iterations while scans are still open and writes the results. Begun on batch B while batch A is not yet
