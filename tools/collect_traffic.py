@@ -38,10 +38,11 @@ def main():
     ap.add_argument("--scans-per-gpu", type=int, default=256)
     ap.add_argument("--map-points", type=int, default=10_000_000)
     ap.add_argument("--method", default="p2plane")
+    ap.add_argument("--search", default="tree", choices=["tree", "tree_exact", "grid"])
     ap.add_argument("--workdir", default=os.path.join(ROOT, "gpurun_out", "traffic"))
     a = ap.parse_args()
     bench_args = ["--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--traffic", "none", "--scans-per-gpu", str(a.scans_per_gpu), "--map-points",
-                  str(a.map_points), "--method", a.method]
+                  str(a.map_points), "--method", a.method, "--search", a.search]
     fetch = run_pass("FETCH_SIZE", os.path.join(a.workdir, "fetch"), bench_args)
     write = run_pass("WRITE_SIZE", os.path.join(a.workdir, "write"), bench_args)
     kernels = {}
@@ -49,11 +50,11 @@ def main():
         f, nf = fetch.get(k, (0.0, 0))
         w, _ = write.get(k, (0.0, 0))
         kernels[k] = dict(dispatches=nf, FETCH_SIZE_KiB=round(f, 2), WRITE_SIZE_KiB=round(w, 2), traffic_bytes_per_launch=int((2 * f + w) * 1024))
-    out = dict(config=dict(scans_per_gpu=a.scans_per_gpu, map_points=a.map_points, method=a.method),
+    out = dict(config=dict(scans_per_gpu=a.scans_per_gpu, map_points=a.map_points, method=a.method, search=a.search),
                formula="(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per dispatch (gfx950 FETCH_SIZE half-count correction)", kernels=kernels)
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
-    print(json.dumps({k: v for k, v in kernels.items() if "icp_" in k or "ndt_" in k or "gn_" in k}))
+    print(json.dumps({k: v for k, v in kernels.items() if "icp_" in k or "ndt_" in k or "gn_" in k or "grid_" in k}))
 
 
 if __name__ == "__main__":
