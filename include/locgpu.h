@@ -104,6 +104,10 @@ LOCGPU_API int locgpu_device_count(void);
 /* ---- ICP target: IcpRegistration::SetInputTarget (icp_registration.cpp:9-29) →
  *      KdtreeRegistration::SetTargetCloud / KdTree::BuildTree (kdtree.cpp:261-270, 10-31). Host pointer. */
 LOCGPU_API int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes);
+/* The same with the host tree build on a worker thread: returns once the points have been copied (the deep copy the reference makes,
+ * icp_registration.cpp:16); the first entry point that reads the ICP target completes the ingest on the caller's thread and reports
+ * its errors. See locgpu_icp_set_target_cloud_async. */
+LOCGPU_API int locgpu_icp_set_target_async(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes);
 /* out[0]=leaves (KdTree::size_), out[1]=tree nodes, out[2]=depth, out[3]=bytes of the packed tree in HBM */
 LOCGPU_API int locgpu_icp_target_info(const locgpu_ctx* ctx, int64_t out[4]);
 
@@ -284,6 +288,12 @@ LOCGPU_API int locgpu_cloud_append(locgpu_cloud* dst, const locgpu_cloud* src);
 
 /* The matcher entry points on resident clouds (same semantics as their host-pointer versions above). */
 LOCGPU_API int locgpu_icp_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* target);
+/* The same SetInputTarget (icp_registration.cpp:14-22; Lio re-ingests its local map every keyframe, lio.cpp:296-305) with the host
+ * tree build on a worker thread: returns once the cloud has been copied out (the caller may change or free it), the build runs while
+ * the caller uploads and filters the next scan, and the first entry point that reads the ICP target — an align, H/B, k-NN,
+ * target_info — completes the ingest (device buffers, copy) on the caller's thread and reports its errors. Until then the previous
+ * target stays in place; another SetInputTarget supersedes a pending one. Results are those of locgpu_icp_set_target_cloud. */
+LOCGPU_API int locgpu_icp_set_target_cloud_async(locgpu_ctx* ctx, const locgpu_cloud* target);
 LOCGPU_API int locgpu_ndt_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* target, const locgpu_ndt_opts* opts);
 LOCGPU_API int locgpu_icp_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const double init_pose[7], const locgpu_icp_opts* opts,
                                       double out_pose[7], locgpu_align_stats* stats);

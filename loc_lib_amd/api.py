@@ -24,14 +24,14 @@ DIRECT_NDT, INCREMENTAL_NDT = 1, 2
 # every symbol include/locgpu.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "locgpu_icp_opts_default", "locgpu_ndt_opts_default", "locgpu_create", "locgpu_destroy", "locgpu_last_error",
-    "locgpu_device_count", "locgpu_icp_set_target", "locgpu_icp_target_info", "locgpu_knn", "locgpu_icp_hb", "locgpu_icp_align",
+    "locgpu_device_count", "locgpu_icp_set_target", "locgpu_icp_set_target_async", "locgpu_icp_target_info", "locgpu_knn", "locgpu_icp_hb", "locgpu_icp_align",
     "locgpu_transform_cloud", "locgpu_batch_create", "locgpu_batch_destroy", "locgpu_icp_align_batch", "locgpu_ndt_align_batch",
     "locgpu_icp_hb_batch", "locgpu_gn_update", "locgpu_ndt_set_target", "locgpu_ndt_target_info", "locgpu_ndt_dump",
     "locgpu_ndt_align", "locgpu_profile_enable", "locgpu_profile_read", "locgpu_visit_count_enable", "locgpu_visit_count_read",
     "locgpu_search_stats_read", "locgpu_debug_batch_nn", "locgpu_graph_enable",
     "locgpu_cloud_create", "locgpu_cloud_destroy", "locgpu_cloud_upload", "locgpu_cloud_info", "locgpu_cloud_download", "locgpu_cloud_copy",
     "locgpu_cloud_remove_nan", "locgpu_cloud_voxel_filter", "locgpu_cloud_crop_box", "locgpu_cloud_transform", "locgpu_cloud_append",
-    "locgpu_icp_set_target_cloud", "locgpu_ndt_set_target_cloud", "locgpu_icp_align_cloud", "locgpu_ndt_align_cloud",
+    "locgpu_icp_set_target_cloud", "locgpu_icp_set_target_cloud_async", "locgpu_ndt_set_target_cloud", "locgpu_icp_align_cloud", "locgpu_ndt_align_cloud",
     "locgpu_voxel_filter", "locgpu_crop_box", "locgpu_remove_nan",
     "locgpu_submap_create", "locgpu_submap_destroy", "locgpu_submap_add_keyframe", "locgpu_submap_cloud", "locgpu_submap_last_keyframe",
     "locgpu_submap_info", "locgpu_cloud_loam_extract", "locgpu_loam_extract",
@@ -91,7 +91,7 @@ def lib():
             "locgpu_icp_opts_default": (None, [vp]), "locgpu_ndt_opts_default": (None, [vp]),
             "locgpu_create": (i32, [i32, vp]), "locgpu_destroy": (None, [vp]), "locgpu_last_error": (ctypes.c_char_p, [vp]),
             "locgpu_device_count": (i32, []),
-            "locgpu_icp_set_target": (i32, [vp, vp, sz, sz]), "locgpu_icp_target_info": (i32, [vp, vp]),
+            "locgpu_icp_set_target": (i32, [vp, vp, sz, sz]), "locgpu_icp_set_target_async": (i32, [vp, vp, sz, sz]), "locgpu_icp_target_info": (i32, [vp, vp]),
             "locgpu_knn": (i32, [vp, vp, sz, i32, i32, f32, i32, vp, vp]),
             "locgpu_icp_hb": (i32, [vp, vp, sz, sz, vp, vp, vp, vp, vp, vp]),
             "locgpu_icp_align": (i32, [vp, vp, sz, sz, vp, vp, vp, vp]),
@@ -113,7 +113,7 @@ def lib():
             "locgpu_cloud_remove_nan": (i32, [vp, vp]), "locgpu_cloud_voxel_filter": (i32, [vp, f32, vp, vp]),
             "locgpu_cloud_crop_box": (i32, [vp, vp, vp, vp]), "locgpu_cloud_transform": (i32, [vp, vp, vp]),
             "locgpu_cloud_append": (i32, [vp, vp]),
-            "locgpu_icp_set_target_cloud": (i32, [vp, vp]), "locgpu_ndt_set_target_cloud": (i32, [vp, vp, vp]),
+            "locgpu_icp_set_target_cloud": (i32, [vp, vp]), "locgpu_icp_set_target_cloud_async": (i32, [vp, vp]), "locgpu_ndt_set_target_cloud": (i32, [vp, vp, vp]),
             "locgpu_icp_align_cloud": (i32, [vp, vp, vp, vp, vp, vp]), "locgpu_ndt_align_cloud": (i32, [vp, vp, vp, vp, vp]),
             "locgpu_voxel_filter": (i32, [vp, vp, sz, sz, sz, i32, f32, vp, vp, vp]),
             "locgpu_crop_box": (i32, [vp, vp, sz, sz, sz, i32, vp, vp, vp, vp, vp]),
@@ -213,9 +213,12 @@ class Context:
             raise LocGpuError(rc, lib().locgpu_last_error(self._h).decode())
 
     # ---- IcpRegistration::SetInputTarget
-    def icp_set_target(self, cloud):
+    def icp_set_target(self, cloud, wait=True):
+        """wait=False: returns once the points are copied; the host tree build runs on a worker thread and the next call that reads
+        the ICP target completes the ingest."""
         c = _cloud(cloud)
-        self._check(lib().locgpu_icp_set_target(self._h, c.ctypes.data, c.shape[0], c.strides[0]))
+        fn = lib().locgpu_icp_set_target if wait else lib().locgpu_icp_set_target_async
+        self._check(fn(self._h, c.ctypes.data, c.shape[0], c.strides[0]))
 
     def icp_target_info(self):
         out = np.zeros(4, dtype=np.int64)
@@ -299,8 +302,10 @@ class Context:
         return edge[:ne.value].copy(), surf[:ns.value].copy()
 
     # ---- matcher entry points on resident clouds
-    def icp_set_target_cloud(self, cloud):
-        self._check(lib().locgpu_icp_set_target_cloud(self._h, cloud._h))
+    def icp_set_target_cloud(self, cloud, wait=True):
+        """wait=False: the host tree build runs on a worker thread; the next call that reads the ICP target completes the ingest."""
+        fn = lib().locgpu_icp_set_target_cloud if wait else lib().locgpu_icp_set_target_cloud_async
+        self._check(fn(self._h, cloud._h))
 
     def ndt_set_target_cloud(self, cloud, opts=None):
         self._check(lib().locgpu_ndt_set_target_cloud(self._h, cloud._h, ctypes.byref(opts) if opts is not None else None))

@@ -14,6 +14,8 @@
 struct NdtTable;  // ndt_kernels.hpp
 namespace locgpu { struct IncNdtState; struct FilterScratch; }  // ndt_inc.hpp, cloud_filters.hpp
 
+namespace locgpu { struct PendingTarget; }
+
 struct locgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;  // = slot_stream[0]: target ingest, clouds, single-scan calls
@@ -27,6 +29,7 @@ struct locgpu_ctx {
     hipStream_t copy_stream = nullptr;  // host → HBM copies of the batch uploader
     hipStream_t comm_stream = nullptr;  // every collective of the context, in host order (one communicator, one stream: no two at once)
     locgpu::Uploader* up = nullptr;     // host → HBM staging shared by the context's batches (batch_upload.hpp)
+    locgpu::PendingTarget* pending_target = nullptr;  // locgpu_icp_set_target_cloud_async: a host tree build still running (locgpu_api.hip)
     std::string err;
 
     // ICP target: packed KD-tree in HBM (kdtree_build.cpp layout)

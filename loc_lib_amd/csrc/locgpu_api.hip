@@ -130,6 +130,8 @@ static void free_batch(locgpu_batch* b) {
     delete b;
 }
 
+static int target_join(locgpu_ctx* ctx, bool install = true);  // finishes a pending locgpu_icp_set_target_cloud_async (defined with it, below)
+
 extern "C" {
 
 void locgpu_icp_opts_default(locgpu_icp_opts* o) {
@@ -200,6 +202,7 @@ int locgpu_create(int device_id, locgpu_ctx** out) {
 void locgpu_destroy(locgpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)target_join(ctx, false);
     for (hipStream_t st : ctx->slot_stream) if (st) (void)hipStreamSynchronize(st);
     if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
     free_batch(ctx->single);
@@ -271,8 +274,54 @@ static hipError_t write_sentinel_leaf(locgpu_ctx* ctx) {
     return hipMemcpyAsync(ctx->d_tree + ctx->tree_slots, leaf, sizeof(leaf), hipMemcpyHostToDevice, ctx->stream);
 }
 
+// ---- SetInputTarget with the host build off the caller's thread (locgpu_icp_set_target_cloud_async) ----
+// The mean-split tree is built on the host (its float32 sums are sequential by definition), 0.5–0.7 ms for a 35 k-pt local map. A
+// streaming front-end that re-ingests its local map every keyframe (lio.cpp:296-305) has work to do in the meantime — upload and
+// filter the next scan — so the build may run on a worker thread. Only the BUILD does: the worker touches its own copy of the points,
+// its own PackedKdTree and the process-wide build pool, nothing of HIP and nothing of the context; every HIP call of the ingest
+// (buffers, H2D, sentinel) is made by the caller's thread in target_join(), which every entry point that reads the target calls first.
+namespace locgpu {
+struct PendingTarget {
+    std::thread worker;
+    std::vector<float> xyz;
+    PackedKdTree tree;
+    std::string err;
+    bool ok = false;
+};
+}  // namespace locgpu
+
+static int install_built_tree(locgpu_ctx* ctx, const PackedKdTree& t) {
+    const long long meta[6] = {(long long)t.slots.size(), (long long)t.num_leaves, (long long)t.num_nodes, (long long)t.num_points, t.depth, t.bounded ? 1 : 0};
+    const int rc = install_tree_meta(ctx, meta);
+    if (rc != LOCGPU_OK) return rc;
+    LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_leaf_slots, t.leaf_slots.data(), t.leaf_slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    LOCGPU_HIP(ctx, write_sentinel_leaf(ctx));
+    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LOCGPU_OK;
+}
+
+// Finishes a pending asynchronous ingest (no-op without one). install = false: only wait for the worker (context teardown, or a new
+// target that supersedes the pending one).
+static int target_join(locgpu_ctx* ctx, bool install) {
+    if (!ctx || !ctx->pending_target) return LOCGPU_OK;
+    locgpu::PendingTarget* p = ctx->pending_target;
+    ctx->pending_target = nullptr;
+    if (p->worker.joinable()) p->worker.join();
+    int rc = LOCGPU_OK;
+    if (install) {
+        if (!p->ok) rc = fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: " + p->err);
+        else if (p->tree.depth > 64) rc = fail(ctx, LOCGPU_ERR_DEPTH, "icp_set_target: KD-tree depth " + std::to_string(p->tree.depth) + " exceeds the 64-entry traversal stack");
+        else if (hipSetDevice(ctx->device) != hipSuccess) rc = LOCGPU_ERR_NO_DEVICE;
+        else rc = install_built_tree(ctx, p->tree);
+    }
+    delete p;
+    return rc;
+}
+
 int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes) {
     if (!ctx) return LOCGPU_ERR_INVALID;
+    (void)target_join(ctx, false);  // a pending asynchronous ingest is superseded
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     static const bool times = getenv("LOCGPU_INGEST_TIMES") != nullptr;  // diagnostic: phase times on stderr
     auto t0 = std::chrono::steady_clock::now();
@@ -286,15 +335,22 @@ int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
     int rc = build_host_tree(ctx, pts, n, stride_bytes, t);
     if (rc != LOCGPU_OK) return rc;
     lap("host build");
-    const long long meta[6] = {(long long)t.slots.size(), (long long)t.num_leaves, (long long)t.num_nodes, (long long)t.num_points, t.depth, t.bounded ? 1 : 0};
-    rc = install_tree_meta(ctx, meta);
-    if (rc != LOCGPU_OK) return rc;
-    lap("device buffers");
-    LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_tree, t.slots.data(), t.slots.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    LOCGPU_HIP(ctx, hipMemcpyAsync(ctx->d_leaf_slots, t.leaf_slots.data(), t.leaf_slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    LOCGPU_HIP(ctx, write_sentinel_leaf(ctx));
-    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    lap("H2D");
+    rc = install_built_tree(ctx, t);
+    lap("device buffers + H2D");
+    return rc;
+}
+
+// The same with the host build on a worker thread (see PendingTarget): returns once the points have been copied.
+int locgpu_icp_set_target_async(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!pts || n == 0 || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: empty cloud or stride < 12");
+    (void)target_join(ctx, false);  // an earlier pending ingest is superseded
+    auto* p = new locgpu::PendingTarget();
+    p->xyz.resize(3 * n);  // the deep copy of SetInputTarget (icp_registration.cpp:16)
+    const char* base = (const char*)pts;
+    for (size_t i = 0; i < n; ++i) std::memcpy(&p->xyz[3 * i], base + i * stride_bytes, 12);
+    p->worker = std::thread([p, n] { p->ok = build_packed_kdtree(p->xyz.data(), n, p->tree, p->err); });
+    ctx->pending_target = p;
     return LOCGPU_OK;
 }
 
@@ -304,6 +360,7 @@ int locgpu_icp_set_target_bcast(locgpu_ctx* ctx, const void* pts, size_t n, size
     if (!ctx) return LOCGPU_ERR_INVALID;
     if (!ctx->comm) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target_bcast: locgpu_comm_init has not been called");
     if (root < 0 || root >= ctx->comm_world) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target_bcast: bad root");
+    (void)target_join(ctx, false);  // a pending asynchronous ingest is superseded
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     hipStream_t s = ctx->stream;
@@ -351,6 +408,7 @@ int locgpu_icp_set_target_bcast(locgpu_ctx* ctx, const void* pts, size_t n, size
 
 int locgpu_icp_target_info(const locgpu_ctx* ctx, int64_t out[4]) {
     if (!ctx || !out) return LOCGPU_ERR_INVALID;
+    { const int jrc = target_join(const_cast<locgpu_ctx*>(ctx)); if (jrc != LOCGPU_OK) return jrc; }
     out[0] = (int64_t)ctx->num_leaves;
     out[1] = (int64_t)ctx->num_nodes;
     out[2] = ctx->depth;
@@ -362,6 +420,7 @@ int locgpu_icp_target_info(const locgpu_ctx* ctx, int64_t out[4]) {
 int locgpu_knn(locgpu_ctx* ctx, const float* queries, size_t nq, int k, int approximate, float alpha, int search_mode, int32_t* out_idx,
                uint32_t* visits) {
     if (!ctx) return LOCGPU_ERR_INVALID;
+    { const int jrc = target_join(ctx); if (jrc != LOCGPU_OK) return jrc; }
     if (!ctx->d_tree) return fail(ctx, LOCGPU_ERR_NO_TARGET, "knn: no target set");
     if (!queries || !out_idx || k < 1 || k > 8) return fail(ctx, LOCGPU_ERR_INVALID, "knn: bad arguments (1 <= k <= 8)");
     if (search_mode != LOCGPU_SEARCH_TREE_FAITHFUL && search_mode != LOCGPU_SEARCH_GRID_EXACT) return fail(ctx, LOCGPU_ERR_INVALID, "knn: unknown search mode");
@@ -927,6 +986,7 @@ static void write_results(locgpu_batch* b, const double* init_poses, double* out
 static int check_icp(locgpu_ctx* ctx, const locgpu_icp_opts* o, GnParams& prm, int& k, float& alpha_eff) {
     if (!ctx) return LOCGPU_ERR_INVALID;
     if (!o) return fail(ctx, LOCGPU_ERR_INVALID, "icp: opts is NULL");
+    { const int jrc = target_join(ctx); if (jrc != LOCGPU_OK) return jrc; }  // an asynchronous SetInputTarget ends here at the latest
     if (!ctx->d_tree) return fail(ctx, LOCGPU_ERR_NO_TARGET, "icp: SetInputTarget has not been called");
     if (o->method < LOCGPU_P2P || o->method > LOCGPU_P2PLANE) return fail(ctx, LOCGPU_ERR_INVALID, "icp: unknown method");
     if (o->search_mode != LOCGPU_SEARCH_TREE_FAITHFUL && o->search_mode != LOCGPU_SEARCH_GRID_EXACT)
@@ -1067,6 +1127,7 @@ int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* poses, c
 
 int locgpu_debug_batch_nn(locgpu_ctx* ctx, locgpu_batch* b, int k, int32_t* out) {
     if (!ctx || !b || b->ctx != ctx || !out || k < 1 || k > 5) return fail(ctx, LOCGPU_ERR_INVALID, "debug_batch_nn: bad arguments");
+    { const int jrc = target_join(ctx); if (jrc != LOCGPU_OK) return jrc; }
     if (!ctx->d_tree) return fail(ctx, LOCGPU_ERR_NO_TARGET, "debug_batch_nn: no ICP target");
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nq = (size_t)b->n_scans * b->max_n;
@@ -1258,7 +1319,7 @@ extern "C" __attribute__((visibility("default"))) int locgpu_debug_stamp_trips(l
 // 140-byte TileRec records; hash: {tile_lin, record} × capacity. Returns the number of grid points (0 on failure).
 extern "C" __attribute__((visibility("default"))) size_t locgpu_debug_grid_dump(locgpu_ctx* ctx, int64_t info[9], float params[6], float* pts, size_t pts_cap,
                                                                                  void* tiles, size_t tiles_cap_bytes, uint32_t* hash, size_t hash_cap) {
-    if (!ctx || !ctx->d_tree || ensure_grid(ctx) != LOCGPU_OK) return 0;
+    if (!ctx || target_join(ctx) != LOCGPU_OK || !ctx->d_tree || ensure_grid(ctx) != LOCGPU_OK) return 0;
     const locgpu::GridView& g = ctx->grid;
     if (info) {
         for (int a = 0; a < 3; ++a) { info[a] = g.dims[a]; info[6 + a] = g.tdims[a]; }
@@ -1412,6 +1473,7 @@ int locgpu_icp_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* target) {
     if (!ctx) return LOCGPU_ERR_INVALID;
     if (!target || target->ctx != ctx) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target_cloud: bad cloud");
     if (target->n == 0) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: empty cloud or stride < 12");
+    (void)target_join(ctx, false);  // a pending asynchronous ingest is superseded
     // The mean-split tree is built on the host (its float32 sums are sequential by definition, kdtree.cpp:94-123), so the
     // cloud crosses PCIe once in each direction: 16 B/point down, the packed tree (≈24 B/point) up.
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
@@ -1420,6 +1482,25 @@ int locgpu_icp_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* target) {
     LOCGPU_HIP(ctx, hipMemcpyAsync(stage, target->d, target->n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return locgpu_icp_set_target(ctx, stage, target->n, sizeof(float4));
+}
+
+int locgpu_icp_set_target_cloud_async(locgpu_ctx* ctx, const locgpu_cloud* target) {
+    if (!ctx) return LOCGPU_ERR_INVALID;
+    if (!target || target->ctx != ctx) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target_cloud: bad cloud");
+    if (target->n == 0) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: empty cloud or stride < 12");
+    (void)target_join(ctx, false);  // an earlier pending ingest is superseded
+    LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    float4* stage = nullptr;
+    if (!hip_ok(ctx, cloud_stage(ctx, target->n, &stage), "pinned staging")) return LOCGPU_ERR_OOM;
+    LOCGPU_HIP(ctx, hipMemcpyAsync(stage, target->d, target->n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto* p = new locgpu::PendingTarget();
+    p->xyz.resize(3 * target->n);  // the deep copy of SetInputTarget (icp_registration.cpp:16): the staging block is free again after it
+    for (size_t i = 0; i < target->n; ++i) std::memcpy(&p->xyz[3 * i], &stage[i], 12);
+    const size_t n = target->n;
+    p->worker = std::thread([p, n] { p->ok = build_packed_kdtree(p->xyz.data(), n, p->tree, p->err); });
+    ctx->pending_target = p;
+    return LOCGPU_OK;
 }
 
 int locgpu_ndt_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* target, const locgpu_ndt_opts* opts) {

@@ -78,8 +78,8 @@ def test_batch_256_scans_vs_10m(gpu_ctx, api, locref, synth, world10m):
 
 
 # ----------------------------------------------------------------------------------------------- configs[4]
-@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
-def test_streaming_loop_matches_oracle(api, locref, synth, graph):
+@pytest.mark.parametrize("graph,async_target", [(False, False), (True, False), (False, True)], ids=["eager", "hipgraph", "async_target"])
+def test_streaming_loop_matches_oracle(api, locref, synth, graph, async_target):
     """Lio::AddCloud's loop (lio.cpp:236-306) composed from the resident entry points: 10 scans, keyframe every 3rd, at most 3
     keyframes in the local map (so the drop-oldest-and-rebuild branch runs), every pose and every local map equal to the oracle's."""
     ctx = api.Context(0)
@@ -110,7 +110,7 @@ def test_streaming_loop_matches_oracle(api, locref, synth, graph):
                 kf_src, kf_dense = raw, False                     # later keyframes keep the RAW scan (lio.cpp:279)
             if s % 3 == 0:
                 sub.add_keyframe(kf_src, pose)
-                ctx.icp_set_target_cloud(sub.cloud())
+                ctx.icp_set_target_cloud(sub.cloud(), wait=not async_target)  # async: the tree is built under the next scan's upload + filter
                 lm.add_keyframe(locref.transform_cloud_f64(pose, kf_src.download(), is_dense=kf_dense), is_dense=kf_dense)
                 icp_ref.set_target(lm.cloud()[:, :3])
                 assert np.array_equal(sub.cloud().download(), lm.cloud(), equal_nan=True)

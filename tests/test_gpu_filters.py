@@ -306,3 +306,54 @@ def test_voxel_filter_of_a_non_dense_cloud_equals_remove_nan_then_filter(gpu_ctx
     wide[2, :3] = -3.0e5
     through = api.Cloud(gpu_ctx, wide, is_dense=True).voxel_filter(0.01)  # 6e7 cells per axis: "leaf size is too small"
     assert np.array_equal(through.download(), wide)
+
+def test_async_target_ingest_equals_the_blocking_one(api, locref, synth, small_world):
+    """locgpu_icp_set_target_cloud_async: the host tree build runs on a worker while the caller goes on (here: uploads and filters a
+    scan, as Lio::AddCloud would between a keyframe and the next ScanMatch); the first reader of the target completes the ingest.
+    Same tree (target_info) and same pose as the blocking call; the next reader always sees the new target; a second SetInputTarget
+    supersedes a pending one; target_info alone completes one; a context destroyed with an ingest pending shuts down cleanly."""
+    m, s, init = small_world["map"], small_world["scan10k"], small_world["init_pose"]
+    opts = api.icp_opts(method=api.P2PLANE)
+
+    def cloud4(a):
+        out = np.zeros((len(a), 4), np.float32)
+        out[:, :3] = a[:, :3]
+        return out
+
+    ctx = api.Context(0)
+    try:
+        big, small = api.Cloud(ctx, cloud4(m)), api.Cloud(ctx, cloud4(m[::7]))
+        ctx.icp_set_target_cloud(big)
+        want_info = ctx.icp_target_info()
+        want_pose, want_st = ctx.icp_align(s, init, opts)
+        ctx.icp_set_target_cloud(small)
+        small_info = ctx.icp_target_info()
+        small_pose, _ = ctx.icp_align(s, init, opts)
+        assert small_info != want_info
+        for rep in range(3):
+            ctx.icp_set_target_cloud(small)                       # something else in place first
+            ctx.icp_set_target_cloud(big, wait=False)             # returns with the build running
+            raw = api.Cloud(ctx, cloud4(s))                       # the caller's own work in the meantime
+            raw.voxel_filter(0.5)
+            pose, st = ctx.icp_align(s, init, opts)               # completes the ingest first
+            assert np.array_equal(pose, want_pose) and st["iterations"] == want_st["iterations"]
+            assert ctx.icp_target_info() == want_info
+        # superseded: async(big) then blocking(small) ⇒ small wins, whenever the worker finishes
+        ctx.icp_set_target_cloud(big, wait=False)
+        ctx.icp_set_target_cloud(small)
+        assert ctx.icp_target_info() == small_info
+        assert np.array_equal(ctx.icp_align(s, init, opts)[0], small_pose)
+        # target_info alone completes a pending ingest
+        ctx.icp_set_target_cloud(big, wait=False)
+        assert ctx.icp_target_info() == want_info
+        # the host-pointer version: the caller's array may be overwritten as soon as the call returns
+        mm = np.ascontiguousarray(m, dtype=np.float32).copy()
+        ctx.icp_set_target(mm, wait=False)
+        mm[:] = 0.0
+        assert ctx.icp_target_info() == want_info
+        assert np.array_equal(ctx.icp_align(s, init, opts)[0], want_pose)
+        with pytest.raises(api.LocGpuError):
+            ctx.icp_set_target(np.zeros((0, 3), np.float32), wait=False)
+        ctx.icp_set_target_cloud(small, wait=False)               # left pending: destroy must cope
+    finally:
+        ctx.close()
