@@ -292,7 +292,8 @@ LOCGPU_API int locgpu_icp_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* 
  * tree build on a worker thread: returns once the cloud has been copied out (the caller may change or free it), the build runs while
  * the caller uploads and filters the next scan, and the first entry point that reads the ICP target — an align, H/B, k-NN,
  * target_info — completes the ingest (device buffers, copy) on the caller's thread and reports its errors. Until then the previous
- * target stays in place; another SetInputTarget supersedes a pending one. Results are those of locgpu_icp_set_target_cloud. */
+ * target stays in place; another SetInputTarget supersedes a pending one. Like every SetInputTarget it must not be called between a
+ * locgpu_*_align_batch_begin and its end. Results are those of locgpu_icp_set_target_cloud. */
 LOCGPU_API int locgpu_icp_set_target_cloud_async(locgpu_ctx* ctx, const locgpu_cloud* target);
 LOCGPU_API int locgpu_ndt_set_target_cloud(locgpu_ctx* ctx, const locgpu_cloud* target, const locgpu_ndt_opts* opts);
 LOCGPU_API int locgpu_icp_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const double init_pose[7], const locgpu_icp_opts* opts,
