@@ -203,7 +203,7 @@ hipError_t ndt_build(NdtTable& t, const float4* d_pts, size_t n, double voxel_si
 
 // ---------------------------------------------------------------------------------------------
 // K5. Grid (ceil(max_n/256), n_scans).
-__global__ __launch_bounds__(kBlock) void ndt_accum_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ vid,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void ndt_accum_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ vid,
                                                            const double* __restrict__ mu, const double* __restrict__ info, size_t cap_mask,
                                                            double inv_voxel, double res_th, int n_nearby, const float4* __restrict__ src,
                                                            const int* __restrict__ counts, const PoseState* __restrict__ st, int max_n,
@@ -226,19 +226,44 @@ __global__ __launch_bounds__(kBlock) void ndt_accum_kernel(const unsigned long l
         const int ox[7] = {0, -1, 1, 0, 0, 0, 0}, oy[7] = {0, 0, 0, 1, -1, 0, 0}, oz[7] = {0, 0, 0, 0, 0, -1, 1};
         double n_acc = 0.0;
         D3 esum{0.0, 0.0, 0.0};
-        for (int j = 0; j < n_nearby; ++j) {
+        // The seven voxels of a point are independent look-ups, each a chain of dependent gathers (hash slot → voxel index → μ, info).
+        // Written as a loop with `continue`, they ran one after the other — 21 memory latencies per point at four waves per SIMD.
+        // Here every level is issued for all seven before the next one is needed (first probe of the open-addressing table for all,
+        // then the few collisions one by one, then the indices, then the records), and the acceptance test is a select; the sums
+        // are formed in the reference's order j = 0..6 from the same numbers, so the result is the same bits.
+        unsigned long long key[7], kk[7];
+        size_t hs[7];
+        bool found[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
             const int x = kx + ox[j], y = ky + oy[j], z = kz + oz[j];
-            if (!ndt_key_in_range(x, y, z)) continue;
-            const unsigned long long key = ndt_pack(x, y, z);
-            size_t h = ndt_hash(key, cap_mask);
-            int v = -1;
-            for (;;) {
-                const unsigned long long kk = keys[h];
-                if (kk == key) { v = vid[h]; break; }
-                if (kk == kNdtEmpty) break;
-                h = (h + 1) & cap_mask;
+            found[j] = j < n_nearby && ndt_key_in_range(x, y, z);
+            key[j] = ndt_pack(found[j] ? x : kx, found[j] ? y : ky, found[j] ? z : kz);
+            hs[j] = ndt_hash(key[j], cap_mask);
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) kk[j] = keys[hs[j]];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            if (found[j] && kk[j] != key[j] && kk[j] != kNdtEmpty) {  // collision on the first probe: walk on (load factor ≤ 0.5)
+                size_t h = (hs[j] + 1) & cap_mask;
+                for (;;) {
+                    const unsigned long long k2 = keys[h];
+                    if (k2 == key[j]) { kk[j] = k2; hs[j] = h; break; }
+                    if (k2 == kNdtEmpty) { kk[j] = k2; break; }
+                    h = (h + 1) & cap_mask;
+                }
             }
-            if (v < 0) continue;
+            found[j] = found[j] && kk[j] == key[j];
+        }
+        int vx[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) vx[j] = vid[found[j] ? hs[j] : 0];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) found[j] = found[j] && vx[j] >= 0;  // −1: a voxel that was dropped for having too few points (ndt cpp:136-142)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int v = found[j] ? vx[j] : 0;  // a voxel that is not there reads record 0 and is not accepted
             const double* m = mu + 3 * (size_t)v;
             const double* I = info + 9 * (size_t)v;
             const D3 e{qs.x - m[0], qs.y - m[1], qs.z - m[2]};
@@ -248,9 +273,11 @@ __global__ __launch_bounds__(kBlock) void ndt_accum_kernel(const unsigned long l
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) res += ev[r] * I[3 * r + c] * ev[c];
-            if (isnan(res) || res > res_th) continue;
-            n_acc += 1.0;
-            esum = esum + e;
+            const bool accept = found[j] && !(isnan(res) || res > res_th);
+            n_acc = accept ? n_acc + 1.0 : n_acc;
+            esum.x = accept ? esum.x + e.x : esum.x;
+            esum.y = accept ? esum.y + e.y : esum.y;
+            esum.z = accept ? esum.z + e.z : esum.z;
         }
         acc[27] += 1.0;  // effective_num++ once per source point (ndt cpp:432)
         if (n_acc > 0.0) {
@@ -262,29 +289,42 @@ __global__ __launch_bounds__(kBlock) void ndt_accum_kernel(const unsigned long l
                 Rh[r][1] = R[3 * r + 2] * q.x - R[3 * r + 0] * q.z;
                 Rh[r][2] = R[3 * r + 0] * q.y - R[3 * r + 1] * q.x;
             }
-            double J[3][6];
+            // J = [A | I3] with A = −R·hat(q) (ndt cpp:413-416). The reference forms JᵀJ and Jᵀe entry by entry; with the identity block
+            // written out, ((J0a·J0b) + J1a·J1b) + J2a·J2b is A's column product for a, b < 3, the element A[b−3][a] for a < 3 ≤ b (the
+            // two products with 0.0 add nothing), 1 on the rest of the diagonal and 0 elsewhere — the same sums bit for bit (up to the
+            // sign of a zero), a third of the FP64 instructions: x·0.0 is not something the compiler may drop on its own.
+            double A[3][3];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { J[r][c] = -Rh[r][c]; J[r][3 + c] = (r == c) ? 1.0 : 0.0; }
+                for (int c = 0; c < 3; ++c) A[r][c] = -Rh[r][c];
             const double ev[3] = {esum.x, esum.y, esum.z};
             int o = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
                 for (int b = a; b < 6; ++b) {
-                    double s = J[0][a] * J[0][b];
-                    s += J[1][a] * J[1][b];
-                    s += J[2][a] * J[2][b];
-                    acc[o++] += n_acc * s;  // the same J for every accepted voxel of this point
+                    if (a < 3 && b < 3) {
+                        double s = A[0][a] * A[0][b];
+                        s += A[1][a] * A[1][b];
+                        s += A[2][a] * A[2][b];
+                        acc[o] += n_acc * s;  // the same J for every accepted voxel of this point
+                    } else if (a < 3) {
+                        acc[o] += n_acc * A[b - 3][a];
+                    } else if (a == b) {
+                        acc[o] += n_acc;
+                    }
+                    ++o;
                 }
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                double s = -J[0][a] * ev[0];
-                s += -J[1][a] * ev[1];
-                s += -J[2][a] * ev[2];
+            for (int a = 0; a < 3; ++a) {
+                double s = -A[0][a] * ev[0];
+                s += -A[1][a] * ev[1];
+                s += -A[2][a] * ev[2];
                 acc[21 + a] += s;
             }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[24 + c] += -ev[c];
         }
     }
     }
