@@ -103,7 +103,7 @@ __global__ void inc_fill_kernel(unsigned long long* p, size_t n, unsigned long l
 
 // ---------------------------------------------------------------------------------------------- accumulate kernel
 // Grid (ceil(max_n/256), n_scans). acc[27] = number of accepted (point, voxel) residuals.
-__global__ __launch_bounds__(kBlock) void inc_accum_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ vid,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void inc_accum_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ vid,
                                                            const double* __restrict__ mu, const double* __restrict__ info, size_t cap_mask,
                                                            double inv_voxel, double res_th, int n_nearby, const float4* __restrict__ src,
                                                            const int* __restrict__ counts, const PoseState* __restrict__ st, int max_n,
@@ -122,19 +122,41 @@ __global__ __launch_bounds__(kBlock) void inc_accum_kernel(const unsigned long l
         const int kx = (int)(qs.x * inv_voxel), ky = (int)(qs.y * inv_voxel), kz = (int)(qs.z * inv_voxel);
         const int ox[7] = {0, -1, 1, 0, 0, 0, 0}, oy[7] = {0, 0, 0, 1, -1, 0, 0}, oz[7] = {0, 0, 0, 0, 0, -1, 1};
         double Is[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Ie[3] = {0, 0, 0}, n_acc = 0.0;
-        for (int j = 0; j < n_nearby; ++j) {
+        // the seven look-ups level by level instead of one chain of dependent gathers after the other (see ndt_accum_kernel); the sums
+        // are formed in the order j = 0..6 from the same numbers
+        unsigned long long key[7], kk[7];
+        size_t hs[7];
+        bool found[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
             const int x = kx + ox[j], y = ky + oy[j], z = kz + oz[j];
-            if (!ndt_key_in_range(x, y, z)) continue;
-            const unsigned long long key = ndt_pack(x, y, z);
-            size_t h = ndt_hash(key, cap_mask);
-            int v = -1;
-            for (;;) {
-                const unsigned long long kk = keys[h];
-                if (kk == key) { v = vid[h]; break; }
-                if (kk == kNdtEmpty) break;
-                h = (h + 1) & cap_mask;
+            found[j] = j < n_nearby && ndt_key_in_range(x, y, z);
+            key[j] = ndt_pack(found[j] ? x : kx, found[j] ? y : ky, found[j] ? z : kz);
+            hs[j] = ndt_hash(key[j], cap_mask);
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) kk[j] = keys[hs[j]];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            if (found[j] && kk[j] != key[j] && kk[j] != kNdtEmpty) {  // collision on the first probe: walk on
+                size_t h = (hs[j] + 1) & cap_mask;
+                for (;;) {
+                    const unsigned long long k2 = keys[h];
+                    if (k2 == key[j]) { kk[j] = k2; hs[j] = h; break; }
+                    if (k2 == kNdtEmpty) { kk[j] = k2; break; }
+                    h = (h + 1) & cap_mask;
+                }
             }
-            if (v < 0) continue;
+            found[j] = found[j] && kk[j] == key[j];
+        }
+        int vx[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) vx[j] = vid[found[j] ? hs[j] : 0];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) found[j] = found[j] && vx[j] >= 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int v = found[j] ? vx[j] : 0;  // a voxel that is not there reads record 0 and is not accepted
             const double* m = mu + 3 * (size_t)v;
             const double* I = info + 9 * (size_t)v;
             const double e[3] = {qs.x - m[0], qs.y - m[1], qs.z - m[2]};
@@ -142,12 +164,12 @@ __global__ __launch_bounds__(kBlock) void inc_accum_kernel(const unsigned long l
 #pragma unroll
             for (int r = 0; r < 3; ++r) ie[r] = (I[3 * r] * e[0] + I[3 * r + 1] * e[1]) + I[3 * r + 2] * e[2];
             const double res = (e[0] * ie[0] + e[1] * ie[1]) + e[2] * ie[2];
-            if (isnan(res) || res > res_th) continue;
-            n_acc += 1.0;
+            const bool accept = found[j] && !(isnan(res) || res > res_th);
+            n_acc = accept ? n_acc + 1.0 : n_acc;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Is[k] += I[k];
+            for (int k = 0; k < 9; ++k) Is[k] = accept ? Is[k] + I[k] : Is[k];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) Ie[k] += ie[k];
+            for (int k = 0; k < 3; ++k) Ie[k] = accept ? Ie[k] + ie[k] : Ie[k];
         }
         acc[27] = n_acc;
         if (n_acc > 0.0) {
