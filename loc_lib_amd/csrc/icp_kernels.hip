@@ -222,8 +222,20 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
         for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
     }
     wave_append(deep_list, deep_count, deep, (uint32_t)gi);
-    if (!walk_exact_in_wave<K>(tree, slow, w.qx, w.qy, w.qz, alpha_eff, s_dyn, nn, nn_pitch, gi, search_stats))
+    if (LANES == 16) {
+        // the one-scan launch: every tied query is answered here, two at a time on the wave's dead stacks, so that the latency path
+        // has no redo launch behind it (a wave holds 16 queries; more than two ties in one is a lattice map)
+        bool pending = slow;
+        for (;;) {
+            const unsigned long long m = __ballot(pending);
+            if (m == 0ull) break;
+            const bool mine = pending && __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull)) < 2;
+            (void)walk_exact_in_wave<K>(tree, mine, w.qx, w.qy, w.qz, alpha_eff, s_dyn, nn, nn_pitch, gi, search_stats);
+            pending = pending && !mine;
+        }
+    } else if (!walk_exact_in_wave<K>(tree, slow, w.qx, w.qy, w.qz, alpha_eff, s_dyn, nn, nn_pitch, gi, search_stats)) {
         wave_append(redo_list, redo_count, slow, (uint32_t)gi);
+    }
 }
 
 // The deep pass: the same traversal with EVERY level stored (T = 0, D + 2 rows) over the list of queries whose un-stored top
@@ -892,9 +904,7 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((icp_search_walk_kernel<K, D + 2, 12, 16>), g1, dim3(64), (D + 2) * 16 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                                a.alpha_eff, 0, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
                                a.search_stats, a.active);
-            hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
-                               a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
-            return;
+            return;  // no redo launch: the 16-lane kernel answers its ties itself
         }
         const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
         dim3 g2((a.max_n + 63) / 64, n_launch);
