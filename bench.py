@@ -19,6 +19,7 @@ the per-scan normal equations inside liblocgpu.so (every rank solves every scan 
 rank aligns its own `--scans-per-gpu` scans, no data-path collective; `value` = scans all ranks completed ÷ max-over-ranks time.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 ...          # no WORLD_SIZE in the environment: this process starts the 8 ranks itself (self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8 ...
 """
 import argparse
@@ -161,6 +162,73 @@ def measure_traffic_live(kernel_name, passthrough_args, budget_s=240.0):
     return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 steps each, (2*FETCH+WRITE)*1024"
 
 
+def launcher_command(n_ranks, port, argv, python=None):
+    """argv of the job that runs this script as `n_ranks` ranks of one node: one process per GPU under torch.distributed.run,
+    rendezvous on 127.0.0.1 (the container's hostname may not resolve). `argv` = this script's own arguments, passed through."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launcher_env(env=None):
+    """Environment of the rank processes: the caller's, minus any rank variables of an enclosing job, plus what multi-process GPU
+    work needs on this image (dmabuf IPC for RCCL)."""
+    e = dict(os.environ if env is None else env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e["LOCGPU_BENCH_SELF_LAUNCHED"] = "1"
+    return e
+
+
+def visible_gpus():
+    """HIP devices on this node, counted in a CHILD process through the library's own entry point (locgpu_device_count): the parent
+    of a multi-rank run must never touch HIP itself."""
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from loc_lib_amd import api; print(api.device_count())" % ROOT],
+                         capture_output=True, text=True, timeout=300)
+    if out.returncode != 0:
+        raise SystemExit("bench.py: cannot count the GPUs (is liblocgpu.so built?): %s" % (out.stderr.strip()[-400:] or out.stdout.strip()[-400:]))
+    return int(out.stdout.strip().splitlines()[-1])
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start the N ranks (torch.distributed.run, one per GPU), pass rank 0's
+    JSON line through to stdout, everything else to stderr, and exit with the job's status. This process imports neither torch nor
+    the library and never initialises a GPU."""
+    import socket
+    import subprocess
+    have = visible_gpus()
+    if n_ranks > have:
+        raise SystemExit("bench.py: --gpus %d but this node has %d GPU(s); refusing to run fewer ranks than asked for" % (n_ranks, have))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = launcher_command(n_ranks, port, argv)
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n_ranks, " ".join(cmd)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=launcher_env(), cwd=ROOT)
+    line_out = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        is_line = False
+        if t.startswith("{") and '"metric"' in t:
+            try:
+                json.loads(t)
+                is_line = True
+            except ValueError:
+                pass
+        if is_line:
+            line_out = t
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit("bench.py: the %d-rank job failed with status %d (its output is above)" % (n_ranks, rc))
+    if line_out is None:
+        raise SystemExit("bench.py: the %d-rank job ended without a result line" % n_ranks)
+    print(line_out, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,13 +259,23 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not launched as a rank of a job: bring the N ranks up from here (before torch or HIP is touched) and relay rank 0's line
+        return self_launch(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:  # never a silent run on fewer (or more) ranks than the line will claim
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.scaling is None:
         args.scaling = "strong" if world > 1 else "weak"
+
+    from loc_lib_amd import api as _api_probe
+    n_dev = _api_probe.device_count()
+    if local_rank >= n_dev:
+        raise SystemExit("bench.py: rank %d (local rank %d) has no GPU: this node has %d" % (rank, local_rank, n_dev))
 
     import torch
     dist = None
@@ -448,4 +526,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -227,3 +227,44 @@ def test_host_tree_build_pool_under_thread_sanitizer(tmp_path):
     if r.returncode != 0 and "unexpected memory mapping" in r.stderr:
         pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
     assert r.returncode == 0 and "tsan harness ok" in r.stdout, r.stdout[-1000:] + r.stderr[-4000:]
+
+
+# ----------------------------------------------------------------------------------------------- bench.py launcher (no GPU needed)
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_launcher_command_and_environment():
+    """`python bench.py --gpus N` without WORLD_SIZE starts N ranks itself (one process per GPU): the job's argv is
+    torch.distributed.run on 127.0.0.1 with this script and its own arguments; the rank environment is the caller's without the
+    rank variables of an enclosing job and with dmabuf IPC on."""
+    b = _load_bench()
+    cmd = b.launcher_command(8, 29511, ["--gpus", "8", "--steps", "20", "--warmup", "5"], python="python3")
+    assert cmd[:3] == ["python3", "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    env = b.launcher_env({"PATH": "/usr/bin", "RANK": "3", "WORLD_SIZE": "4", "LOCAL_RANK": "3", "MASTER_PORT": "1", "FOO": "bar"})
+    assert "RANK" not in env and "WORLD_SIZE" not in env and "LOCAL_RANK" not in env and "MASTER_PORT" not in env
+    assert env["FOO"] == "bar" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["LOCGPU_BENCH_SELF_LAUNCHED"] == "1"
+    assert b.launcher_env({"HSA_ENABLE_IPC_MODE_LEGACY": "1"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"  # an explicit setting is kept
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """--gpus N above the node's GPU count is an error, never a silent run on fewer ranks (this container has no GPU at all), and a
+    WORLD_SIZE that disagrees with --gpus is refused too."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4096", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode != 0 and "--gpus 4096 but this node has" in out.stderr, out.stderr[-800:]
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert out.returncode != 0 and "--gpus 8 but WORLD_SIZE=1" in out.stderr, out.stderr[-800:]
