@@ -151,7 +151,9 @@ LOCGPU_API void locgpu_batch_destroy(locgpu_batch* b);
  * are running (e.g. the align call of ANOTHER batch: two batches alternate as a double buffer; one upload per context at a
  * time — a second one waits for the first one's packing). The host clouds must stay valid
  * until locgpu_batch_upload_wait returns (it returns the upload's status); every align / hb call on the batch waits for its
- * pending upload first. */
+ * pending upload first. An upload into a batch whose alignment has been begun and not ended (locgpu_*_align_batch_begin) is
+ * refused with LOCGPU_ERR_INVALID — rotate one more batch than there are alignments in flight. A failed upload stays with its
+ * batch: that batch's next align / hb / upload_wait returns the failure until a new upload replaces its scans. */
 LOCGPU_API int locgpu_batch_create_empty(locgpu_ctx* ctx, int n_scans, size_t max_points_per_scan, locgpu_batch** out);
 LOCGPU_API int locgpu_batch_upload_async(locgpu_batch* b, const void* const* srcs, const size_t* counts, size_t stride_bytes);
 LOCGPU_API int locgpu_batch_upload_wait(locgpu_batch* b);
@@ -166,8 +168,8 @@ LOCGPU_API int locgpu_ndt_align_batch(locgpu_ctx* ctx, locgpu_batch* b, const do
  * enqueues further iterations while scans are still open and writes the results. Begun on batch B while batch A is not yet
  * ended, B's first iterations fill the chip under A's last ones (which hold a handful of unconverged scans):
  *     begin(A); loop { begin(B); end(A); swap(A, B); }
- * One alignment per batch at a time; results are those of the blocking calls, bit for bit. The target must not change between
- * begin and end. Sharded batches: every rank begins and ends its batches in the same order. */
+ * One alignment per batch at a time and no locgpu_batch_upload_async into the batch between begin and end (LOCGPU_ERR_INVALID);
+ * results are those of the blocking calls, bit for bit. The target must not change between begin and end. Sharded batches: every rank begins and ends its batches in the same order. */
 LOCGPU_API int locgpu_icp_align_batch_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const locgpu_icp_opts* opts);
 LOCGPU_API int locgpu_ndt_align_batch_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses);
 LOCGPU_API int locgpu_align_batch_end(locgpu_ctx* ctx, locgpu_batch* b, double* out_poses, locgpu_align_stats* stats);

@@ -143,10 +143,15 @@ int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts,
         if (counts[s] && !srcs[s]) return fail(ctx, LOCGPU_ERR_INVALID, "batch upload: NULL scan pointer");
         pieces += (counts[s] + Uploader::kSlotPoints - 1) / Uploader::kSlotPoints;
     }
+    // One alignment per batch at a time, and no upload into a batch whose alignment has been begun and not ended: the
+    // chunks locgpu_align_batch_end enqueues later read d_src / d_counts / b->counts, which this upload would replace under them.
+    // A caller with several alignments in flight rotates depth + 1 batches (bench.py) — the copy always goes to an idle one.
+    if (b->pending.active) return fail(ctx, LOCGPU_ERR_INVALID, "batch upload: an alignment of this batch has been begun and not finished");
     static const bool dbg = getenv("LOCGPU_UPLOAD_DEBUG") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    const int jrc = upload_join(ctx);  // one upload per context at a time
-    if (jrc != LOCGPU_OK) return jrc;
+    // one upload per context at a time. A failure of the upload that was running belongs to ITS batch (upload_join records it
+    // there: that batch's next align or upload_wait reports it) and does not stop this one.
+    (void)upload_join(ctx);
     const auto t1 = std::chrono::steady_clock::now();
     if (!ctx->up) ctx->up = new Uploader();
     if (!ensure_resources(ctx, pieces)) return LOCGPU_ERR_OOM;
@@ -161,17 +166,10 @@ int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts,
         fprintf(stderr, "[upload] join %.2f ms, previous upload of this batch landed %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
                 std::chrono::duration<double, std::milli>(t2 - t1).count());
     }
-    // The previous contents of the source array may still be read by kernels enqueued on the batch's compute stream (an alignment
-    // that was begun and not yet finished): order the copies behind them.
-    // (Only then: every finished alignment ends with its stream synchronised, and an idle stream needs no ordering — an event
-    // recorded on it can still inherit waits a library queued there: with an RCCL communicator on the context, uploads into every
-    // second batch started ≈12 ms late.)
-    hipEvent_t ev = nullptr;
-    if (b->pending.active && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
-        (void)hipEventRecord(ev, b->stream);
-        (void)hipStreamWaitEvent(u.stream, ev, 0);
-        (void)hipEventDestroy(ev);
-    }
+    // No ordering behind the batch's compute stream is needed: its last alignment has ended (checked above), and every ended
+    // alignment leaves its stream synchronised.
+    st.rc = LOCGPU_OK;
+    st.err.clear();
     u.srcs.assign(srcs, srcs + b->n_scans);
     u.counts.assign(counts, counts + b->n_scans);
     u.stride = stride_bytes;
@@ -191,15 +189,22 @@ int upload_join(locgpu_ctx* ctx) {
     Uploader& u = *ctx->up;
     u.worker.join();
     u.worker_active = false;
+    locgpu_batch* cur = u.current;
     u.current = nullptr;
-    if (u.rc != LOCGPU_OK) return fail(ctx, u.rc, u.err);
+    if (u.rc != LOCGPU_OK) {
+        // the failure stays with the batch it happened to: its source array is partly copied and its `done` event was not recorded
+        // again, so every later use of that batch (align, upload_wait) must fail until a new upload replaces the scans
+        if (cur) { cur->upl.rc = u.rc; cur->upl.err = u.err; cur->upl.done_valid = false; }
+        return fail(ctx, u.rc, u.err);
+    }
     return LOCGPU_OK;
 }
 
 int upload_join_batch(locgpu_batch* b) {
     locgpu_ctx* ctx = b->ctx;
-    if (!ctx->up || !ctx->up->worker_active || ctx->up->current != b) return LOCGPU_OK;
-    return upload_join(ctx);
+    if (ctx->up && ctx->up->worker_active && ctx->up->current == b) return upload_join(ctx);
+    if (b->upl.rc != LOCGPU_OK) return fail(ctx, b->upl.rc, b->upl.err);  // an earlier upload of this batch failed (joined on behalf of another call)
+    return LOCGPU_OK;
 }
 
 hipError_t upload_order_after(locgpu_batch* b, hipStream_t s) {

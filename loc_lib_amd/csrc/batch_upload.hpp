@@ -45,6 +45,8 @@ struct BatchUploadState {  // per batch
     hipEvent_t done = nullptr;  // recorded behind the last slot of the batch's most recent upload
     bool done_valid = false;
     int* h_counts = nullptr;    // pinned copy of the per-scan point counts
+    int rc = 0;                 // status of the batch's most recent upload once joined (sticky until the next upload of the batch)
+    std::string err;
 };
 
 // n strided points (x, y, z as float32 at the start of each record) → float4 {x, y, z, 0}.

@@ -197,6 +197,10 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     extern __shared__ uint2 s_dyn[];
     constexpr int ROWB = LANES * 8;
     static_assert(DF * ROWB >= 64 * 2 * 8, "exact stack columns do not fit");
+    // The traversal reads rows BELOW the stack's bottom (they must lie outside the workgroup's LDS allocation and read as 0): the
+    // stack has to start at LDS address 0, i.e. the kernel must own no other LDS. The launcher checks the code object
+    // (lds_stack_starts_at_zero); this is the last line of defence — wrong neighbours or an endless loop otherwise.
+    if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;  // later chunks of an alignment launch only the scans still open
     if (st[scan].done) return;
     const int tid = threadIdx.x;
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* _
                                                                   unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats) {
     extern __shared__ uint2 s_dyn[];
     constexpr int ROWB = 64 * 8;
+    if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();  // see icp_search_walk_kernel
     const unsigned int n = *n_list;
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0 && search_stats) atomicAdd(&search_stats[2], (unsigned long long)n);
@@ -874,8 +879,32 @@ static int fast_stack_depth() {
     return v;
 }
 
+// The walk kernels' LDS stack must start at LDS address 0 (search_walk.hpp: rows below the bottom are read and must fall outside
+// the allocation). That holds exactly when the kernel has no static LDS of its own — checked on the code object for every
+// instantiation the launchers below can select, once per process, when the first context is created (not at launch time: a launch
+// may happen under stream capture).
+template <auto Kernel>
+static bool no_static_lds() {
+    hipFuncAttributes attr{};
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(Kernel)) == hipSuccess && attr.sharedSizeBytes == 0;
+}
 template <int K, int D, int DF>
-static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
+static bool walk_kernels_ok_kdf() {
+    return no_static_lds<icp_search_walk_kernel<K, DF, 0>>() && no_static_lds<icp_search_walk_kernel<K, DF, 2>>() && no_static_lds<icp_search_walk_kernel<K, DF, 12>>();
+}
+template <int K, int D>
+static bool walk_kernels_ok_kd() {
+    return walk_kernels_ok_kdf<K, D, 12>() && walk_kernels_ok_kdf<K, D, 15>() && walk_kernels_ok_kdf<K, D, 24>() &&
+           no_static_lds<icp_search_walk_kernel<K, D + 2, 12, 16>>() && no_static_lds<icp_search_walk_list_kernel<K, D>>();
+}
+bool search_kernels_lds_ok() {
+    static const bool ok = walk_kernels_ok_kd<1, 32>() && walk_kernels_ok_kd<1, 40>() && walk_kernels_ok_kd<1, 64>() &&
+                           walk_kernels_ok_kd<5, 32>() && walk_kernels_ok_kd<5, 40>() && walk_kernels_ok_kd<5, 64>();
+    return ok;
+}
+
+template <int K, int D, int DF>
+static bool launch_fast_kd(const SearchArgs& a, hipStream_t s) {
     const int T = a.depth > DF ? a.depth - DF : 0;  // leading stack positions the fast kernel does not store
     // a.redo_count is zero here: the caller clears it before an alignment's first iteration, gn_solve_kernel after every search
     static const bool stamp = [] { const char* e = getenv("LOCGPU_STAMP"); return e && atoi(e) != 0; }();
@@ -885,7 +914,7 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
                            a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats, 64);
         hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                            a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
-        return;
+        return true;
     }
     static const int blk = [] { const char* e = getenv("LOCGPU_FAST_BLOCK"); const int v = e ? atoi(e) : 64; return (v == 256 || v == 128) ? v : 64; }();
     static const int walk = [] { const char* e = getenv("LOCGPU_WALK"); return e ? atoi(e) : 1; }();  // 0 = the round-2 kernel (A/B runs)
@@ -904,7 +933,7 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((icp_search_walk_kernel<K, D + 2, 12, 16>), g1, dim3(64), (D + 2) * 16 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                                a.alpha_eff, 0, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
                                a.search_stats, a.active);
-            return;  // no redo launch: the 16-lane kernel answers its ties itself
+            return true;  // no redo launch: the 16-lane kernel answers its ties itself
         }
         const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
         dim3 g2((a.max_n + 63) / 64, n_launch);
@@ -922,7 +951,7 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
                            a.alpha_eff, (unsigned int)a.tree_bytes + 16u, dummy, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count, a.search_stats);
         hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                            a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
-        return;
+        return true;
     }
     if (blk != 256) {
         static const int lds_pad = [] { const char* e = getenv("LOCGPU_LDS_PAD"); return e ? atoi(e) : 0; }();  // experiment: extra dynamic LDS lowers occupancy
@@ -938,29 +967,29 @@ static void launch_fast_kd(const SearchArgs& a, hipStream_t s) {
                                a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats, 128);
         hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                            a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
-        return;
+        return true;
     }
     dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
     hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, kBlock>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                        a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats, kBlock);
     hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                        a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
+    return true;
 }
 template <int K, int D>
-static void launch_fast_d(const SearchArgs& a, hipStream_t s) {
+static bool launch_fast_d(const SearchArgs& a, hipStream_t s) {
     switch (fast_stack_depth()) {
-        case 12: launch_fast_kd<K, D, 12>(a, s); break;
-        case 24: launch_fast_kd<K, D, 24>(a, s); break;
-        default: launch_fast_kd<K, D, 15>(a, s); break;
+        case 12: return launch_fast_kd<K, D, 12>(a, s);
+        case 24: return launch_fast_kd<K, D, 24>(a, s);
+        default: return launch_fast_kd<K, D, 15>(a, s);
     }
 }
 template <int K>
 static bool launch_fast_k(const SearchArgs& a, hipStream_t s) {
-    if (a.depth <= 32) launch_fast_d<K, 32>(a, s);
-    else if (a.depth <= 40) launch_fast_d<K, 40>(a, s);
-    else if (a.depth <= 64) launch_fast_d<K, 64>(a, s);
-    else return false;
-    return true;
+    if (a.depth <= 32) return launch_fast_d<K, 32>(a, s);
+    if (a.depth <= 40) return launch_fast_d<K, 40>(a, s);
+    if (a.depth <= 64) return launch_fast_d<K, 64>(a, s);
+    return false;
 }
 
 template <int K>

@@ -66,6 +66,9 @@ void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st,
 void launch_sum_partials(const double* partials, int blocks_per_scan, const PoseState* st_all, int first, int n_local, int n_total, double* acc,
                          hipStream_t s);
 void launch_transform_cloud(const float4* src, size_t n, const float* m12, float4* dst, hipStream_t s);
+// Code-object self-test (once per process): no walk kernel owns static LDS, so every traversal stack starts at LDS address 0 —
+// the precondition of search_walk.hpp's out-of-range rows (tests/test_gpu_lds_semantics.py pins the hardware side).
+bool search_kernels_lds_ok();
 // test hook: slot lists [k][pitch] → original point indices out[query * k + j] (-1 = none)
 void launch_nn_to_index(const uint2* tree, const uint32_t* nn, size_t nn_pitch, size_t n_queries, int k, int32_t* out, hipStream_t s);
 

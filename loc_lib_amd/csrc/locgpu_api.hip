@@ -195,6 +195,10 @@ int locgpu_create(int device_id, locgpu_ctx** out) {
         return LOCGPU_ERR_NO_DEVICE;
     }
     ctx->stream = ctx->slot_stream[0];
+    if (!search_kernels_lds_ok()) {
+        locgpu_destroy(ctx);
+        return fail(nullptr, LOCGPU_ERR_INVALID, "locgpu_create: a search kernel of this build owns static LDS — its traversal stack would not start at LDS address 0 (search_walk.hpp)");
+    }
     *out = ctx;
     return LOCGPU_OK;
 }

@@ -612,6 +612,8 @@ def test_align_begin_end_two_batches_in_flight(gpu_ctx, api, small_world):
         gpu_ctx.icp_align_batch_begin(bb, poses[1], opts)
         with pytest.raises(RuntimeError):
             gpu_ctx.icp_align_batch_begin(ba, poses[0], opts)
+        with pytest.raises(RuntimeError):  # no upload into a batch between begin and end (later chunks would read the new scans)
+            ba.upload_async(api.MarshalledScans(sets[1]))
         pa, sa = gpu_ctx.align_batch_end(ba)
         pb, sb = gpu_ctx.align_batch_end(bb)
         with pytest.raises(RuntimeError):
