@@ -1357,21 +1357,14 @@ static int check_ndt(locgpu_ctx* ctx, GnParams& prm) {
 
 extern "C" {
 
-// Target ingest from a cloud already in HBM. `host` (optional) = the same points on the host; the incremental method's
-// LRU bookkeeping walks them there and they are fetched when absent.
+// Target ingest from a cloud already in HBM. `host` (optional) = the same points on the host: the incremental method replays a
+// cloud whose own working set exceeds the voxel capacity point by point there (ndt_inc.hip) and fetches them when absent.
 static int ndt_set_target_dev(locgpu_ctx* ctx, const float4* d_pts, const float4* host, size_t n, const locgpu_ndt_opts* opts) {
     locgpu_ndt_opts o;
     if (opts) o = *opts; else locgpu_ndt_opts_default(&o);
     if (!(o.voxel_size > 0.0) || (o.nearby_type != 0 && o.nearby_type != 1) || (o.method != 1 && o.method != 2) || (o.method == 2 && o.capacity < 2))
         return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: bad options");
     if (o.method == 2) {
-        std::vector<float4> fetched;
-        if (!host) {
-            fetched.resize(n);
-            LOCGPU_HIP(ctx, hipMemcpyAsync(fetched.data(), d_pts, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-            LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            host = fetched.data();
-        }
         // incremental: keep the voxel set unless the grid itself changed
         if (ctx->inc && (ctx->ndt_opts.method != 2 || ctx->ndt_opts.voxel_size != o.voxel_size || ctx->ndt_opts.capacity != o.capacity)) {
             inc_ndt_destroy(ctx->inc);

@@ -2,103 +2,223 @@
 // (slam_demo/config/slam.yaml:53).
 //
 // Reference: NdtRegistration::SetIncNdtTargetCloud (ndt_registration.cpp:150-183), UpdateVoxel (:185-236),
-// AlignIncNdt (:262-372). Split of work:
-//   * host (this file, IncNdtState::ingest): the reference's LRU bookkeeping, point by point in input order — a
-//     std::list of voxels with move-to-front on touch and eviction from the tail once `capacity_` is reached (:158-171).
-//     This is sequential control logic (which voxels exist), not arithmetic; each live voxel owns a dense slot.
-//   * device: per-voxel statistics of the points added by THIS call and the per-iteration sums. `flag_first_scan_` is set
-//     to true at the end of every SetIncNdtTargetCloud (:181), so UpdateVoxel always takes its first branch (:186-198):
-//     more than one point ⇒ mean, (n−1)-covariance, info = (Σ + 1e-3·I)⁻¹; a single point ⇒ μ = the point, info = 100·I.
-//     Voxels not touched by the call keep their previous statistics.
-//   * align: AlignIncNdt differs from the direct variant: sums ARE info-weighted (H += Jᵀ·info·J, err += −Jᵀ·info·e,
-//     :345-346), effective_num counts accepted (point, voxel) pairs (:343), too few ⇒ `return false` with result = current
-//     pose (:349-353), and there is no det(H) test.
-#include <list>
-#include <unordered_map>
+// AlignIncNdt (:262-372).
+//
+// State, all of it in HBM (round 4; rounds 1-3 walked the points on the host through a std::list + std::unordered_map):
+//   per slot   key (u64, kNdtEmpty = free), recency stamp (call number << 32 | index of the voxel's last point in that call),
+//              μ (3 f64), info (9 f64);    a stack of free slots;    an open-addressing table key → slot for the align kernel.
+// The reference's container is an LRU cache of capacity − 1 voxels (inc_ndt_lru.hpp restates its loop), and an LRU cache always
+// holds exactly the most recently used keys. So when a cloud touches m ≤ capacity − 1 distinct voxels:
+//   * none of the voxels it touches can be evicted again within the call (fewer than capacity − 1 other keys are younger);
+//   * the voxel set after the call = the capacity − 1 largest stamps of {old voxels} ∪ {touched voxels}, i.e. the E =
+//     max(0, live + new − (capacity − 1)) old voxels with the smallest stamps leave, whatever the order of the points was;
+//   * every touched voxel's statistics are recomputed from ALL of its points of this call, in input order (`flag_first_scan_` is
+//     forced true at the end of every SetIncNdtTargetCloud, :181, so UpdateVoxel always takes its first branch, :186-198: more
+//     than one point ⇒ mean, (n−1)-covariance, info = (Σ + 1e-3·I)⁻¹; a single point ⇒ μ = the point, info = 100·I), untouched
+//     voxels keep theirs.
+// That is a sort, a scan and a few per-voxel kernels: keys → stable radix sort (a voxel's points stay in input order) → segment
+// heads → table look-ups → ONE read-back of three counters → stamps, evictions (a sort of the live stamps, only when E > 0), slots
+// for the new voxels, table rebuild, per-voxel statistics by one thread per voxel summing its points sequentially in input order —
+// the reference's own summation order (math_utils.h:55-72), so μ and info carry the oracle's bits, not just its digits, and are
+// the same bits run after run (the round-3 kernels summed with FP64 atomics).
+// A cloud whose own working set exceeds the capacity (m > capacity − 1: test-sized capacities only — the reference default is
+// 100 000 voxels) needs the order of its points: the live {key, stamp, slot} records come back to the host, inc_lru_replay()
+// walks the points exactly like the reference, and the device finishes from the replayed state with the lost points masked out.
+// Every buffer is owned by the state and only grows: no hipMalloc / hipFree per call. Every array is written before it is
+// read: a slot's μ/info are written by the call that hands the slot out (its voxel has at least one point), the table is
+// refilled on every call, the scratch arrays are produced by the kernels in front of their readers.
+//
+// align: AlignIncNdt differs from the direct variant: sums ARE info-weighted (H += Jᵀ·info·J, err += −Jᵀ·info·e, :345-346),
+// effective_num counts accepted (point, voxel) pairs (:343), too few ⇒ `return false` with result = current pose (:349-353), and
+// there is no det(H) test.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "icp_kernels.hpp"
+#include "inc_ndt_lru.hpp"
 #include "ndt_inc.hpp"
 #include "ndt_kernels.hpp"
 
 namespace locgpu {
 
-// ---------------------------------------------------------------------------------------------- statistics kernels
-__global__ __launch_bounds__(kBlock) void inc_sum_kernel(const float4* __restrict__ pts, const int* __restrict__ pt_slot, size_t n,
-                                                         const unsigned char* __restrict__ slot_dead, double* sums, int* counts) {
+static_assert(kIncNoKey == kNdtEmpty, "inc_ndt_lru.hpp and ndt_kernels.hpp disagree on the empty key");
+
+// ---------------------------------------------------------------------------------------------- ingest kernels
+// counters (device, mirrored in pinned host memory): [0] distinct keys of the call incl. the run of skipped points, [1] a point lay
+// outside the key range, [2] distinct keys that are not in the table (new voxels), [3] the last run is the skipped points' (key = kNdtEmpty),
+// [4] live slots collected for the eviction sort
+constexpr int kIncCtrs = 8;
+
+// key of every point ((pt * inv_voxel_size_).cast<int>(), ndt cpp:154: truncation toward zero); kNdtEmpty for a point outside the
+// ±2^20-voxel range (reported) or masked out by the host replay (keep[i] == 0)
+__global__ __launch_bounds__(kBlock) void inc_key_kernel(const float4* __restrict__ pts, size_t n, double inv_voxel, const unsigned char* __restrict__ keep,
+                                                         unsigned long long* __restrict__ pkey, uint32_t* __restrict__ pidx, int* __restrict__ ctr) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const int s = pt_slot[i];
-    if (s < 0 || slot_dead[s]) return;
     const float4 p = pts[i];
-    atomicAdd(&counts[s], 1);
-    atomicAdd(&sums[3 * (size_t)s + 0], (double)p.x);
-    atomicAdd(&sums[3 * (size_t)s + 1], (double)p.y);
-    atomicAdd(&sums[3 * (size_t)s + 2], (double)p.z);
+    const int kx = (int)((double)p.x * inv_voxel), ky = (int)((double)p.y * inv_voxel), kz = (int)((double)p.z * inv_voxel);
+    unsigned long long key = kNdtEmpty;
+    if (!ndt_key_in_range(kx, ky, kz)) ctr[1] = 1;
+    else if (!keep || keep[i]) key = ndt_pack(kx, ky, kz);
+    pkey[i] = key;
+    pidx[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(kBlock) void inc_mean_kernel(const int* __restrict__ active, int n_active, const double* sums, const int* counts,
-                                                          double* mu) {
-    const int a = blockIdx.x * kBlock + threadIdx.x;
-    if (a >= n_active) return;
-    const int s = active[a];
-    const double len = (double)counts[s];
-    if (len > 0)
-        for (int c = 0; c < 3; ++c) mu[3 * (size_t)s + c] = sums[3 * (size_t)s + c] / len;
-}
-
-__global__ __launch_bounds__(kBlock) void inc_cov_kernel(const float4* __restrict__ pts, const int* __restrict__ pt_slot, size_t n,
-                                                         const unsigned char* __restrict__ slot_dead, const double* mu, double* cov6) {
+// sorted keys → 1 at the first point of every run
+__global__ __launch_bounds__(kBlock) void inc_head_kernel(const unsigned long long* __restrict__ skey, size_t n, int* __restrict__ head) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const int s = pt_slot[i];
-    if (s < 0 || slot_dead[s]) return;
-    const float4 p = pts[i];
-    const double dx = (double)p.x - mu[3 * (size_t)s], dy = (double)p.y - mu[3 * (size_t)s + 1], dz = (double)p.z - mu[3 * (size_t)s + 2];
-    double* c = cov6 + 6 * (size_t)s;
-    atomicAdd(&c[0], dx * dx); atomicAdd(&c[1], dx * dy); atomicAdd(&c[2], dx * dz);
-    atomicAdd(&c[3], dy * dy); atomicAdd(&c[4], dy * dz); atomicAdd(&c[5], dz * dz);
+    head[i] = (i == 0 || skey[i] != skey[i - 1]) ? 1 : 0;
 }
 
-// UpdateVoxel, first-scan branch (ndt cpp:186-198).
-__global__ __launch_bounds__(kBlock) void inc_info_kernel(const int* __restrict__ active, int n_active, const int* counts, const double* cov6,
-                                                          double* info) {
-    const int a = blockIdx.x * kBlock + threadIdx.x;
-    if (a >= n_active) return;
-    const int s = active[a];
-    const int n = counts[s];
-    double* I = info + 9 * (size_t)s;
-    if (n > 1) {
-        const double l1 = (double)(n - 1);
-        const double* c = cov6 + 6 * (size_t)s;
-        const double m00 = c[0] / l1 + 1e-3, m01 = c[1] / l1, m02 = c[2] / l1, m11 = c[3] / l1 + 1e-3, m12 = c[4] / l1, m22 = c[5] / l1 + 1e-3;
-        const double det = m00 * (m11 * m22 - m12 * m12) - m01 * (m01 * m22 - m12 * m02) + m02 * (m01 * m12 - m11 * m02);
-        const double id = 1.0 / det;
-        I[0] = (m11 * m22 - m12 * m12) * id; I[1] = (m02 * m12 - m01 * m22) * id; I[2] = (m01 * m12 - m02 * m11) * id;
-        I[3] = I[1];                         I[4] = (m00 * m22 - m02 * m02) * id; I[5] = (m02 * m01 - m00 * m12) * id;
-        I[6] = I[2];                         I[7] = I[5];                         I[8] = (m00 * m11 - m01 * m01) * id;
-    } else if (n == 1) {
-        for (int k = 0; k < 9; ++k) I[k] = (k % 4 == 0) ? 1e2 : 0.0;
+// run u: key, first sorted position; ustart[runs] = n; ctr[0] = runs; the points in voxel order (a voxel's points consecutive, in
+// input order — what the statistics kernel sums over)
+__global__ __launch_bounds__(kBlock) void inc_runs_kernel(const unsigned long long* __restrict__ skey, const uint32_t* __restrict__ sidx, const int* __restrict__ head,
+                                                          const int* __restrict__ uid, size_t n, const float4* __restrict__ pts,
+                                                          unsigned long long* __restrict__ ukey, uint32_t* __restrict__ ustart, float4* __restrict__ psorted,
+                                                          int* __restrict__ ctr) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    psorted[i] = pts[sidx[i]];
+    if (head[i]) { ukey[uid[i]] = skey[i]; ustart[uid[i]] = (uint32_t)i; }
+    if (i == n - 1) {
+        const int runs = uid[i] + head[i];
+        ustart[runs] = (uint32_t)n;
+        ctr[0] = runs;
+        ctr[3] = skey[i] == kNdtEmpty ? 1 : 0;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void inc_table_kernel(const unsigned long long* __restrict__ keys_in, const int* __restrict__ slots_in, int n,
-                                                           unsigned long long* keys, int* vid, size_t cap_mask) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long key = keys_in[i];
+// run u → its voxel's slot (−1: not in the table, −2: the run of skipped points); counts the new voxels
+__global__ __launch_bounds__(kBlock) void inc_lookup_kernel(const unsigned long long* __restrict__ ukey, const int* __restrict__ ctr_in,
+                                                            const unsigned long long* __restrict__ tkeys, const int* __restrict__ tvid, size_t cap_mask,
+                                                            int* __restrict__ uslot, int* __restrict__ unew, int* __restrict__ ctr) {
+    const int u = blockIdx.x * kBlock + threadIdx.x;
+    if (u >= ctr_in[0]) return;
+    const unsigned long long key = ukey[u];
+    int slot = -2, is_new = 0;
+    if (key != kNdtEmpty) {
+        slot = -1;
+        size_t h = ndt_hash(key, cap_mask);
+        for (;;) {
+            const unsigned long long k2 = tkeys[h];
+            if (k2 == key) { slot = tvid[h]; break; }
+            if (k2 == kNdtEmpty) break;
+            h = (h + 1) & cap_mask;
+        }
+        is_new = slot < 0 ? 1 : 0;
+        if (is_new) atomicAdd(&ctr[2], 1);
+    }
+    uslot[u] = slot;
+    unew[u] = is_new;
+}
+
+// the voxels the call touches that already exist: most recent now (ndt cpp:169-170)
+__global__ __launch_bounds__(kBlock) void inc_touch_kernel(const int* __restrict__ uslot, const uint32_t* __restrict__ ustart, const uint32_t* __restrict__ sidx, int m,
+                                                           unsigned long long epoch_hi, unsigned long long* __restrict__ slot_stamp) {
+    const int u = blockIdx.x * kBlock + threadIdx.x;
+    if (u >= m) return;
+    const int slot = uslot[u];
+    if (slot >= 0) slot_stamp[slot] = epoch_hi | (unsigned long long)sidx[ustart[u + 1] - 1u];  // stable sort: the run's last element is the voxel's last point
+}
+
+// {stamp, slot} of every live slot, for the eviction sort
+__global__ __launch_bounds__(kBlock) void inc_collect_kernel(const unsigned long long* __restrict__ slot_key, const unsigned long long* __restrict__ slot_stamp, int n_slots,
+                                                             unsigned long long* __restrict__ ev_stamp, int* __restrict__ ev_slot, int* __restrict__ ctr) {
+    const int sl = blockIdx.x * kBlock + threadIdx.x;
+    if (sl >= n_slots || slot_key[sl] == kNdtEmpty) return;
+    const int pos = atomicAdd(&ctr[4], 1);  // the order is settled by the sort (stamps are unique)
+    ev_stamp[pos] = slot_stamp[sl];
+    ev_slot[pos] = sl;
+}
+
+// the E least recently used voxels leave (ndt cpp:161-165); their slots go on top of the free stack, the oldest lowest
+__global__ __launch_bounds__(kBlock) void inc_evict_kernel(const int* __restrict__ ev_slot_sorted, int n_evict, int n_free, unsigned long long* __restrict__ slot_key,
+                                                           int* __restrict__ free_stack) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_evict) return;
+    const int sl = ev_slot_sorted[e];
+    slot_key[sl] = kNdtEmpty;
+    free_stack[n_free + e] = sl;
+}
+
+// a slot for every new voxel: from the top of the free stack, then fresh ones
+__global__ __launch_bounds__(kBlock) void inc_assign_kernel(const unsigned long long* __restrict__ ukey, const int* __restrict__ unew, const int* __restrict__ urank,
+                                                            const uint32_t* __restrict__ ustart, const uint32_t* __restrict__ sidx, int m, const int* __restrict__ free_stack,
+                                                            int n_free, int n_slots, unsigned long long epoch_hi, unsigned long long* __restrict__ slot_key,
+                                                            unsigned long long* __restrict__ slot_stamp, int* __restrict__ uslot) {
+    const int u = blockIdx.x * kBlock + threadIdx.x;
+    if (u >= m || !unew[u]) return;
+    const int r = urank[u];
+    const int slot = r < n_free ? free_stack[n_free - 1 - r] : n_slots + (r - n_free);
+    slot_key[slot] = ukey[u];
+    slot_stamp[slot] = epoch_hi | (unsigned long long)sidx[ustart[u + 1] - 1u];
+    uslot[u] = slot;
+}
+
+__global__ void inc_fill_kernel(unsigned long long* p, size_t n, unsigned long long v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// key → slot table of the live slots (refilled on every call)
+__global__ __launch_bounds__(kBlock) void inc_table_kernel(const unsigned long long* __restrict__ slot_key, int n_slots, unsigned long long* keys, int* vid,
+                                                           size_t cap_mask) {
+    const int sl = blockIdx.x * kBlock + threadIdx.x;
+    if (sl >= n_slots) return;
+    const unsigned long long key = slot_key[sl];
+    if (key == kNdtEmpty) return;
     size_t h = ndt_hash(key, cap_mask);
     for (;;) {
         const unsigned long long prev = atomicCAS(&keys[h], kNdtEmpty, key);
         if (prev == kNdtEmpty) break;
         h = (h + 1) & cap_mask;
     }
-    vid[h] = slots_in[i];
+    vid[h] = sl;
 }
 
-__global__ void inc_fill_kernel(unsigned long long* p, size_t n, unsigned long long v) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+// UpdateVoxel, first-scan branch (ndt cpp:186-198) with math::ComputeMeanAndCov (math_utils.h:55-72): one thread per touched
+// voxel, its points consecutive in psorted and in input order — sums run in the reference's order, products are not fused
+// (the library is built with -ffp-contract=off), the 3×3 inverse is the cofactor form of Eigen's fixed-size inverse.
+__global__ __launch_bounds__(kBlock) void inc_stats_kernel(const float4* __restrict__ psorted, const uint32_t* __restrict__ ustart, const int* __restrict__ uslot, int m,
+                                                           double* __restrict__ mu, double* __restrict__ info) {
+    const int u = blockIdx.x * kBlock + threadIdx.x;
+    if (u >= m) return;
+    const int slot = uslot[u];
+    if (slot < 0) return;  // the run of skipped points
+    const uint32_t b = ustart[u], e = ustart[u + 1];
+    const uint32_t len = e - b;
+    double* M = mu + 3 * (size_t)slot;
+    double* I = info + 9 * (size_t)slot;
+    if (len > 1) {
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (uint32_t j = b; j < e; ++j) { const float4 p = psorted[j]; sx = sx + (double)p.x; sy = sy + (double)p.y; sz = sz + (double)p.z; }
+        const double mx = sx / (double)len, my = sy / (double)len, mz = sz / (double)len;
+        double c00 = 0.0, c01 = 0.0, c02 = 0.0, c11 = 0.0, c12 = 0.0, c22 = 0.0;
+        for (uint32_t j = b; j < e; ++j) {
+            const float4 p = psorted[j];
+            const double dx = (double)p.x - mx, dy = (double)p.y - my, dz = (double)p.z - mz;
+            c00 += dx * dx; c01 += dx * dy; c02 += dx * dz; c11 += dy * dy; c12 += dy * dz; c22 += dz * dz;
+        }
+        const double l1 = (double)(len - 1);
+        const double a = c00 / l1 + 1e-3, bq = c01 / l1, c = c02 / l1, e4 = c11 / l1 + 1e-3, f = c12 / l1, i8 = c22 / l1 + 1e-3;
+        const double d = bq, g = c, h = f;  // the matrix is symmetric: (row 1, col 0) = (0, 1) etc. — the same numbers, so the same bits
+        const double det = a * (e4 * i8 - f * h) - bq * (d * i8 - f * g) + c * (d * h - e4 * g);
+        const double id = 1.0 / det;
+        I[0] = (e4 * i8 - f * h) * id; I[1] = (c * h - bq * i8) * id; I[2] = (bq * f - c * e4) * id;
+        I[3] = (f * g - d * i8) * id;  I[4] = (a * i8 - c * g) * id;  I[5] = (c * d - a * f) * id;
+        I[6] = (d * h - e4 * g) * id;  I[7] = (bq * g - a * h) * id;  I[8] = (a * e4 - bq * d) * id;
+        M[0] = mx; M[1] = my; M[2] = mz;
+    } else {
+        const float4 p = psorted[b];
+        M[0] = (double)p.x; M[1] = (double)p.y; M[2] = (double)p.z;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) I[k] = (k % 4 == 0) ? 1e2 : 0.0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- accumulate kernel
@@ -216,52 +336,123 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
 }
 
-// ---------------------------------------------------------------------------------------------- host state
-struct KeyHash {
-    size_t operator()(unsigned long long k) const { return (size_t)ndt_hash(k, ~(size_t)0); }
-};
-
+// ---------------------------------------------------------------------------------------------- state
 struct IncNdtState {
     size_t capacity = 100000;
     double inv_voxel = 1.0;
-    std::list<unsigned long long> lru;  // front = most recently touched (data_, ndt_registration.hpp:126)
-    struct Entry { std::list<unsigned long long>::iterator it; int slot; };
-    std::unordered_map<unsigned long long, Entry, KeyHash> map;  // inc_grids_ (:127)
-    std::vector<int> free_slots;
-    int n_slots = 0;  // slots ever handed out
-    // device
-    double *d_mu = nullptr, *d_info = nullptr, *d_sums = nullptr, *d_cov = nullptr;
-    int* d_counts = nullptr;
-    unsigned char* d_dead = nullptr;
+    uint32_t epoch = 0;  // calls so far (the high half of the recency stamps)
+    // counts the host keeps (the arrays below are the state itself)
+    int n_slots = 0;  // slots ever handed out: [0, n_slots)
+    int n_live = 0;   // voxels alive
+    int n_free = 0;   // entries on the free stack
+    // per slot
+    unsigned long long *d_slot_key = nullptr, *d_slot_stamp = nullptr;
+    double *d_mu = nullptr, *d_info = nullptr;
+    int* d_free = nullptr;
     size_t slot_cap = 0;
+    // key → slot table for the align kernel
     unsigned long long* d_keys = nullptr;
     int* d_vid = nullptr;
     size_t table_cap = 0;
+    // per-call scratch, by points (pt_cap) — also holds the per-voxel arrays (a call has at most n voxels)
+    unsigned long long *d_pkey = nullptr, *d_skey = nullptr, *d_ukey = nullptr;
+    uint32_t *d_pidx = nullptr, *d_sidx = nullptr, *d_ustart = nullptr;
+    int *d_head = nullptr, *d_uid = nullptr, *d_uslot = nullptr, *d_unew = nullptr, *d_urank = nullptr;
+    float4* d_psorted = nullptr;
+    unsigned char* d_keep = nullptr;
+    size_t pt_cap = 0;
+    // eviction scratch, by slots (ev_cap)
+    unsigned long long *d_ev_stamp = nullptr, *d_ev_stamp_sorted = nullptr;
+    int *d_ev_slot = nullptr, *d_ev_slot_sorted = nullptr;
+    size_t ev_cap = 0;
+    void* d_temp = nullptr;  // hipcub
+    size_t temp_bytes = 0;
+    int *d_ctr = nullptr, *h_ctr = nullptr;  // kIncCtrs counters, device + pinned
 };
 
 #define INC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
-static hipError_t grow(IncNdtState& st, size_t need, hipStream_t s) {
-    if (need <= st.slot_cap) return hipSuccess;
-    size_t cap = st.slot_cap ? st.slot_cap : 4096;
-    while (cap < need) cap *= 2;
-    double *mu = nullptr, *info = nullptr, *sums = nullptr, *cov = nullptr;
-    int* counts = nullptr;
-    unsigned char* dead = nullptr;
-    INC_TRY(hipMalloc((void**)&mu, cap * 3 * sizeof(double)));
-    INC_TRY(hipMalloc((void**)&info, cap * 9 * sizeof(double)));
-    INC_TRY(hipMalloc((void**)&sums, cap * 3 * sizeof(double)));
-    INC_TRY(hipMalloc((void**)&cov, cap * 6 * sizeof(double)));
-    INC_TRY(hipMalloc((void**)&counts, cap * sizeof(int)));
-    INC_TRY(hipMalloc((void**)&dead, cap));
-    if (st.slot_cap) {
-        INC_TRY(hipMemcpyAsync(mu, st.d_mu, st.slot_cap * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-        INC_TRY(hipMemcpyAsync(info, st.d_info, st.slot_cap * 9 * sizeof(double), hipMemcpyDeviceToDevice, s));
+template <typename T>
+static hipError_t regrow(T*& p, size_t old_count, size_t new_count, bool keep, hipStream_t s) {
+    T* q = nullptr;
+    INC_TRY(hipMalloc((void**)&q, new_count * sizeof(T)));
+    if (keep && p && old_count) {
+        const hipError_t e = hipMemcpyAsync(q, p, old_count * sizeof(T), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { (void)hipFree(q); return e; }
         INC_TRY(hipStreamSynchronize(s));
-        (void)hipFree(st.d_mu); (void)hipFree(st.d_info); (void)hipFree(st.d_sums); (void)hipFree(st.d_cov); (void)hipFree(st.d_counts); (void)hipFree(st.d_dead);
     }
-    st.d_mu = mu; st.d_info = info; st.d_sums = sums; st.d_cov = cov; st.d_counts = counts; st.d_dead = dead;
+    if (p) (void)hipFree(p);
+    p = q;
+    return hipSuccess;
+}
+
+static size_t grown(size_t have, size_t need, size_t floor_) {
+    size_t cap = have ? have : floor_;
+    while (cap < need) cap *= 2;
+    return cap;
+}
+
+static hipError_t ensure_temp(IncNdtState& st, size_t bytes) {
+    if (bytes <= st.temp_bytes) return hipSuccess;
+    if (st.d_temp) (void)hipFree(st.d_temp);
+    st.d_temp = nullptr; st.temp_bytes = 0;
+    INC_TRY(hipMalloc(&st.d_temp, bytes + 256));
+    st.temp_bytes = bytes + 256;
+    return hipSuccess;
+}
+
+// room for `need` slots (μ/info/keys/stamps of the slots in use are kept)
+static hipError_t ensure_slots(IncNdtState& st, size_t need, hipStream_t s) {
+    if (need <= st.slot_cap) return hipSuccess;
+    const size_t cap = grown(st.slot_cap, need, 4096), old = (size_t)st.n_slots;
+    INC_TRY(regrow(st.d_slot_key, old, cap, true, s));
+    INC_TRY(regrow(st.d_slot_stamp, old, cap, true, s));
+    INC_TRY(regrow(st.d_mu, 3 * old, 3 * cap, true, s));
+    INC_TRY(regrow(st.d_info, 9 * old, 9 * cap, true, s));
+    INC_TRY(regrow(st.d_free, (size_t)st.n_free, cap, true, s));
     st.slot_cap = cap;
+    return hipSuccess;
+}
+
+static hipError_t ensure_points(IncNdtState& st, size_t n, hipStream_t s) {
+    if (!st.d_ctr) {
+        INC_TRY(hipMalloc((void**)&st.d_ctr, kIncCtrs * sizeof(int)));
+        INC_TRY(hipHostMalloc((void**)&st.h_ctr, kIncCtrs * sizeof(int)));
+    }
+    if (!st.table_cap) {  // an empty table, so that the first call's look-ups run like every other call's
+        const size_t cap = 1024;
+        INC_TRY(hipMalloc((void**)&st.d_keys, cap * sizeof(unsigned long long)));
+        INC_TRY(hipMalloc((void**)&st.d_vid, cap * sizeof(int)));
+        st.table_cap = cap;
+        hipLaunchKernelGGL(inc_fill_kernel, dim3((unsigned)(cap / kBlock)), dim3(kBlock), 0, s, st.d_keys, cap, kNdtEmpty);
+        INC_TRY(hipMemsetAsync(st.d_vid, 0xFF, cap * sizeof(int), s));
+    }
+    if (n + 1 > st.pt_cap) {
+        const size_t cap = grown(st.pt_cap, n + 1, 16384);
+        INC_TRY(regrow(st.d_pkey, 0, cap, false, s)); INC_TRY(regrow(st.d_skey, 0, cap, false, s)); INC_TRY(regrow(st.d_ukey, 0, cap, false, s));
+        INC_TRY(regrow(st.d_pidx, 0, cap, false, s)); INC_TRY(regrow(st.d_sidx, 0, cap, false, s)); INC_TRY(regrow(st.d_ustart, 0, cap, false, s));
+        INC_TRY(regrow(st.d_head, 0, cap, false, s)); INC_TRY(regrow(st.d_uid, 0, cap, false, s)); INC_TRY(regrow(st.d_uslot, 0, cap, false, s));
+        INC_TRY(regrow(st.d_unew, 0, cap, false, s)); INC_TRY(regrow(st.d_urank, 0, cap, false, s));
+        INC_TRY(regrow(st.d_psorted, 0, cap, false, s)); INC_TRY(regrow(st.d_keep, 0, cap, false, s));
+        st.pt_cap = cap;
+        size_t b1 = 0, b2 = 0;
+        INC_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, st.d_pkey, st.d_skey, st.d_pidx, st.d_sidx, (int)cap, 0, 64, s));
+        INC_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, st.d_head, st.d_uid, (int)cap, s));
+        INC_TRY(ensure_temp(st, std::max(b1, b2)));
+    }
+    return hipSuccess;
+}
+
+static hipError_t ensure_evict(IncNdtState& st, size_t n_live, hipStream_t s) {
+    if (n_live > st.ev_cap) {
+        const size_t cap = grown(st.ev_cap, n_live, 4096);
+        INC_TRY(regrow(st.d_ev_stamp, 0, cap, false, s)); INC_TRY(regrow(st.d_ev_stamp_sorted, 0, cap, false, s));
+        INC_TRY(regrow(st.d_ev_slot, 0, cap, false, s)); INC_TRY(regrow(st.d_ev_slot_sorted, 0, cap, false, s));
+        st.ev_cap = cap;
+        size_t b = 0;
+        INC_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b, st.d_ev_stamp, st.d_ev_stamp_sorted, st.d_ev_slot, st.d_ev_slot_sorted, (int)cap, 0, 64, s));
+        INC_TRY(ensure_temp(st, b));
+    }
     return hipSuccess;
 }
 
@@ -274,117 +465,150 @@ IncNdtState* inc_ndt_create(size_t capacity, double voxel_size) {
 
 void inc_ndt_destroy(IncNdtState* st) {
     if (!st) return;
-    (void)hipFree(st->d_mu); (void)hipFree(st->d_info); (void)hipFree(st->d_sums); (void)hipFree(st->d_cov); (void)hipFree(st->d_counts);
-    (void)hipFree(st->d_dead); (void)hipFree(st->d_keys); (void)hipFree(st->d_vid);
+    void* dev[] = {st->d_slot_key, st->d_slot_stamp, st->d_mu, st->d_info, st->d_free, st->d_keys, st->d_vid, st->d_pkey, st->d_skey, st->d_ukey, st->d_pidx,
+                   st->d_sidx, st->d_ustart, st->d_head, st->d_uid, st->d_uslot, st->d_unew, st->d_urank, st->d_psorted, st->d_keep, st->d_ev_stamp,
+                   st->d_ev_stamp_sorted, st->d_ev_slot, st->d_ev_slot_sorted, st->d_temp, st->d_ctr};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    if (st->h_ctr) (void)hipHostFree(st->h_ctr);
     delete st;
 }
 
-size_t inc_ndt_num_voxels(const IncNdtState* st) { return st ? st->map.size() : 0; }
+size_t inc_ndt_num_voxels(const IncNdtState* st) { return st ? (size_t)st->n_live : 0; }
 
-// SetIncNdtTargetCloud. `host_pts` = the cloud as float4 on the host (for the key pass), `d_pts` = the same on the device.
+static unsigned grid_for(size_t n) { return (unsigned)((std::max<size_t>(n, 1) + kBlock - 1) / kBlock); }
+
+// keys → sort → runs → look-ups; returns with h_ctr read back (one synchronisation)
+static hipError_t sort_and_look_up(IncNdtState& st, const float4* d_pts, size_t n, bool masked, hipStream_t s) {
+    INC_TRY(hipMemsetAsync(st.d_ctr, 0, kIncCtrs * sizeof(int), s));
+    hipLaunchKernelGGL(inc_key_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, d_pts, n, st.inv_voxel, masked ? st.d_keep : nullptr, st.d_pkey, st.d_pidx, st.d_ctr);
+    size_t tb = st.temp_bytes;
+    INC_TRY(hipcub::DeviceRadixSort::SortPairs(st.d_temp, tb, st.d_pkey, st.d_skey, st.d_pidx, st.d_sidx, (int)n, 0, 64, s));  // stable: a voxel's points keep their input order
+    hipLaunchKernelGGL(inc_head_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, st.d_skey, n, st.d_head);
+    tb = st.temp_bytes;
+    INC_TRY(hipcub::DeviceScan::ExclusiveSum(st.d_temp, tb, st.d_head, st.d_uid, (int)n, s));
+    hipLaunchKernelGGL(inc_runs_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, st.d_skey, st.d_sidx, st.d_head, st.d_uid, n, d_pts, st.d_ukey, st.d_ustart, st.d_psorted, st.d_ctr);
+    hipLaunchKernelGGL(inc_lookup_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, st.d_ukey, st.d_ctr, st.d_keys, st.d_vid, st.table_cap - 1, st.d_uslot, st.d_unew, st.d_ctr);
+    INC_TRY(hipGetLastError());
+    INC_TRY(hipMemcpyAsync(st.h_ctr, st.d_ctr, kIncCtrs * sizeof(int), hipMemcpyDeviceToHost, s));
+    INC_TRY(hipStreamSynchronize(s));
+    return hipSuccess;
+}
+
+// table of the live slots + per-voxel statistics of the m touched voxels (uslot[u] ≥ 0 for every real run)
+static hipError_t rebuild_table_and_stats(IncNdtState& st, int m, hipStream_t s) {
+    size_t cap = 1024;
+    while (cap < 2 * (size_t)std::max(st.n_live, 1)) cap <<= 1;
+    if (cap > st.table_cap) {  // grows only
+        if (st.d_keys) (void)hipFree(st.d_keys);
+        if (st.d_vid) (void)hipFree(st.d_vid);
+        st.d_keys = nullptr; st.d_vid = nullptr; st.table_cap = 0;
+        INC_TRY(hipMalloc((void**)&st.d_keys, cap * sizeof(unsigned long long)));
+        INC_TRY(hipMalloc((void**)&st.d_vid, cap * sizeof(int)));
+        st.table_cap = cap;
+    }
+    hipLaunchKernelGGL(inc_fill_kernel, dim3(grid_for(st.table_cap)), dim3(kBlock), 0, s, st.d_keys, st.table_cap, kNdtEmpty);
+    INC_TRY(hipMemsetAsync(st.d_vid, 0xFF, st.table_cap * sizeof(int), s));
+    hipLaunchKernelGGL(inc_table_kernel, dim3(grid_for((size_t)st.n_slots)), dim3(kBlock), 0, s, st.d_slot_key, st.n_slots, st.d_keys, st.d_vid, st.table_cap - 1);
+    if (m > 0) hipLaunchKernelGGL(inc_stats_kernel, dim3(grid_for((size_t)m)), dim3(kBlock), 0, s, st.d_psorted, st.d_ustart, st.d_uslot, m, st.d_mu, st.d_info);
+    INC_TRY(hipGetLastError());
+    return hipStreamSynchronize(s);
+}
+
+// The cloud's own working set exceeds the capacity: replay the points in order on the host (inc_lru_replay), from the device's state.
+static hipError_t ingest_replayed(IncNdtState& st, const float4* host_pts, const float4* d_pts, size_t n, hipStream_t s) {
+    std::vector<float4> fetched;
+    if (!host_pts) {
+        fetched.resize(n);
+        INC_TRY(hipMemcpyAsync(fetched.data(), d_pts, n * sizeof(float4), hipMemcpyDeviceToHost, s));
+        INC_TRY(hipStreamSynchronize(s));
+        host_pts = fetched.data();
+    }
+    const size_t ns = (size_t)st.n_slots;
+    std::vector<unsigned long long> h_key(ns), h_stamp(ns);
+    std::vector<int> free_slots((size_t)st.n_free);
+    if (ns) {
+        INC_TRY(hipMemcpyAsync(h_key.data(), st.d_slot_key, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        INC_TRY(hipMemcpyAsync(h_stamp.data(), st.d_slot_stamp, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    }
+    if (st.n_free) INC_TRY(hipMemcpyAsync(free_slots.data(), st.d_free, (size_t)st.n_free * sizeof(int), hipMemcpyDeviceToHost, s));
+    INC_TRY(hipStreamSynchronize(s));
+    std::vector<IncLive> live;
+    live.reserve((size_t)st.n_live);
+    for (size_t sl = 0; sl < ns; ++sl)
+        if (h_key[sl] != kNdtEmpty) live.push_back(IncLive{h_key[sl], h_stamp[sl], (int)sl});
+    std::vector<uint64_t> keys(n);
+    for (size_t i = 0; i < n; ++i) {
+        const int kx = (int)((double)host_pts[i].x * st.inv_voxel), ky = (int)((double)host_pts[i].y * st.inv_voxel), kz = (int)((double)host_pts[i].z * st.inv_voxel);
+        keys[i] = ndt_key_in_range(kx, ky, kz) ? ndt_pack(kx, ky, kz) : kIncNoKey;
+    }
+    std::vector<unsigned char> keep;
+    int n_slots = st.n_slots;
+    inc_lru_replay(live, free_slots, n_slots, st.capacity, st.epoch, keys.data(), n, keep);
+    INC_TRY(ensure_slots(st, (size_t)std::max(n_slots, 1), s));
+    st.n_slots = n_slots;
+    st.n_live = (int)live.size();
+    st.n_free = (int)free_slots.size();
+    h_key.assign((size_t)n_slots, kNdtEmpty);
+    h_stamp.assign((size_t)n_slots, 0ull);
+    for (const IncLive& v : live) { h_key[(size_t)v.slot] = v.key; h_stamp[(size_t)v.slot] = v.stamp; }
+    if (n_slots) {
+        INC_TRY(hipMemcpyAsync(st.d_slot_key, h_key.data(), (size_t)n_slots * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        INC_TRY(hipMemcpyAsync(st.d_slot_stamp, h_stamp.data(), (size_t)n_slots * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    }
+    if (st.n_free) INC_TRY(hipMemcpyAsync(st.d_free, free_slots.data(), (size_t)st.n_free * sizeof(int), hipMemcpyHostToDevice, s));
+    INC_TRY(hipMemcpyAsync(st.d_keep, keep.data(), n, hipMemcpyHostToDevice, s));
+    INC_TRY(hipStreamSynchronize(s));  // the vectors above are pageable: nothing may still be reading them when they go out of scope
+    // the device finishes from the replayed state: table of the new voxel set, then the surviving points by voxel
+    INC_TRY(rebuild_table_and_stats(st, 0, s));
+    INC_TRY(sort_and_look_up(st, d_pts, n, true, s));
+    const int m = st.h_ctr[0] - st.h_ctr[3];
+    if (st.h_ctr[2] != 0) return hipErrorUnknown;  // every surviving point's voxel is in the replayed set
+    if (m > 0) hipLaunchKernelGGL(inc_stats_kernel, dim3(grid_for((size_t)m)), dim3(kBlock), 0, s, st.d_psorted, st.d_ustart, st.d_uslot, m, st.d_mu, st.d_info);
+    INC_TRY(hipGetLastError());
+    return hipStreamSynchronize(s);
+}
+
+// SetIncNdtTargetCloud. `d_pts` = the cloud in HBM; `host_pts` = the same on the host when the caller has it (else fetched if needed).
 hipError_t inc_ndt_ingest(IncNdtState& st, const float4* host_pts, const float4* d_pts, size_t n, hipStream_t s, bool* bad_key) {
     *bad_key = false;
-    std::vector<int> pt_slot(n);
-    std::vector<int> active;            // slots touched by this call, in first-touch order
-    std::vector<char> touched;          // per slot
-    std::vector<int> died;              // slots evicted during this call: recycled only afterwards
-    std::vector<unsigned char> dead;    // per slot, for the device
-    auto mark = [&](int slot) {
-        if ((size_t)slot >= touched.size()) touched.resize(slot + 1, 0);
-        if (!touched[slot]) { touched[slot] = 1; active.push_back(slot); }
-    };
-    for (size_t i = 0; i < n; ++i) {
-        const double x = (double)host_pts[i].x * st.inv_voxel, y = (double)host_pts[i].y * st.inv_voxel, z = (double)host_pts[i].z * st.inv_voxel;
-        const int kx = (int)x, ky = (int)y, kz = (int)z;  // (pt * inv_voxel_size_).cast<int>(): truncation toward zero
-        if (!ndt_key_in_range(kx, ky, kz)) { *bad_key = true; pt_slot[i] = -1; continue; }
-        const unsigned long long key = ndt_pack(kx, ky, kz);
-        auto it = st.map.find(key);
-        if (it == st.map.end()) {
-            int slot;
-            if (!st.free_slots.empty()) { slot = st.free_slots.back(); st.free_slots.pop_back(); }
-            else slot = st.n_slots++;
-            st.lru.push_front(key);
-            st.map.emplace(key, IncNdtState::Entry{st.lru.begin(), slot});
-            pt_slot[i] = slot;
-            mark(slot);
-            if (st.lru.size() >= st.capacity) {  // ndt cpp:161-165: drop the least recently used voxel
-                const unsigned long long old = st.lru.back();
-                auto oit = st.map.find(old);
-                died.push_back(oit->second.slot);
-                st.map.erase(oit);
-                st.lru.pop_back();
-            }
-        } else {
-            st.lru.splice(st.lru.begin(), st.lru, it->second.it);  // touched ⇒ most recent (ndt cpp:169-170)
-            it->second.it = st.lru.begin();
-            pt_slot[i] = it->second.slot;
-            mark(it->second.slot);
-        }
+    if (n == 0) return hipSuccess;
+    if (n > 0x7FFFFFF0ull) return hipErrorInvalidValue;
+    st.epoch++;
+    const unsigned long long epoch_hi = (unsigned long long)st.epoch << 32;
+    INC_TRY(ensure_points(st, n, s));
+    INC_TRY(sort_and_look_up(st, d_pts, n, false, s));
+    *bad_key = st.h_ctr[1] != 0;
+    const int m = st.h_ctr[0] - st.h_ctr[3];                   // distinct voxels the cloud touches
+    const int m_new = st.h_ctr[2];                             // … of which not alive yet
+    const long long M = (long long)st.capacity - 1;            // voxels the reference's list holds after every point (ndt cpp:161-165)
+    if (m == 0) return hipSuccess;                             // every point skipped: nothing changes
+    const int n_evict = (long long)m > M ? -1 : (int)std::max<long long>(0, (long long)st.n_live + m_new - M);
+    static const bool dbg = getenv("LOCGPU_INC_DEBUG") != nullptr;  // which path a call took (the determinism harness asserts it has seen all three)
+    if (dbg) fprintf(stderr, "[locgpu inc-ndt] call %u: %zu points, %d voxels touched (%d new), %d alive, capacity %zu: %s\n", st.epoch, n, m, m_new, st.n_live, st.capacity,
+                     n_evict < 0 ? "replayed on the host" : (n_evict > 0 ? "device path with evictions" : "device path, no eviction"));
+    if (n_evict < 0) return ingest_replayed(st, host_pts, d_pts, n, s);
+    const int n_free_after_evict = st.n_free + n_evict;
+    const int n_fresh = std::max(0, m_new - n_free_after_evict);
+    INC_TRY(ensure_slots(st, (size_t)(st.n_slots + n_fresh), s));
+    hipLaunchKernelGGL(inc_touch_kernel, dim3(grid_for((size_t)m)), dim3(kBlock), 0, s, st.d_uslot, st.d_ustart, st.d_sidx, m, epoch_hi, st.d_slot_stamp);
+    if (n_evict > 0) {
+        INC_TRY(ensure_evict(st, (size_t)st.n_live, s));
+        hipLaunchKernelGGL(inc_collect_kernel, dim3(grid_for((size_t)st.n_slots)), dim3(kBlock), 0, s, st.d_slot_key, st.d_slot_stamp, st.n_slots, st.d_ev_stamp, st.d_ev_slot, st.d_ctr);
+        size_t tb = st.temp_bytes;
+        INC_TRY(hipcub::DeviceRadixSort::SortPairs(st.d_temp, tb, st.d_ev_stamp, st.d_ev_stamp_sorted, st.d_ev_slot, st.d_ev_slot_sorted, st.n_live, 0, 64, s));
+        hipLaunchKernelGGL(inc_evict_kernel, dim3(grid_for((size_t)n_evict)), dim3(kBlock), 0, s, st.d_ev_slot_sorted, n_evict, st.n_free, st.d_slot_key, st.d_free);
     }
-    INC_TRY(grow(st, (size_t)std::max(st.n_slots, 1), s));
-    dead.assign(st.slot_cap, 0);
-    for (int sl : died) dead[sl] = 1;
-    // active voxels that were evicted again within this very call are not updated (the reference would dereference a
-    // default-constructed iterator there, ndt cpp:178)
-    std::vector<int> live_active;
-    for (int sl : active) if (!dead[sl]) live_active.push_back(sl);
-
-    int *d_pt_slot = nullptr, *d_active = nullptr;
-    hipError_t rc = hipSuccess;
-    auto run = [&]() -> hipError_t {
-        INC_TRY(hipMalloc((void**)&d_pt_slot, std::max<size_t>(n, 1) * sizeof(int)));
-        INC_TRY(hipMalloc((void**)&d_active, std::max<size_t>(live_active.size(), 1) * sizeof(int)));
-        INC_TRY(hipMemcpyAsync(d_pt_slot, pt_slot.data(), n * sizeof(int), hipMemcpyHostToDevice, s));
-        INC_TRY(hipMemcpyAsync(d_active, live_active.data(), live_active.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        INC_TRY(hipMemcpyAsync(st.d_dead, dead.data(), st.slot_cap, hipMemcpyHostToDevice, s));
-        INC_TRY(hipMemsetAsync(st.d_counts, 0, st.slot_cap * sizeof(int), s));
-        INC_TRY(hipMemsetAsync(st.d_sums, 0, st.slot_cap * 3 * sizeof(double), s));
-        INC_TRY(hipMemsetAsync(st.d_cov, 0, st.slot_cap * 6 * sizeof(double), s));
-        const unsigned gn = (unsigned)((n + kBlock - 1) / kBlock), ga = (unsigned)((live_active.size() + kBlock - 1) / kBlock);
-        if (n && !live_active.empty()) {
-            hipLaunchKernelGGL(inc_sum_kernel, dim3(gn), dim3(kBlock), 0, s, d_pts, d_pt_slot, n, st.d_dead, st.d_sums, st.d_counts);
-            hipLaunchKernelGGL(inc_mean_kernel, dim3(ga), dim3(kBlock), 0, s, d_active, (int)live_active.size(), st.d_sums, st.d_counts, st.d_mu);
-            hipLaunchKernelGGL(inc_cov_kernel, dim3(gn), dim3(kBlock), 0, s, d_pts, d_pt_slot, n, st.d_dead, st.d_mu, st.d_cov);
-            hipLaunchKernelGGL(inc_info_kernel, dim3(ga), dim3(kBlock), 0, s, d_active, (int)live_active.size(), st.d_counts, st.d_cov, st.d_info);
-        }
-        // rebuild the key → slot table from the live map
-        std::vector<unsigned long long> keys;
-        std::vector<int> slots;
-        keys.reserve(st.map.size());
-        slots.reserve(st.map.size());
-        for (const auto& kv : st.map) { keys.push_back(kv.first); slots.push_back(kv.second.slot); }
-        size_t cap = 1024;
-        while (cap < 2 * keys.size()) cap <<= 1;
-        if (cap != st.table_cap) {
-            (void)hipFree(st.d_keys); (void)hipFree(st.d_vid);
-            st.d_keys = nullptr; st.d_vid = nullptr;
-            INC_TRY(hipMalloc((void**)&st.d_keys, cap * sizeof(unsigned long long)));
-            INC_TRY(hipMalloc((void**)&st.d_vid, cap * sizeof(int)));
-            st.table_cap = cap;
-        }
-        hipLaunchKernelGGL(inc_fill_kernel, dim3((unsigned)((cap + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, st.d_keys, cap, kNdtEmpty);
-        unsigned long long* d_kin = nullptr;
-        int* d_sin = nullptr;
-        if (!keys.empty()) {
-            INC_TRY(hipMalloc((void**)&d_kin, keys.size() * sizeof(unsigned long long)));
-            hipError_t e = hipMalloc((void**)&d_sin, slots.size() * sizeof(int));
-            if (e != hipSuccess) { (void)hipFree(d_kin); return e; }
-            (void)hipMemcpyAsync(d_kin, keys.data(), keys.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s);
-            (void)hipMemcpyAsync(d_sin, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice, s);
-            hipLaunchKernelGGL(inc_table_kernel, dim3((unsigned)((keys.size() + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d_kin, d_sin, (int)keys.size(),
-                               st.d_keys, st.d_vid, cap - 1);
-        }
-        hipError_t e = hipStreamSynchronize(s);
-        if (d_kin) (void)hipFree(d_kin);
-        if (d_sin) (void)hipFree(d_sin);
-        if (e != hipSuccess) return e;
-        return hipGetLastError();
-    };
-    rc = run();
-    if (d_pt_slot) (void)hipFree(d_pt_slot);
-    if (d_active) (void)hipFree(d_active);
-    for (int sl : died) st.free_slots.push_back(sl);  // recycle only now: no slot is reused within the call that freed it
-    return rc;
+    if (m_new > 0) {
+        size_t tb = st.temp_bytes;
+        INC_TRY(hipcub::DeviceScan::ExclusiveSum(st.d_temp, tb, st.d_unew, st.d_urank, m, s));
+        hipLaunchKernelGGL(inc_assign_kernel, dim3(grid_for((size_t)m)), dim3(kBlock), 0, s, st.d_ukey, st.d_unew, st.d_urank, st.d_ustart, st.d_sidx, m, st.d_free,
+                           n_free_after_evict, st.n_slots, epoch_hi, st.d_slot_key, st.d_slot_stamp, st.d_uslot);
+    }
+    INC_TRY(hipGetLastError());
+    st.n_free = std::max(0, n_free_after_evict - m_new);
+    st.n_slots += n_fresh;
+    st.n_live += m_new - n_evict;
+    return rebuild_table_and_stats(st, m, s);
 }
 
 void launch_inc_accum(const IncNdtState* st, double res_th, int n_nearby, const float4* src, const int* counts, const PoseState* ps, int max_n,
@@ -395,16 +619,19 @@ void launch_inc_accum(const IncNdtState* st, double res_th, int n_nearby, const 
 }
 
 size_t inc_ndt_dump(const IncNdtState* st, int32_t* keys, double* mu, double* info, size_t cap) {
-    std::vector<double> h_mu((size_t)st->n_slots * 3), h_info((size_t)st->n_slots * 9);
-    if (st->n_slots) {
+    const size_t ns = (size_t)st->n_slots;
+    std::vector<unsigned long long> h_key(ns);
+    std::vector<double> h_mu(ns * 3), h_info(ns * 9);
+    if (ns) {
+        (void)hipMemcpy(h_key.data(), st->d_slot_key, ns * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         (void)hipMemcpy(h_mu.data(), st->d_mu, h_mu.size() * sizeof(double), hipMemcpyDeviceToHost);
         (void)hipMemcpy(h_info.data(), st->d_info, h_info.size() * sizeof(double), hipMemcpyDeviceToHost);
     }
     size_t n = 0;
-    for (const auto& kv : st->map) {
+    for (size_t sl = 0; sl < ns; ++sl) {
+        const unsigned long long k = h_key[sl];
+        if (k == kNdtEmpty) continue;
         if (n < cap) {
-            const unsigned long long k = kv.first;
-            const size_t sl = (size_t)kv.second.slot;
             if (keys) {
                 keys[3 * n + 0] = (int)((k >> 42) & 0x1FFFFF) - kNdtBias;
                 keys[3 * n + 1] = (int)((k >> 21) & 0x1FFFFF) - kNdtBias;

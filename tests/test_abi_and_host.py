@@ -229,6 +229,31 @@ def test_host_tree_build_pool_under_thread_sanitizer(tmp_path):
     assert r.returncode == 0 and "tsan harness ok" in r.stdout, r.stdout[-1000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_inc_ndt_host_replay_under_sanitizers(tmp_path, san):
+    """the host side of SetIncNdtTargetCloud (csrc/inc_ndt_lru.hpp — the per-point LRU replay used when a
+    cloud's working set exceeds the voxel capacity) under ASan + UBSan and under TSan, checked against a plain restatement of the
+    reference's list + map loop (ndt_registration.cpp:150-171) on random multi-call sequences; the same harness proves the closed
+    form the device path uses (top capacity-1 recency stamps) equal to the sequential replay whenever it applies."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    csrc = os.path.join(ROOT, "loc_lib_amd", "csrc")
+    exe = str(tmp_path / "inc_ndt_host_sanitize")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-I", csrc, os.path.join(ROOT, "tests", "cpp", "inc_ndt_host_sanitize.cpp"), "-o", exe]
+    if san != "thread":
+        cmd.insert(5, "-fno-sanitize-recover=undefined")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and ("sanitize" in r.stderr or "tsan" in r.stderr):
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    if r.returncode != 0 and "unexpected memory mapping" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
+    assert r.returncode == 0 and "inc-ndt host harness ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 # ----------------------------------------------------------------------------------------------- bench.py launcher (no GPU needed)
 def _load_bench():
     import importlib.util

@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Determinism + parity harness for the NDT targets (run ON the GPU box). VERDICT r3 item 1: one incremental-NDT fuzz case came out
+wrong ONCE in round 3 and never again — the signature of uninitialised device memory or a missing ordering. This harness repeats
+the sequence that case ran in (fresh direct-NDT / ICP contexts alternating with fresh incremental-NDT contexts in one process, so
+that every allocation lands on memory another context has just freed) thousands of times and demands BITWISE equality:
+
+  * every repetition's incremental voxel table (`locgpu_ndt_dump`: keys, mu, info) equals the first repetition's bit for bit,
+    and equals the ORACLE's table bit for bit (the device sums a voxel's points sequentially in input order, like
+    math::ComputeMeanAndCov, math_utils.h:55-72);
+  * every repetition's pose, iteration count and status equal the first repetition's bit for bit and the oracle's to 1e-12 / exactly.
+
+Three incremental configurations cover the three ways a SetIncNdtTargetCloud call can go (LOCGPU_INC_DEBUG reports which one ran, and
+the harness insists it has seen all three): capacity 300 (the cloud's own working set exceeds the capacity: per-point replay on the
+host), 3000 (device path with LRU evictions on the second cloud), 100000 (the reference default: device path, nothing evicted).
+
+    python tools/ndt_determinism.py [--reps 5000]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("LOCGPU_INC_DEBUG", "1")
+from loc_lib_amd import api, synth  # noqa: E402
+from oracle import locref  # noqa: E402
+
+
+def sorted_dump(keys, mu, info):
+    o = np.lexsort(keys.T[::-1])
+    return keys[o], mu[o], np.asarray(info)[o].reshape(len(o), 9)
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5000)
+    ap.add_argument("--map-points", type=int, default=60000)
+    ap.add_argument("--seconds", type=float, default=0.0, help="stop after this many seconds (0 = run all repetitions)")
+    a = ap.parse_args()
+    sid = 17
+    m1 = synth.make_local_map(a.map_points, sid, half=40.0)
+    m2 = synth.make_local_map(a.map_points // 2, sid + 1, half=40.0)
+    scan = synth.make_scan(sid, subsample=5000, crop_half=36.0)
+    _, init = synth.make_pose(sid, trans_amp=0.4, rot_amp_deg=3.0, seed=5)
+    kw = dict(voxel_size=2.1311215983306657, nearby_type=1, min_pts_in_voxel=3, res_outlier_th=100.0, min_effective_pts=200, max_iteration=30)
+    caps = [300, 3000, 100000]
+    want = {}
+    for cap in caps:  # the oracle, once per configuration
+        ref = locref.Ndt(method=api.INCREMENTAL_NDT, capacity=cap, **kw)
+        ref.set_target(m1)
+        ref.set_target(m2)
+        r = ref.align(scan, init)
+        want[cap] = dict(dump=sorted_dump(*ref.dump()), pose=r["pose"], iters=r["iters"], status=r["status"], voxels=ref.num_voxels())
+        print("oracle capacity %6d: %5d voxels, %2d iterations, status %d" % (cap, want[cap]["voxels"], r["iters"], r["status"]), flush=True)
+    # stderr of the library (LOCGPU_INC_DEBUG) goes through a pipe so that the paths taken can be counted
+    rfd, wfd = os.pipe()
+    saved = os.dup(2)
+    os.dup2(wfd, 2)
+    os.set_blocking(rfd, False)
+    log = b""
+    first = {}
+    bad = 0
+    t0 = time.time()
+    done = 0
+    try:
+        for rep in range(a.reps):
+            cap = caps[rep % len(caps)]
+            c1 = api.Context(0)  # what ran between two incremental cases of the fuzz run: a direct-NDT and an ICP alignment on another context
+            c1.ndt_set_target(m1, api.ndt_opts(voxel_size=0.5 + 0.01 * (rep % 50), min_pts_in_voxel=3))
+            c1.ndt_align(scan, init)
+            if rep % 4 == 0:
+                c1.icp_set_target(m2)
+                c1.icp_align(scan, init, api.icp_opts(method=api.P2PLANE))
+            del c1
+            c2 = api.Context(0)
+            c2.ndt_set_target(m1, api.ndt_opts(method=api.INCREMENTAL_NDT, capacity=cap, **kw))
+            c2.ndt_set_target(m2, api.ndt_opts(method=api.INCREMENTAL_NDT, capacity=cap, **kw))
+            got, st = c2.ndt_align(scan, init)
+            dump = sorted_dump(*c2.ndt_dump())
+            del c2
+            w = want[cap]
+            problems = []
+            if not all(same_bits(x, y) for x, y in zip(dump, w["dump"])):
+                if not same_bits(dump[0], w["dump"][0]):
+                    problems.append("voxel keys differ from the oracle's (%d vs %d voxels)" % (len(dump[0]), len(w["dump"][0])))
+                else:
+                    problems.append("table differs from the oracle's bits: max |dmu| %.3e, max |dinfo| %.3e" % (np.abs(dump[1] - w["dump"][1]).max(), np.abs(dump[2] - w["dump"][2]).max()))
+            if st["iterations"] != w["iters"] or st["status"] != w["status"] or np.abs(got - w["pose"]).max() > 1e-12:
+                problems.append("alignment differs from the oracle: iterations %d/%d status %d/%d |dpose| %.2e" % (st["iterations"], w["iters"], st["status"], w["status"], np.abs(got - w["pose"]).max()))
+            if cap in first:
+                f = first[cap]
+                if not all(same_bits(x, y) for x, y in zip(dump, f["dump"])):
+                    problems.append("table differs from repetition %d's bits" % f["rep"])
+                if not same_bits(got, f["pose"]) or st != f["st"]:
+                    problems.append("pose / stats differ from repetition %d's bits: |dpose| %.2e" % (f["rep"], np.abs(got - f["pose"]).max()))
+            else:
+                first[cap] = dict(dump=dump, pose=got.copy(), st=dict(st), rep=rep)
+            if problems:
+                bad += 1
+                sys.stdout.write("rep %d capacity %d MISMATCH: %s\n" % (rep, cap, "; ".join(problems)))
+                sys.stdout.flush()
+            done = rep + 1
+            try:
+                while True:
+                    chunk = os.read(rfd, 1 << 16)
+                    if not chunk:
+                        break
+                    log += chunk
+                    log = log[-(1 << 20):] if len(log) > (1 << 21) else log
+            except BlockingIOError:
+                pass
+            if a.seconds and time.time() - t0 > a.seconds:
+                break
+    finally:
+        os.dup2(saved, 2)
+        os.close(wfd)
+    text = log.decode(errors="replace")
+    paths = {p: text.count(p) for p in ("replayed on the host", "device path with evictions", "device path, no eviction")}
+    print("paths seen in the library's log (tail): %s" % paths)
+    missing = [p for p, c in paths.items() if c == 0]
+    if missing:
+        bad += 1
+        print("MISMATCH: ingest path(s) never taken: %s" % missing)
+    print("repetitions %d (%.0f s): mismatches %d" % (done, time.time() - t0, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
