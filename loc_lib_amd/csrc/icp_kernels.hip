@@ -141,7 +141,7 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
 // K1, round 3: the traversal of search_walk.hpp. One-wave workgroups; dynamic LDS = DF rows x 64 lanes x 8 B (the stack is the
 // ONLY LDS of the kernel: a row below its bottom must lie outside the allocation). `dummy` = slot of the sentinel leaf.
 // Every lane of the wave must call walk_query (wave-wide ballots inside); a lane without a query passes valid = false.
-template <int K, int ROWB, int MODE>  // MODE 0: flat trips, 2: rounds, 12: rounds capped at two internal steps (default)
+template <int K, int ROWB, int MODE, bool STAMP = false>  // MODE 0: flat trips, 2: rounds, 12: rounds capped at two internal steps (default)
 __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const uint2* __restrict__ tree, Walk<K>& w, bool valid, float alpha_eff, int T, uint32_t dummy,
                                            uint32_t col_addr, int cap) {
 #pragma unroll
@@ -155,7 +155,7 @@ __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const ui
         w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = valid ? 1u : 0u;
     }
     if (MODE == 2) walk_rounds<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr, cap);
-    else if (MODE == 12) walk_rounds_capped<K, ROWB, 2>(rsrc, w, alpha_eff, dummy, col_addr, cap);
+    else if (MODE == 12) walk_rounds_capped<K, ROWB, 2, STAMP>(rsrc, w, alpha_eff, dummy, col_addr, cap);
     else do walk_trip<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr, cap); while (__ballot(w.cur != dummy || w.avail > 0) != 0ull);
 #pragma unroll
     for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;  // equal distances in the final set: heap pop order is layout-dependent
@@ -186,7 +186,7 @@ __device__ __forceinline__ bool walk_exact_in_wave(const uint2* __restrict__ tre
 
 // LANES = active lanes per wave = stack columns (64; 16 for launches that cannot fill the chip anyway: a wave's time is its
 // longest traversal, and with 128-byte rows every level fits in LDS — T = 0 — so that no query needs the deep pass).
-template <int K, int DF, int MODE, int LANES = 64>
+template <int K, int DF, int MODE, int LANES = 64, bool STAMP = false>
 __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                              const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                              uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, float alpha_eff, int T,
@@ -218,7 +218,15 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
     Walk<K> w;
     w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
-    walk_query<K, ROWB, MODE>(rsrc, tree, w, true, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]), DF);  // DF rows: a stack that outgrows them → deep pass
+    walk_query<K, ROWB, MODE, STAMP>(rsrc, tree, w, true, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]), DF);  // DF rows: a stack that outgrows them → deep pass
+    if (STAMP && search_stats) {
+        // diagnostic build (LOCGPU_STAMP=1, MODE 12): rounds each lane needed against the rounds its wave ran — the kernel's lane
+        // efficiency — and the per-query round counts behind the neighbour-list area of redo_list (2 x pitch entries in this build)
+        atomicAdd(&search_stats[4], (unsigned long long)w.rounds);
+        if ((tid & 63) == 0) { atomicAdd(&search_stats[9], (unsigned long long)w.wave_rounds); atomicAdd(&search_stats[12], 1ull); }
+        atomicAdd(&search_stats[13], (unsigned long long)w.wave_rounds);  // rounds paid by this lane's wave, summed over lanes
+        redo_list[nn_pitch + gi] = w.rounds;
+    }
     const bool deep = w.c3n == 1u;
     const bool slow = !deep && w.slow != 0u;
     if (!deep && !slow) {
@@ -908,10 +916,19 @@ static bool launch_fast_kd(const SearchArgs& a, hipStream_t s) {
     const int T = a.depth > DF ? a.depth - DF : 0;  // leading stack positions the fast kernel does not store
     // a.redo_count is zero here: the caller clears it before an alignment's first iteration, gn_solve_kernel after every search
     static const bool stamp = [] { const char* e = getenv("LOCGPU_STAMP"); return e && atoi(e) != 0; }();
-    if (stamp) {  // diagnostic build of the default shape; results unchanged, timing meaningless
-        dim3 g2((a.max_n + 63) / 64, a.n_scans);
-        hipLaunchKernelGGL((icp_search_fast_kernel<K, DF, 64, true>), g2, dim3(64), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.alpha_eff, T, (unsigned int)a.tree_bytes, a.skip_nonfinite, a.redo_list, a.redo_count, a.search_stats, 64);
+    if (stamp && a.redo_list2) {
+        // diagnostic build of the default shape (capped rounds, 64 lanes, DF rows) that counts rounds per lane and per wave:
+        // results unchanged, timing meaningless. search_stats[4] = Σ lane rounds, [13] = Σ over lanes of their wave's rounds,
+        // [9] = Σ wave rounds, [12] = waves; per-query rounds at redo_list[pitch + gi] (locgpu_debug_stamp_trips).
+        const uint32_t dummy = (uint32_t)(a.tree_bytes / 8);
+        const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
+        const int n_launch = a.active ? a.n_active : a.n_scans;
+        dim3 g2((a.max_n + 63) / 64, n_launch);
+        hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, 12, 64, true>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+                           a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
+                           a.search_stats, a.active);
+        hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(2048), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
+                           a.alpha_eff, (unsigned int)a.tree_bytes + 16u, dummy, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count, a.search_stats);
         hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                            a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
         return true;

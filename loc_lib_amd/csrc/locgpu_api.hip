@@ -1263,19 +1263,13 @@ int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset) {
     for (hipStream_t st : ctx->slot_stream) LOCGPU_HIP(ctx, hipStreamSynchronize(st));
     unsigned long long h[kSearchStatSlots];
     LOCGPU_HIP(ctx, hipMemcpy(h, ctx->d_search_stats, sizeof(h), hipMemcpyDeviceToHost));
-    out[0] = h[0]; out[1] = h[1]; out[2] = getenv("LOCGPU_STAMP") ? 0 : h[2]; out[3] = getenv("LOCGPU_STAMP") ? h[15] : 0;
-    if (getenv("LOCGPU_STAMP") && h[12]) {  // diagnostic build only
-        const double q = (double)h[0], w = (double)h[12];
-        fprintf(stderr, "[locgpu stamp] per lane: descent %.0f cyc, total %.0f cyc, trips %.1f (visit %.1f, pop-only %.1f) | per wave (max over lanes): "
-                        "descent %.0f cyc, total %.0f cyc, trips %.1f (visit %.1f, pop %.1f)\n",
-                h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / w, h[8] / w, h[9] / w, h[10] / w, h[11] / w);
-        // histograms of main-loop trips (bins of two trips): what a lane needs, and what its wave pays (the maximum over its lanes)
-        fprintf(stderr, "[locgpu stamp] main-loop trips, lanes:");
-        for (int j = 0; j < 64; ++j) fprintf(stderr, " %llu", h[16 + j]);
-        fprintf(stderr, "\n[locgpu stamp] main-loop trips, wave maxima:");
-        for (int j = 0; j < 64; ++j) fprintf(stderr, " %llu", h[80 + j]);
-        fprintf(stderr, "\n");
-    }
+    static const bool stamp = getenv("LOCGPU_STAMP") != nullptr;
+    // diagnostic build (LOCGPU_STAMP=1): out[2] = Σ over queries of the main-loop rounds the query needed, out[3] = Σ over queries of
+    // the rounds its wave ran (what the wave paid for that lane) — lane efficiency of the search kernel = out[2] / out[3]
+    out[0] = h[0]; out[1] = h[1]; out[2] = stamp ? h[4] : h[2]; out[3] = stamp ? h[13] : 0;
+    if (stamp && h[12])
+        fprintf(stderr, "[locgpu stamp] %llu queries in %llu waves: %.2f rounds per lane, %.2f per wave; lane efficiency %.3f\n", h[0], h[12], (double)h[4] / (double)h[0],
+                (double)h[9] / (double)h[12], (double)h[4] / (double)std::max<unsigned long long>(h[13], 1ull));
     if (getenv("LOCGPU_WALK_DEBUG")) fprintf(stderr, "[locgpu walk] searched %llu exact-in-wave+redo %llu overflow %llu tie-evict %llu replays %llu slow %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
     if (reset) LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, sizeof(h)));
     return LOCGPU_OK;
@@ -1307,8 +1301,8 @@ int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset) {
 
 }  // extern "C"
 
-// Diagnostic build only (LOCGPU_STAMP=1 when the batch was created): per query (first-descent trips << 16 | main-loop trips) of the batch's
-// most recent search stage, out[n_scans * max_n].
+// Diagnostic build only (LOCGPU_STAMP=1 when the batch was created): per query the main-loop rounds it needed in the batch's most
+// recent search stage, out[n_scans * max_n].
 extern "C" __attribute__((visibility("default"))) int locgpu_debug_stamp_trips(locgpu_ctx* ctx, locgpu_batch* b, uint32_t* out) {
     if (!ctx || !b || !out || !getenv("LOCGPU_STAMP")) return LOCGPU_ERR_INVALID;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));

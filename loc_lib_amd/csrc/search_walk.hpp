@@ -42,6 +42,7 @@ struct Walk {
     int avail;         // rows on the stack
     uint32_t c3n;      // bits of −(third smallest d² of the un-stored levels); 0 = none; 1 = the query needs the deep pass
     uint32_t slow;
+    uint32_t rounds, wave_rounds;  // LOCGPU_STAMP diagnostic build only: main-loop rounds this lane needed / its wave ran
 };
 
 typedef uint32_t __attribute__((address_space(3))) lds_u32;
@@ -331,11 +332,12 @@ __device__ __forceinline__ void walk_rounds(__amdgpu_buffer_rsrc_t rsrc, Walk<K>
 // Capped rounds: like walk_rounds, but a round runs at most C internal steps; a lane that has not reached its leaf by then sits
 // out the next leaf stage (x = +inf, pop switched off) and keeps descending after it. Between the flat loop (C = 1, both blocks
 // every trip) and the rounds loop (C = ∞: every round waits for the wave's longest descent).
-template <int K, int ROWB, int C>
+template <int K, int ROWB, int C, bool STAMP = false>
 __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr, int cap) {
     const float qx = w.qx, qy = w.qy, qz = w.qz;
     uint32_t cur = w.cur;
     int avail = w.avail;
+    uint32_t my_rounds = 0, all_rounds = 0;  // STAMP: rounds in which this lane still had work / rounds the wave ran
     float d[K];
     uint32_t id[K];
 #pragma unroll
@@ -343,6 +345,7 @@ __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, 
     uint32_t slow = w.slow, c3n = w.c3n;
     u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
     do {
+        if (STAMP) { my_rounds += (cur != dummy || avail > 0) ? 1u : 0u; all_rounds++; }
         const bool is_leaf = n.y >= 0xC0000000u;
         const uint32_t a4 = col_addr + (uint32_t)(avail - 4) * ROWB;
         const u32x2 r3 = *reinterpret_cast<lds_u32x2*>(a4), r2 = *reinterpret_cast<lds_u32x2*>(a4 + ROWB),
@@ -415,6 +418,7 @@ __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, 
 #pragma unroll
     for (int j = 0; j < K; ++j) { w.d[j] = d[j]; w.id[j] = id[j]; }
     w.slow = slow; w.c3n = c3n; w.cur = cur; w.avail = avail;
+    if (STAMP) { w.rounds = my_rounds; w.wave_rounds = all_rounds; }
 }
 
 }  // namespace locgpu

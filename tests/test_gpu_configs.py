@@ -405,6 +405,21 @@ def test_bench_line_contract(mode):
     assert d["config"]["pipeline_depth"] == 3 and "roofline_k2" in d
 
 
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` brings up N ranks itself — and on a box with fewer GPUs it fails loudly instead of
+    running one rank and printing n_gpus 1 (what a SCALE run would otherwise record eight times)."""
+    import os
+    import subprocess
+    import sys
+    from loc_lib_amd import api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = api.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and ("--gpus %d but this node has %d GPU" % (n, n - 1)) in out.stderr, out.stderr[-1500:]
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
 # ----------------------------------------------------------------------------------------------- other LDS stack depths
 @pytest.mark.parametrize("rows", ["12", "24"])
 def test_search_parity_at_other_stack_depths(rows):
