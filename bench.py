@@ -272,12 +272,10 @@ def main():
     if args.scaling is None:
         args.scaling = "strong" if world > 1 else "weak"
 
-    from loc_lib_amd import api as _api_probe
-    n_dev = _api_probe.device_count()
+    import torch  # before the library: torch brings its own HIP runtime and must be the first to load one in this process
+    n_dev = torch.cuda.device_count()  # counts without initialising the GPU
     if local_rank >= n_dev:
         raise SystemExit("bench.py: rank %d (local rank %d) has no GPU: this node has %d" % (rank, local_rank, n_dev))
-
-    import torch
     dist = None
     if world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ):  # launched by torch.distributed.run (even with one rank)
         import torch.distributed as dist

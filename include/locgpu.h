@@ -229,9 +229,10 @@ LOCGPU_API int locgpu_graph_enable(locgpu_ctx* ctx, int on);
 LOCGPU_API int locgpu_profile_enable(locgpu_ctx* ctx, int on);
 LOCGPU_API int locgpu_profile_read(locgpu_ctx* ctx, double out[6], int reset);
 /* Total tree nodes / leaves visited by the search kernel of the NEXT align/hb call(s) when counting is on
- * (separate instrumented kernel; never on in timed runs). out[0]=nodes, out[1]=leaves, out[2]=queries. */
+ * (separate instrumented kernel; never on in timed runs). out[0]=nodes, out[1]=leaves, out[2]=queries, out[3]=distinct 8-byte
+ * tree slots a search launch read at all, summed over the launches (the compulsory tree traffic of the search stage). */
 LOCGPU_API int locgpu_visit_count_enable(locgpu_ctx* ctx, int on);
-LOCGPU_API int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset);
+LOCGPU_API int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[4], int reset);
 
 /* Search bookkeeping since the last reset (enabled by the first call): out[0] = queries handled by the fast search
  * kernel's launches, out[1] = queries it handed to the exact redo kernel (distance ties / near-misses on the top tree levels),

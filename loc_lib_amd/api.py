@@ -432,9 +432,9 @@ class Context:
         self._check(lib().locgpu_visit_count_enable(self._h, int(on)))
 
     def visit_count_read(self, reset=True):
-        out = np.zeros(3, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
         self._check(lib().locgpu_visit_count_read(self._h, out.ctypes.data, int(reset)))
-        return dict(nodes=int(out[0]), leaves=int(out[1]), queries=int(out[2]))
+        return dict(nodes=int(out[0]), leaves=int(out[1]), queries=int(out[2]), distinct_slots=int(out[3]))
 
 
     def debug_batch_nn(self, batch, k=5):

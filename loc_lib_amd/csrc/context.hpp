@@ -72,7 +72,9 @@ struct locgpu_ctx {
     long long prof_n[3] = {0, 0, 0};
     bool use_graph = false;  // replay a captured hipGraph of all GN iterations instead of eager chunks
     bool count_visits = false;
-    unsigned long long* d_visits = nullptr;
+    unsigned long long* d_visits = nullptr;  // [4]: nodes, leaves, queries, distinct tree slots read (summed over launches)
+    uint32_t* d_touched = nullptr;           // instrumented pass: one bit per tree slot
+    size_t touched_words = 0;
     unsigned long long* d_search_stats = nullptr;  // [2]: queries searched / queries redone by the exact kernel
 };
 

@@ -13,7 +13,7 @@ template <int KMAX, int D, bool COUNT, int VARIANT = 0>
 __global__ __launch_bounds__(kBlock) void icp_search_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                             const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                             uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, int k, float alpha_eff,
-                                                            int skip_nonfinite, unsigned long long* __restrict__ visit_totals) {
+                                                            int skip_nonfinite, unsigned long long* __restrict__ visit_totals, uint32_t* __restrict__ touched) {
     __shared__ uint32_t s_far[D][kBlock];
     __shared__ float s_d2[D][kBlock];
     const int scan = blockIdx.y;
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kBlock) void icp_search_kernel(const uint2* __restr
     if (finite) {
         const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
         KnnHeap<KMAX> heap;
-        if (VARIANT != 9) tree_knn_flat<KMAX, D, COUNT>(tree, (float)qs.x, (float)qs.y, (float)qs.z, k, alpha_eff, s_far, s_d2, tid, heap, nvis, lvis);
+        if (VARIANT != 9) tree_knn_flat<KMAX, D, COUNT>(tree, (float)qs.x, (float)qs.y, (float)qs.z, k, alpha_eff, s_far, s_d2, tid, heap, nvis, lvis, touched);
         else tree_knn<KMAX, D, COUNT>(tree, (float)qs.x, (float)qs.y, (float)qs.z, k, alpha_eff, s_far, s_d2, tid, heap, nvis, lvis);
         heap_to_sorted<KMAX>(heap, out, cnt);
     } else {
@@ -798,6 +798,17 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* __re
     if (threadIdx.x < kAccW) acc[(size_t)g * kAccW + threadIdx.x] = threadIdx.x < 28 ? t : 0.0;
 }
 
+// Instrumented pass: number of tree slots a search launch read at all (bitmap of tree_knn_flat), added to totals[3]; the bitmap is cleared.
+__global__ __launch_bounds__(kBlock) void count_touched_kernel(uint32_t* __restrict__ touched, size_t n_words, unsigned long long* __restrict__ totals) {
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_words; i += (size_t)gridDim.x * kBlock) {
+        c += (unsigned long long)__popc(touched[i]);
+        touched[i] = 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&totals[3], c);
+}
+
 // pcl::transformPointCloud with the float32 4×4 (icp_registration.cpp:241): ((m0·x + m1·y) + m2·z) + m3 per row.
 __global__ __launch_bounds__(kBlock) void transform_cloud_kernel(const float4* __restrict__ src, size_t n, const float* __restrict__ m12,
                                                                  float4* __restrict__ dst) {
@@ -834,17 +845,17 @@ static void launch_search_kd(const SearchArgs& a, hipStream_t s) {
     dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
     if (a.visit_totals)
         hipLaunchKernelGGL((icp_search_kernel<KMAX, D, true>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals);
+                           a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals, a.touched);
     else
         hipLaunchKernelGGL((icp_search_kernel<KMAX, D, false>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals);
+                           a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals, nullptr);
 }
 // EXPERIMENT hook (timing only; variants 2-4 truncate the stack and give wrong neighbours): LOCGPU_SEARCH_VARIANT
 template <int KMAX, int D, int V>
 static void launch_search_exp(const SearchArgs& a, hipStream_t s) {
     dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
     hipLaunchKernelGGL((icp_search_kernel<KMAX, D, false, V>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                       a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals);
+                       a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals, nullptr);
 }
 static int search_variant() {
     static int v = -1;
@@ -1101,6 +1112,10 @@ void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st,
 void launch_sum_partials(const double* partials, int blocks_per_scan, const PoseState* st_all, int first, int n_local, int n_total, double* acc,
                          hipStream_t s) {
     hipLaunchKernelGGL(sum_partials_kernel, dim3(n_total), dim3(kBlock), 0, s, partials, blocks_per_scan, st_all, first, n_local, acc);
+}
+
+void launch_count_touched(uint32_t* touched, size_t n_words, unsigned long long* totals, hipStream_t s) {
+    hipLaunchKernelGGL(count_touched_kernel, dim3(1024), dim3(kBlock), 0, s, touched, n_words, totals);
 }
 
 void launch_transform_cloud(const float4* src, size_t n, const float* m12, float4* dst, hipStream_t s) {

@@ -210,7 +210,7 @@ __device__ __forceinline__ void tree_knn(const uint2* __restrict__ tree, float q
 template <int KMAX, int D, bool COUNT, int BLK = kBlock>
 __device__ __forceinline__ void tree_knn_flat(const uint2* __restrict__ tree, float qx, float qy, float qz, int k, float alpha_eff,
                                               uint32_t (*s_far)[BLK], float (*s_d2)[BLK], int tid, KnnHeap<KMAX>& heap,
-                                              uint32_t& nvis, uint32_t& lvis) {
+                                              uint32_t& nvis, uint32_t& lvis, uint32_t* __restrict__ touched = nullptr) {
     heap.n = 0;
     int sp = 0;
     uint32_t cur = 0;
@@ -221,6 +221,11 @@ __device__ __forceinline__ void tree_knn_flat(const uint2* __restrict__ tree, fl
         if (COUNT) nvis++;
         const uint32_t meta = w.y;
         const uint32_t tag = meta >> 30;
+        // instrumented pass: one bit per 8-byte tree slot this launch reads at all (a leaf is two slots) — the compulsory tree bytes
+        if (COUNT && touched) {
+            atomicOr(&touched[cur >> 5], 1u << (cur & 31u));
+            if (tag == 3u) atomicOr(&touched[(cur + 1u) >> 5], 1u << ((cur + 1u) & 31u));
+        }
         if (tag == 3u) {
             if (COUNT) lvis++;
             const float dx = qx - as_f32(w.x), dy = qy - as_f32(w.z), dz = qz - as_f32(w.w);

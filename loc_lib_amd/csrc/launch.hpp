@@ -32,6 +32,9 @@ struct SearchArgs {
     // iterations hold a handful of scans: 460 k empty workgroups cost ≈96 µs per launch). nullptr = every scan.
     const int* active = nullptr;
     int n_active = 0;
+    // instrumented pass only: bitmap over the tree's 8-byte slots (one bit each, zeroed by the caller, counted and cleared again
+    // by launch_count_touched) — which slots this search launch reads at all
+    uint32_t* touched = nullptr;
 };
 
 struct AccumArgs {
@@ -69,6 +72,8 @@ void launch_transform_cloud(const float4* src, size_t n, const float* m12, float
 // Code-object self-test (once per process): no walk kernel owns static LDS, so every traversal stack starts at LDS address 0 —
 // the precondition of search_walk.hpp's out-of-range rows (tests/test_gpu_lds_semantics.py pins the hardware side).
 bool search_kernels_lds_ok();
+// instrumented pass: totals[3] += number of set bits of touched[0..n_words), then touched := 0
+void launch_count_touched(uint32_t* touched, size_t n_words, unsigned long long* totals, hipStream_t s);
 // test hook: slot lists [k][pitch] → original point indices out[query * k + j] (-1 = none)
 void launch_nn_to_index(const uint2* tree, const uint32_t* nn, size_t nn_pitch, size_t n_queries, int k, int32_t* out, hipStream_t s);
 

@@ -219,6 +219,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     if (ctx->d_bfnn) (void)hipFree(ctx->d_bfnn);
     free_grid(ctx);
     if (ctx->d_visits) (void)hipFree(ctx->d_visits);
+    if (ctx->d_touched) (void)hipFree(ctx->d_touched);
     if (ctx->d_search_stats) (void)hipFree(ctx->d_search_stats);
     ndt_free(ctx);
     filters_free(ctx);
@@ -713,9 +714,20 @@ bool IterLauncher::launch(int do_update) {
         if (grid_mode && !b->d_grid_qkey) { fail(ctx, LOCGPU_ERR_INVALID, "grid search: work list missing (ensure_grid_lists was not called)"); return false; }
         sa.redo_list2 = b->d_redo_list2;
         sa.active = active; sa.n_active = n_active;
+        if (sa.visit_totals && !capturing) {  // instrumented pass: which tree slots does this launch read at all? (bench.py: compulsory bytes)
+            const size_t words = (ctx->tree_slots + 2 + 31) / 32;
+            if (words > ctx->touched_words) {
+                if (ctx->d_touched) (void)hipFree(ctx->d_touched);
+                ctx->d_touched = nullptr; ctx->touched_words = 0;
+                if (hipMalloc((void**)&ctx->d_touched, words * sizeof(uint32_t)) == hipSuccess && hipMemsetAsync(ctx->d_touched, 0, words * sizeof(uint32_t), s) == hipSuccess)
+                    ctx->touched_words = words;
+            }
+            sa.touched = ctx->touched_words ? ctx->d_touched : nullptr;
+        }
         const GridSearchScratch gsc{b->d_grid_qkey, b->d_grid_sorted};
         const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, gsc, s) : launch_icp_search(sa, s);
         if (!ok_search) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
+        if (sa.touched) launch_count_touched(sa.touched, (ctx->tree_slots + 2 + 31) / 32, sa.visit_totals, s);
         mark(true);
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
         AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
@@ -1279,22 +1291,22 @@ int locgpu_visit_count_enable(locgpu_ctx* ctx, int on) {
     if (!ctx) return LOCGPU_ERR_INVALID;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     if (on && !ctx->d_visits) {
-        LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_visits, 3 * sizeof(unsigned long long)));
-        LOCGPU_HIP(ctx, hipMemset(ctx->d_visits, 0, 3 * sizeof(unsigned long long)));
+        LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_visits, 4 * sizeof(unsigned long long)));
+        LOCGPU_HIP(ctx, hipMemset(ctx->d_visits, 0, 4 * sizeof(unsigned long long)));
     }
     ctx->count_visits = on != 0;
     return LOCGPU_OK;
 }
 
-int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[3], int reset) {
+int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[4], int reset) {
     if (!ctx || !out) return LOCGPU_ERR_INVALID;
-    out[0] = out[1] = out[2] = 0;
+    out[0] = out[1] = out[2] = out[3] = 0;
     if (!ctx->d_visits) return LOCGPU_OK;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     for (hipStream_t st : ctx->slot_stream) LOCGPU_HIP(ctx, hipStreamSynchronize(st));
-    unsigned long long h[3];
+    unsigned long long h[4];
     LOCGPU_HIP(ctx, hipMemcpy(h, ctx->d_visits, sizeof(h), hipMemcpyDeviceToHost));
-    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
     if (reset) LOCGPU_HIP(ctx, hipMemset(ctx->d_visits, 0, sizeof(h)));
     return LOCGPU_OK;
 }

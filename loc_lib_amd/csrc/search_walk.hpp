@@ -392,9 +392,13 @@ __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, 
         // query to the deep pass as well. One compare and a scalar OR per stage.
         const bool deep = ((int)c3sel < nb) | (avail > cap);
         c3n = deep ? 1u : c3n;
+        // A query that goes to the deep pass is recomputed there from scratch: its lane RETIRES here (round 4) instead of finishing a
+        // traversal whose result is thrown away — these are the long traversals, the ones a wave waits for (0.5-3 % of the queries,
+        // but 30-85 % of the waves hold one). After an overflow the rows above the stack's top are not the lane's own either.
+        nxt = deep ? dummy : nxt;
         const bool moved = nxt != cur;
         cur = nxt;
-        avail -= used;
+        avail = deep ? 0 : avail - used;
         // a lane that popped loads its new node; one that was not on a leaf still holds its internal node in n
         if (moved) n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
 #pragma unroll

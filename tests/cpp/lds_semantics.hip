@@ -1,11 +1,14 @@
 // tests/cpp/lds_semantics.hip — pins the hardware behaviour the hot search kernel relies on (loc_lib_amd/csrc/search_walk.hpp):
 //   (1) with no static __shared__ in the kernel, the dynamic LDS block of a one-wave workgroup starts at LDS address 0;
-//   (2) a ds_read of an address BELOW 0 (wrapped: 0xFFFFF...) or AT/ABOVE the workgroup's allocation returns 0 — also when many
-//       other workgroups, whose LDS is full of non-zero words, are resident on the same CU;
-//   (3) a ds_write outside the allocation is dropped: it changes neither this workgroup's words nor a neighbour's.
+//   (2) a ds_read of an address BELOW 0 (wrapped: 0xFFFFF...) returns 0 — also when many other workgroups, whose LDS is full of
+//       non-zero words, are resident on the same CU;
+//   (3) a ds_write at or above the end of the allocation changes neither this workgroup's words nor a neighbour's: it is dropped,
+//       or it lands in the padding up to the workgroup's allocation granule (1280 B on gfx950: a 6144-byte request owns 6400).
 // The walk kernels read stack rows avail-4..avail-1 unconditionally (rows below the bottom must read {0,0}) and push
-// unconditionally to the row above the top (a push beyond the last row must vanish). Built by __graft_entry__.build(), run by
-// tests/test_gpu_lds_semantics.py on the GPU box. Exit status 0 = every assumption holds; each violated one is printed.
+// unconditionally to the row above the top (a push beyond the last row must be harmless; the kernel notices the overflow by
+// itself). They never READ above the top, so what such a read returns is reported but not required (it is 0 beyond the
+// granule and whatever was stored there inside it). Built by __graft_entry__.build(), run by tests/test_gpu_lds_semantics.py
+// on the GPU box. Exit status 0 = every assumption holds; each violated one is printed.
 //
 //     hipcc --offload-arch=gfx950 -O2 lds_semantics.hip -o lds_semantics && ./lds_semantics
 #include <hip/hip_runtime.h>
@@ -72,9 +75,10 @@ int main() {
     uint32_t* d = nullptr;
     if (hipMalloc((void**)&d, n_wg * sizeof(uint32_t)) != hipSuccess) return 2;
     static const char* what[6] = {"dynamic LDS does not start at address 0", "a read below the allocation returned non-zero",
-                                  "a read above the allocation returned non-zero", "a read far above the allocation returned non-zero",
-                                  "a write outside the allocation was not dropped (reads back non-zero)",
+                                  "a read just above the requested size returned non-zero", "a read far above the allocation returned non-zero",
+                                  "a write just outside the requested size reads back",
                                   "a workgroup's own LDS words were changed by somebody's out-of-range write"};
+    const uint32_t required = 1u | 2u | 8u | 32u;  // bits 4 and 16 are informative: inside the allocation granule the padding is ordinary LDS
     int rc = 0;
     // the search kernels' sizes: 15 / 12 / 24 rows x 64 lanes x 8 B, the 34-row deep pass, the 16-lane one-scan kernel (34 x 128 B)
     for (int bytes : {15 * 512, 12 * 512, 24 * 512, 34 * 512, 34 * 128, 1280}) {
@@ -86,9 +90,12 @@ int main() {
         uint32_t any = 0;
         int n_bad = 0;
         for (uint32_t v : h) { any |= v; n_bad += v != 0u; }
-        printf("LDS SEMANTICS: %6d B per workgroup, %d workgroups: %s (mask %#x, %d workgroups)\n", bytes, n_wg, any ? "VIOLATED" : "ok", any, n_bad);
+        printf("LDS SEMANTICS: %6d B per workgroup, %d workgroups: %s (mask %#x, %d workgroups)\n", bytes, n_wg, (any & required) ? "VIOLATED" : "ok", any, n_bad);
         for (int b = 0; b < 6; ++b)
-            if (any & (1u << b)) { printf("  - %s\n", what[b]); rc = 1; }
+            if (any & (1u << b)) {
+                printf("  - %s%s\n", what[b], (required & (1u << b)) ? "" : " (not required: padding of the 1280-byte allocation granule)");
+                if (required & (1u << b)) rc = 1;
+            }
     }
     (void)hipFree(d);
     printf(rc ? "LDS SEMANTICS FAILED\n" : "LDS SEMANTICS OK\n");

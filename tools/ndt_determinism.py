@@ -11,7 +11,7 @@ that every allocation lands on memory another context has just freed) thousands 
 
 Three incremental configurations cover the three ways a SetIncNdtTargetCloud call can go (LOCGPU_INC_DEBUG reports which one ran, and
 the harness insists it has seen all three): capacity 300 (the cloud's own working set exceeds the capacity: per-point replay on the
-host), 3000 (device path with LRU evictions on the second cloud), 100000 (the reference default: device path, nothing evicted).
+host), one between the first cloud's voxel count and the union's (device path with LRU evictions on the second cloud), 100000 (the reference default: device path, nothing evicted).
 
     python tools/ndt_determinism.py [--reps 5000]
 """
@@ -50,7 +50,16 @@ def main():
     scan = synth.make_scan(sid, subsample=5000, crop_half=36.0)
     _, init = synth.make_pose(sid, trans_amp=0.4, rot_amp_deg=3.0, seed=5)
     kw = dict(voxel_size=2.1311215983306657, nearby_type=1, min_pts_in_voxel=3, res_outlier_th=100.0, min_effective_pts=200, max_iteration=30)
-    caps = [300, 3000, 100000]
+    # capacities for the three paths: 300 — far below the clouds' own working sets (host replay); one between the first cloud's voxel
+    # count and the union's, so that the first call fits and the second evicts on the device; the reference default (nothing evicted)
+    probe = locref.Ndt(method=api.INCREMENTAL_NDT, capacity=100000, **kw)
+    probe.set_target(m1)
+    n1 = probe.num_voxels()
+    probe.set_target(m2)
+    n12 = probe.num_voxels()
+    assert n12 > n1 + 4, "the second cloud adds no voxels"
+    caps = [300, n1 + 2 + (n12 - n1) // 2, 100000]
+    print("voxels: first cloud %d, both %d; capacities %s" % (n1, n12, caps), flush=True)
     want = {}
     for cap in caps:  # the oracle, once per configuration
         ref = locref.Ndt(method=api.INCREMENTAL_NDT, capacity=cap, **kw)
