@@ -9,10 +9,12 @@ mode). The map and its tree are in HBM before the timed region starts. The SCANS
 copy of every ScanMatch call (SetSource, icp_registration.cpp:221,252-265) — every step aligns a batch that
 was copied host → HBM for it through pinned staging on a copy stream, while the previous step's Gauss–Newton loop ran
 (depth + 1 batches rotate: one is being copied, the others are being aligned; `--resident` keeps the scans in HBM instead and is
-reported as the secondary number). Up to `--pipeline` alignments are in flight (`locgpu_*_align_batch_begin` /
-`locgpu_align_batch_end`): the first Gauss–Newton iterations of step i+1 run under the last ones of step i, which hold a handful of
-unconverged scans (`--pipeline 1` = one at a time, the default at 256 scans per GPU). Every step still begins and ends inside the
-timed region.
+reported as the secondary number). Three alignments are in flight by default (`locgpu_*_align_batch_begin` /
+`locgpu_align_batch_end`; `--pipeline 1|2|3`): the first Gauss–Newton iterations of step i+1 fill the chip under the last ones of step i,
+which hold a handful of unconverged scans. Every step still begins and ends inside the timed region, which carries no instrumentation;
+the kernel durations behind `roofline` and `kernel_ms_per_step` are HIP-event times of `--extra-steps` further steps of the same workload run
+one alignment at a time right behind it (launches of different batches overlap inside the timed region), the hardware counters come
+from child runs of this script under `rocprofv3 --pmc`, the search loop's lane efficiency from one child run on the library's diagnostic build.
 One GPU: BASELINE.json configs[2], every step aligns `--scans-per-gpu` (256) scans. Several GPUs, default (`--scaling strong`):
 configs[3] as written — `--total-scans` (256) scans in all, sharded contiguously over the ranks, per-iteration RCCL all-reduce of
 the per-scan normal equations inside liblocgpu.so (every rank solves every scan and holds all poses). `--scaling weak`: every
@@ -120,12 +122,18 @@ def load_traffic(kernel_name, scans_per_gpu, map_points, method):
     return best
 
 
-def measure_traffic_live(kernel_name, passthrough_args, budget_s=240.0):
-    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script (2 steps, same workload) under
-    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` — separate passes, no tracing, the program directly after `--`, as
-    /opt/skills/guides/MI355X_MICROARCH.md prescribes — then (2·FETCH_SIZE + WRITE_SIZE)·1024 (both counters are KiB; gfx950
-    FETCH_SIZE counts half the bytes of wide reads). Children are ordinary subprocesses (never an exec of this process).
-    Returns (bytes_per_launch | None, note)."""
+PMC_PASSES = [  # one rocprofv3 --pmc run each, nothing but --pmc (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+    ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"],
+]
+
+
+def measure_counters_live(passthrough_args, budget_s=300.0):
+    """Per-kernel hardware counters of this very workload, measured NOW: child runs of this script (2 timed + 4 profiled steps, one
+    alignment in flight) under `rocprofv3 --pmc <group>` — separate passes, no tracing, the program directly after `--`, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes. Children are ordinary subprocesses (never an exec of this process).
+    Returns ({kernel base name: {counter: mean per launch, "launches": n}}, note)."""
     import collections
     import csv
     import glob
@@ -133,33 +141,51 @@ def measure_traffic_live(kernel_name, passthrough_args, budget_s=240.0):
     import subprocess
     import tempfile
     if not shutil.which("rocprofv3"):
-        return None, "rocprofv3 not on PATH"
-    base = [a for a in passthrough_args]
-    child = ["python3", os.path.abspath(__file__)] + base + ["--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--traffic", "none"]
-    want = kernel_name.split("(")[0]
-    vals = {}
+        return {}, "rocprofv3 not on PATH"
+    child = ["python3", os.path.abspath(__file__)] + list(passthrough_args) + ["--steps", "2", "--warmup", "0", "--pipeline", "1", "--no-cpu-baseline", "--traffic", "none"]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
     t_start = time.time()
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    notes = []
+    for counters in PMC_PASSES:
         outdir = tempfile.mkdtemp(prefix="locgpu_pmc_", dir="/tmp")
         try:
             left = budget_s - (time.time() - t_start)
             if left < 20:
-                return None, "PMC passes ran out of their %.0f s budget" % budget_s
-            subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", outdir, "--"] + child, stdout=subprocess.DEVNULL,
+                notes.append("%s: out of the %.0f s budget" % (counters[0], budget_s))
+                break
+            subprocess.run(["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", outdir, "--"] + child, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", timeout=left, check=True)
-            agg = collections.defaultdict(list)
             for f in glob.glob(os.path.join(outdir, "**", "*_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == counter and want in r["Kernel_Name"]:
-                        agg[counter].append(float(r["Counter_Value"]))
-            if not agg[counter]:
-                return None, "no %s rows for %s" % (counter, want)
-            vals[counter] = sum(agg[counter]) / len(agg[counter])
+                    k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("locgpu::", "").strip()
+                    agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         except Exception as e:  # a failed profile never fails the bench
-            return None, "%s pass failed: %s" % (counter, type(e).__name__)
+            notes.append("%s pass failed: %s" % (counters[0], type(e).__name__))
         finally:
             shutil.rmtree(outdir, ignore_errors=True)
-    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2 steps each, (2*FETCH+WRITE)*1024"
+    out = {}
+    for k, cs in agg.items():
+        out[k] = {c: sum(v) / len(v) for c, v in cs.items()}
+        out[k]["launches"] = max(len(v) for v in cs.values())
+    return out, "live: rocprofv3 --pmc passes %s, 2 + 4 steps each%s" % (" | ".join(" ".join(c) for c in PMC_PASSES), ("; " + "; ".join(notes)) if notes else "")
+
+
+def measure_lane_efficiency_live(passthrough_args, budget_s=120.0):
+    """Lane efficiency of the search kernel's main loop on this workload, measured NOW by one child run of this script on the
+    library's diagnostic build (LOCGPU_STAMP=1: the same kernel counting, per lane, the rounds the lane needed and the rounds its
+    wave ran; its timing is meaningless and not used). Returns (useful / paid | None, note)."""
+    import subprocess
+    child = ["python3", os.path.abspath(__file__)] + list(passthrough_args) + ["--steps", "1", "--warmup", "0", "--pipeline", "1", "--no-cpu-baseline", "--traffic", "none", "--resident"]
+    try:
+        out = subprocess.run(child, capture_output=True, text=True, timeout=budget_s, env=dict(os.environ, LOCGPU_STAMP="1"), cwd=ROOT)
+        for ln in out.stdout.splitlines():
+            if ln.startswith("{") and '"stamp"' in ln:
+                st = json.loads(ln)["stamp"]
+                if st["paid_rounds"] > 0:
+                    return st["lane_rounds"] / st["paid_rounds"], "live: one step on the LOCGPU_STAMP=1 diagnostic build (rounds needed per lane / rounds its wave ran, summed over the step's search launches)"
+        return None, "the diagnostic run printed no stamp"
+    except Exception as e:
+        return None, "diagnostic run failed: %s" % type(e).__name__
 
 
 def launcher_command(n_ranks, port, argv, python=None):
@@ -232,8 +258,8 @@ def self_launch(n_ranks, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=80)  # the default timed region is ≥ 2 s
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scans-per-gpu", type=int, default=256)
     ap.add_argument("--method", choices=["p2plane", "p2line", "p2p", "ndt"], default="p2plane",
                     help="matcher to time; the headline metric is p2plane (others are reported for DESIGN.md tables)")
@@ -247,14 +273,13 @@ def main():
                     help="strong (default with several GPUs): --total-scans in all, sharded over the ranks with the per-iteration RCCL "
                          "all-reduce (BASELINE configs[3]); weak (default with one GPU): --scans-per-gpu scans on every rank, no collective")
     ap.add_argument("--pipeline", type=int, choices=[0, 1, 2, 3], default=0,
-                    help="alignments in flight (the library has three compute streams): k = step i+k-1 is begun before step i is ended, "
-                         "1 = one at a time, 0 (default) = 3 when a rank holds fewer than 128 scans (the shards of the multi-GPU runs: "
-                         "+14 %% over two in flight at 32 and 64 scans), else 1 — at 256 scans per GPU two in flight give +6 %% scans/s "
-                         "but every kernel's launch duration then includes the other batches' share of the chip, and `roofline` is "
-                         "defined on launch durations")
+                    help="alignments in flight (the library has three compute streams): k = step i+k-1 is begun before step i is ended; "
+                         "0 (default) = 3. Kernel launch durations are NOT taken from the timed region (launches of several batches "
+                         "overlap there): they come from --extra-steps further steps of the same workload run one at a time behind it")
+    ap.add_argument("--extra-steps", type=int, default=4, help="untimed steps behind the timed region, one alignment at a time with HIP events around every stage")
     ap.add_argument("--total-scans", type=int, default=256)
     ap.add_argument("--traffic", choices=["live", "profiles", "none"], default="live",
-                    help="roofline.traffic: live = two rocprofv3 --pmc child runs now (1 GPU only), profiles = newest committed collection")
+                    help="roofline counters: live = rocprofv3 --pmc child runs + one diagnostic-build child run now (1 GPU only), profiles = newest committed traffic collection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -322,7 +347,7 @@ def main():
     def new_batch():
         return ctx.batch(scans, first=lo, n_total=n_total) if strong else ctx.batch(scans)
 
-    depth = args.pipeline if args.pipeline else (3 if B_local < 128 else 1)
+    depth = args.pipeline if args.pipeline else 3
     # resident: `depth` batches hold the same scans; streaming: one more, so that the copy for step g+1 never lands in a batch
     # that an alignment in flight (steps g, g-1) is reading
     bufs = [new_batch() for _ in range(depth if args.resident else depth + 1)]
@@ -389,12 +414,10 @@ def main():
         bufs[g_step[0] % len(bufs)].upload_async(scans_c)
     run_steps(args.warmup)
 
-    # ---- timed region: exactly `steps` steps; HIP events on the library's stream time each kernel launch
-    ctx.profile_read(reset=True)
-    # HIP events on the library's stream around the dominant kernel's launches only (mode 2: two records per iteration): events
-    # around every stage (mode 1) cost ≈0.3 ms per step next to the copy stream's traffic. NDT has no search stage: mode 1.
-    prof_mode = int(os.environ.get("LOCGPU_BENCH_PROFILE", "1" if method < 0 else "2"))
-    ctx.profile_enable(prof_mode)
+    # ---- timed region: exactly `steps` steps, `depth` alignments in flight, no instrumentation inside it
+    stamp_build = bool(os.environ.get("LOCGPU_STAMP"))
+    if stamp_build:
+        ctx.search_stats_read(reset=True)  # diagnostic build (a child of measure_lane_efficiency_live): switch the counters on
     barrier()
     t0 = time.perf_counter()
     out_poses, stats = run_steps(args.steps)
@@ -402,20 +425,19 @@ def main():
     dt = time.perf_counter() - t0
     if debug_times is not None:
         sys.stderr.write("host ms per step (upload_async, begin): %s\n" % [(round(1e3 * a, 2), round(1e3 * b, 2)) for a, b in debug_times[-args.steps:]])
-    ctx.profile_enable(False)
-    prof = ctx.profile_read(reset=True)
+    stamp = ctx.search_stats_read(reset=True) if stamp_build else None
     for b in bufs:
         b.upload_wait()
-    stage_src = "HIP events over the timed region"
-    if prof_mode == 2:  # the other stages' share: two more (untimed) passes of the same step with events around every stage
-        ctx.profile_enable(1)
-        for _ in range(2):
-            align_batch(bufs[0])
-        extra = ctx.profile_read(reset=True)
-        ctx.profile_enable(False)
-        for kk in ("accum", "solve"):
-            prof[kk + "_ms"], prof[kk + "_n"] = extra[kk + "_ms"], extra[kk + "_n"] * args.steps / 2.0
-        stage_src = "search: HIP events over the timed region; fit_accumulate, solve: two extra untimed steps"
+    # ---- kernel durations: `extra` further steps of the same workload, ONE alignment at a time (launches of different batches
+    # overlap in the timed region), HIP events on the library's stream around every stage of every iteration
+    n_extra = max(1, args.extra_steps)
+    ctx.profile_read(reset=True)
+    ctx.profile_enable(1)
+    for _ in range(n_extra):
+        align_batch(bufs[0])
+    prof = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+    stage_src = "HIP events around every stage of %d further steps of the same workload, one alignment at a time, right behind the timed region" % n_extra
 
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -441,31 +463,71 @@ def main():
         if method < 0:
             nv = ctx.ndt_target_info()["num_voxels"]
             accum_bytes = q * (16 + 7 * 12) + (prof["accum_n"] or 1) * nv * 96  # src + 7 hash probes per point; voxel μ/info once per launch
-        t_search = prof["search_ms"] * prof["search_n"] / args.steps      # ms per step
-        t_accum = prof["accum_ms"] * prof["accum_n"] / args.steps
-        t_solve = prof["solve_ms"] * prof["solve_n"] / args.steps
+        t_search = prof["search_ms"] * prof["search_n"] / n_extra      # ms per step (profiled steps)
+        t_accum = prof["accum_ms"] * prof["accum_n"] / n_extra
+        t_solve = prof["solve_ms"] * prof["solve_n"] / n_extra
+        search_kernels = ("icp_search_grid",) if args.search == "grid" else ("icp_search_walk_kernel", "icp_search_walk_list_kernel", "icp_search_redo_kernel")
+        accum_kernels = ("ndt_accum_kernel",) if method < 0 else ("icp_%s_accum_kernel" % dict(p2plane="plane", p2line="line", p2p="point")[args.method], "icp_plane_refit_kernel")
         if t_search >= t_accum:
-            kname, kbytes, kt, kn, kavg = ("icp_search_grid_kernel(+pass2+redo)" if args.search == "grid" else "icp_search_walk_kernel(+deep pass+redo)"), search_bytes, t_search, prof["search_n"], prof["search_ms"]
+            kname, kset, kbytes, kt, kn, kavg = ("icp_search_grid_kernel(+pass2+redo)" if args.search == "grid" else "icp_search_walk_kernel(+deep pass+redo)"), search_kernels, search_bytes, t_search, prof["search_n"], prof["search_ms"]
         else:
-            kname, kbytes, kt, kn, kavg = ("ndt_accum_kernel" if method < 0 else "icp_%s_accum_kernel" % args.method), accum_bytes, t_accum, prof["accum_n"], prof["accum_ms"]
-        launches_per_step = kn / args.steps
-        traffic, traffic_note = None, "not collected"
+            kname, kset, kbytes, kt, kn, kavg = accum_kernels[0], accum_kernels, accum_bytes, t_accum, prof["accum_n"], prof["accum_ms"]
+        launches_per_step = kn / n_extra
+        # ---- hardware counters of the same workload: HBM bytes, VALU / FP64 instruction counts (rocprofv3 --pmc child runs), lane
+        # efficiency of the search loop (one child run on the diagnostic build)
+        counters, counters_note, lane_eff, lane_note = {}, "not collected", None, "not collected"
         if args.traffic == "live" and world == 1 and dist is None:
             passthrough = ["--scans-per-gpu", str(args.scans_per_gpu), "--map-points", str(args.map_points), "--method", args.method,
                            "--search", args.search, "--scaling", args.scaling, "--total-scans", str(args.total_scans)] + (["--resident"] if args.resident else [])
-            traffic, traffic_note = measure_traffic_live(kname, passthrough)
+            counters, counters_note = measure_counters_live(passthrough)
+            if method >= 0 and args.search != "grid":
+                lane_eff, lane_note = measure_lane_efficiency_live(passthrough)
+
+        def stage_counter(kernels, name):
+            """Sum over the stage's kernels of the counter's mean per launch (every kernel of a stage is launched once per iteration)."""
+            vals = [counters[kk][name] for kk in counters for want in kernels if kk.startswith(want) and name in counters[kk]]
+            return sum(vals) if vals else None
+
+        def hbm_bytes(kernels):
+            f, w = stage_counter(kernels, "FETCH_SIZE"), stage_counter(kernels, "WRITE_SIZE")
+            return int((2.0 * f + w) * 1024) if f is not None and w is not None else None  # both count KiB; gfx950 FETCH_SIZE counts half the bytes of wide reads
+
+        SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; a wave64 VALU (or FP64) instruction occupies its SIMD's issue port for 4 cycles
+
+        def issue_frac(kernels, names, avg_ms):
+            v = [stage_counter(kernels, nm) for nm in names]
+            if any(x is None for x in v) or avg_ms <= 0:
+                return None, None
+            n_inst = sum(v)
+            return n_inst, n_inst * 4.0 / (SIMDS * CLOCK_HZ * avg_ms / 1e3)
+
+        traffic, traffic_note = hbm_bytes(kset), counters_note
         if traffic is None and args.traffic != "none":
             t2 = load_traffic(kname, args.scans_per_gpu, args.map_points, args.method)
             if t2 is not None:
-                traffic, traffic_note = t2, "copied from the newest committed profiles/*traffic*.json of this workload (" + traffic_note + ")"
+                traffic, traffic_note = t2, "copied from the newest committed profiles/*traffic*.json of this workload (" + counters_note + ")"
         achieved = (kbytes / 1e9) / (kt / 1e3) if kt > 0 else 0.0
+        valu_n, valu_frac = issue_frac(kset, ["SQ_INSTS_VALU"], kavg)
         roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                        frac_note="nominal: SURVEY 8(d)'s algorithmic bytes (one 16-byte load per node visit) over launch time; most of those loads are "
+                                  "served by L1/L2, so this is an effective rate, not HBM traffic, and may pass 1 — hbm_frac is the measured HBM share, "
+                                  "issue.valu_issue_frac the bound that binds",
                         hbm_frac=(round(traffic / (kavg / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and kavg > 0 else None),
                         traffic_source=traffic_note,
                         algorithmic_bytes_per_launch=int(kbytes / max(launches_per_step, 1)), avg_launch_ms=round(kavg, 5),
                         launches_per_step=launches_per_step,
                         nodes_per_query=round(vc["nodes"] / max(q, 1), 2), leaves_per_query=round(vc["leaves"] / max(q, 1), 2))
+        if method >= 0 and args.search != "grid":
+            # what the stage cannot avoid moving: every query's source point and index list once, and every tree slot any query of the
+            # launch reads, once (counted by the instrumented pass, per launch)
+            roofline["compulsory_bytes"] = int((q * (16 + 4 * k) + vc["distinct_slots"] * 8) / max(launches_per_step, 1))
+            roofline["issue"] = dict(bound="valu_issue", valu_insts_per_launch=(int(valu_n) if valu_n else None),
+                                     valu_issue_frac=(round(valu_frac, 4) if valu_frac else None),
+                                     peak="1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
+                                     lane_efficiency=(round(lane_eff, 4) if lane_eff else None), lane_efficiency_source=lane_note,
+                                     note="the kernel is bound by vector-instruction issue: valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (SIMDs x launch time) at the nominal "
+                                          "clock; lane_efficiency = main-loop rounds the lanes need / rounds their waves run (a wave runs until its slowest lane is done)")
         # which BASELINE.json configuration the arguments amount to
         if strong:
             cfg_name = "BASELINE configs[3] (%d scans in all, sharded over %d GPU(s), RCCL all-reduce)" % (n_total, world)
@@ -497,15 +559,28 @@ def main():
                     median_translation_error_to_truth_m=round(err_t, 4),
                     setup_s=dict(map_gen=round(t_map, 2), tree_ingest=round(t_ingest, 2)),
                     roofline=roofline)
+        line["scans_per_rank"] = B_local
+        line["rccl_ranks"] = (ctx.comm_info()[1] if use_comm else (world if dist is not None else 1))  # ranks RCCL joined: the library's communicator (strong), torch's process group (weak)
+        line["rccl_use"] = ("per-iteration all-reduce + tree broadcast inside liblocgpu.so (locgpu_comm_info)" if use_comm else
+                            ("barrier and max-over-ranks only (torch.distributed nccl)" if dist is not None else "none (one rank, no process group)"))
+        if stamp is not None:
+            line["stamp"] = dict(lane_rounds=stamp["walked"], paid_rounds=stamp["replayed"])
         if method >= 0 and t_accum > 0:
-            # the second kernel (fit + accumulate): algorithmic bytes of SURVEY §8(d) against HBM, and — what actually bounds it —
-            # its FP64 instruction count (profiles/*pmc*: 407 per point for P2Plane) against the FP64 vector issue rate
-            # (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3e12 lane-instructions/s)
+            # the second kernel (fit + accumulate): algorithmic bytes of SURVEY §8(d) against HBM, its measured HBM traffic, and — what
+            # actually bounds it — its FP64 and VALU instruction counts against the issue rate (a wave64 FP64 instruction = 4 cycles of its SIMD)
             a_gbs = (accum_bytes / 1e9) / (t_accum / 1e3)
-            line["roofline_k2"] = dict(bound="hbm", kernel="icp_%s_accum_kernel" % args.method, achieved=round(a_gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                                       frac=round(a_gbs / HBM_PEAK_GBS, 5), ms_per_step=round(t_accum, 4),
-                                       fp64_issue_frac=(round(q * 407 / (t_accum / 1e3) / 39.3e12, 4) if args.method == "p2plane" else None),
-                                       note="measured on two extra untimed steps" if prof_mode == 2 else "HIP events over the timed region")
+            k2_traffic = hbm_bytes(accum_kernels)
+            k2_avg = prof["accum_ms"]
+            f64_n, f64_frac = issue_frac(accum_kernels, ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"], k2_avg)
+            v_n, v_frac = issue_frac(accum_kernels, ["SQ_INSTS_VALU"], k2_avg)
+            line["roofline_k2"] = dict(bound="hbm", kernel=accum_kernels[0], achieved=round(a_gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                       frac=round(a_gbs / HBM_PEAK_GBS, 5), ms_per_step=round(t_accum, 4), avg_launch_ms=round(k2_avg, 5), traffic=k2_traffic,
+                                       hbm_frac=(round(k2_traffic / (k2_avg / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if k2_traffic and k2_avg > 0 else None),
+                                       issue=dict(bound="fp64_issue", fp64_insts_per_launch=(int(f64_n) if f64_n else None),
+                                                  fp64_issue_frac=(round(f64_frac, 4) if f64_frac else None),
+                                                  valu_insts_per_launch=(int(v_n) if v_n else None), valu_issue_frac=(round(v_frac, 4) if v_frac else None),
+                                                  note="dependent FP64 chains retire at less than half rate on this part (tools/ubench/fp64_rate.hip): the kernel is latency-bound below its issue peak"),
+                                       note=stage_src)
         if world == 1 and not args.no_cpu_baseline and args.search == "tree":
             cb, cpu_poses = cpu_baseline(map_xyz, scans, inits, args.cpu_seconds, args.method)
             n = len(cpu_poses)

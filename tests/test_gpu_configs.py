@@ -403,6 +403,12 @@ def test_bench_line_contract(mode):
     # the workload label follows the arguments (a 1 M-pt map is configs[1], the sharded mode configs[3]); small shards run three in flight
     assert ("configs[3]" if mode == "strong" else "configs[1]") in d["config"]["workload"]
     assert d["config"]["pipeline_depth"] == 3 and "roofline_k2" in d
+    # round 4: a bound that binds next to the nominal one, what RCCL saw, where the kernel durations come from
+    assert r["issue"]["bound"] == "valu_issue" and "lane_efficiency" in r["issue"] and "valu_issue_frac" in r["issue"]
+    assert 0 < r["compulsory_bytes"] < r["algorithmic_bytes_per_launch"]
+    assert d["roofline_k2"]["issue"]["bound"] == "fp64_issue"
+    assert d["scans_per_rank"] == 8 and d["rccl_ranks"] == 1
+    assert "further steps" in d["kernel_ms_source"] and d["kernel_ms_per_step"]["search"] > 0
 
 
 def test_bench_refuses_more_ranks_than_gpus():
