@@ -94,6 +94,11 @@ struct locgpu_batch {
     int* d_counts = nullptr;
     locgpu::PoseState* d_state = nullptr;
     uint32_t* d_nn = nullptr;      // [5][pitch]
+    // plane cache of the P2Plane fit kernel (batches large enough for the 64-lane search kernel; launch.hpp): per point the plane
+    // 4-vector fitted for the list it had then, per 64 queries the "same list as last iteration" bits of the search kernel
+    double* d_plane_cache = nullptr;             // [pitch][4]
+    unsigned long long* d_same_mask = nullptr;   // [n_scans][ceil(max_n / 64)]
+    bool cache_chain = false;                    // the previous iteration of the running alignment filled the cache
     double* d_partials = nullptr;  // [n_scans][blocks_per_scan][kAccW]
     double* d_hb = nullptr;        // [n_scans][44]
     uint32_t* d_redo_list = nullptr;      // [pitch]

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
                                                              unsigned int tree_bytes, uint32_t dummy, int skip_nonfinite, uint32_t* __restrict__ redo_list,
                                                              unsigned int* __restrict__ redo_count, uint32_t* __restrict__ deep_list,
                                                              unsigned int* __restrict__ deep_count, unsigned long long* __restrict__ search_stats,
-                                                             const int* __restrict__ active) {
+                                                             const int* __restrict__ active, unsigned long long* __restrict__ same_mask, int have_previous) {
     extern __shared__ uint2 s_dyn[];
     constexpr int ROWB = LANES * 8;
     static_assert(DF * ROWB >= 64 * 2 * 8, "exact stack columns do not fit");
@@ -208,6 +208,13 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     if (tid >= LANES || i >= counts[scan]) return;
     const size_t gi = (size_t)scan * max_n + i;
     const float4 p = load_once(&src[gi]);
+    // plane cache: the previous iteration's list of this query, read now (streamed, K coalesced dwords) and compared at the end
+    uint32_t prev_id[K];
+    const bool cmp_prev = LANES == 64 && same_mask != nullptr && have_previous != 0;  // wave-uniform
+    if (cmp_prev) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) prev_id[j] = __builtin_nontemporal_load(&nn[(size_t)j * nn_pitch + gi]);
+    }
     if (skip_nonfinite && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {  // pcl::isFinite, icp cpp:64 (P2P only)
 #pragma unroll
         for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = kInvalidSlot;
@@ -232,6 +239,18 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     if (!deep && !slow) {
 #pragma unroll
         for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
+    }
+    if (LANES == 64 && same_mask != nullptr) {
+        // one word per wave: the lanes whose list is, index for index, the one the plane cache was filled for. A query finished by
+        // the deep pass, in the wave or by the redo kernel counts as changed (its list is written elsewhere): it is simply refitted.
+        bool same = cmp_prev && !deep && !slow;
+        if (cmp_prev) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) same = same && w.id[j] == prev_id[j];
+        }
+        const unsigned long long m = __ballot(same);
+        if (__builtin_amdgcn_readfirstlane(tid) == tid)  // the first live lane of the wave
+            same_mask[(size_t)scan * (size_t)((max_n + 63) >> 6) + blockIdx.x] = m;
     }
     wave_append(deep_list, deep_count, deep, (uint32_t)gi);
     if (LANES == 16) {
@@ -550,6 +569,120 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                         J[0][3] = n3.x; J[0][4] = n3.y; J[0][5] = n3.z;
                         neg_e[0] = -dis;
                     }
+                }
+            }
+        }
+        ra.add<1>(s_row, J, neg_e, fitted);
+    }
+    ra.store(s_slice, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
+}
+
+// K2 with the PLANE CACHE (round 4; batches large enough for the 64-lane search kernel). FitPlane's 4-vector depends only on the five
+// neighbour indices, and from the second iteration on a growing share of the points keeps its list (5 % / 13 % / 22 % / 36 % / 49 % / 60 % /
+// 69 % / 75 % in iterations 1…8 of the bench workload) — never a whole wave of them, so skipping the fit per lane saves nothing. Here
+// a block compacts the points that need a fit: the search kernel has left one bit per query ("same five indices as last time", same_mask),
+//   1. every thread looks up the bits of its `pts` points; the ones to (re)fit are appended to a list in LDS;
+//   2. the block's threads walk that list — full waves except the last: gather the five leaves, fit, residual check of the five
+//      (math_utils.h:112-136), and leave the 4-vector in the per-point cache in HBM (all zero = "no plane": k > size_, or the check failed;
+//      a fitted vector has unit length);
+//   3. every thread reads its points' vectors back (its own block wrote the new ones: visible after the barrier), forms residual and
+//      Jacobian (icp cpp:184-201) and the rows are summed exactly as in icp_plane_accum_kernel — same order, same bits.
+// A cached vector is the one the same code computed from the same five leaves: results equal the uncached kernel's bit for bit.
+constexpr int kPlaneCachePtsMax = 8;
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_plane_cached_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
+                                                                 const int* __restrict__ counts, const PoseState* __restrict__ st,
+                                                                 const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
+                                                                 double max_plane_distance, double* __restrict__ partials, int kPlanePts,
+                                                                 const int* __restrict__ active, double* __restrict__ plane_cache,
+                                                                 const unsigned long long* __restrict__ same_mask, int use_cache) {
+    __shared__ double s_row[8][kAccPad];
+    __shared__ double s_slice[kBlock / 32][32];
+    __shared__ unsigned short s_todo[kPlaneCachePtsMax * kBlock];
+    __shared__ int s_ntodo;
+    const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
+    if (st[scan].done) return;  // uniform per block
+    const int tid = threadIdx.x;
+    const int n_pts = counts[scan];
+    const int base_i = blockIdx.x * kPlanePts * kBlock;
+    const size_t scan_off = (size_t)scan * max_n;
+    if (tid == 0) s_ntodo = 0;
+    __syncthreads();
+    // ---- 1. which of the block's points need a fit
+    const size_t mask_row = (size_t)scan * (size_t)((max_n + 63) >> 6);
+#pragma unroll 1
+    for (int pp = 0; pp < kPlanePts; ++pp) {
+        const int off = pp * kBlock + tid;
+        const int i = base_i + off;
+        bool todo = i < n_pts;
+        if (todo && use_cache) todo = ((same_mask[mask_row + (size_t)(i >> 6)] >> (i & 63)) & 1ull) == 0ull;
+        const unsigned long long m = __ballot(todo);
+        if (m != 0ull) {
+            const int lane = tid & 63;
+            const int leader = __ffsll((long long)m) - 1;
+            int b0 = 0;
+            if (lane == leader) b0 = atomicAdd(&s_ntodo, __popcll(m));
+            b0 = __shfl(b0, leader, 64);
+            if (todo) s_todo[b0 + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)off;
+        }
+    }
+    __syncthreads();
+    // ---- 2. fit them (which thread fits which point varies from run to run; what is written for a point does not)
+    const int n_todo = s_ntodo;
+#pragma unroll 1
+    for (int t = tid; t < n_todo; t += kBlock) {
+        const size_t gi = scan_off + (size_t)(base_i + (int)s_todo[t]);
+        uint32_t slot[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) slot[j] = __builtin_nontemporal_load(&nn[(size_t)j * nn_pitch + gi]);
+        double n4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (slot[4] != kInvalidSlot) {  // nn.size() > 3: k=5 yields 5 or (k > size_) none
+            D3 nb[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, slot[j]);
+            plane_null_vector(nb, n4);
+            const D3 n3{n4[0], n4[1], n4[2]};
+            bool fit = true;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const double err = dot3(n3, nb[j]) + n4[3];
+                if (err * err > 1e-2) fit = false;
+            }
+            if (!fit) { n4[0] = 0.0; n4[1] = 0.0; n4[2] = 0.0; n4[3] = 0.0; }
+        }
+        double* c = plane_cache + 4 * gi;
+        c[0] = n4[0]; c[1] = n4[1]; c[2] = n4[2]; c[3] = n4[3];
+    }
+    __syncthreads();  // the block's own stores to plane_cache are visible to all of its threads from here on
+    // ---- 3. residual, Jacobian, sums — as icp_plane_accum_kernel
+    RowAccum ra;
+    ra.init();
+#pragma unroll 1
+    for (int pp = 0; pp < kPlanePts; ++pp) {
+        const int i = base_i + pp * kBlock + tid;
+        double J[1][6] = {{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
+        double neg_e[1] = {0.0};
+        double fitted = 0.0;
+        if (i < n_pts) {
+            const size_t gi = scan_off + (size_t)i;
+            const double* c = plane_cache + 4 * gi;
+            const double n40 = c[0], n41 = c[1], n42 = c[2], n43 = c[3];
+            const float4 p = src[gi];
+            if (!(n40 == 0.0 && n41 == 0.0 && n42 == 0.0 && n43 == 0.0)) {
+                fitted = 1.0;  // effective_num++ before the residual gate (icp cpp:184)
+                const D3 n3{n40, n41, n42};
+                const D3 q{(double)p.x, (double)p.y, (double)p.z};
+                const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
+                const double dis = dot3(n3, qs) + n43;
+                if (!(fabs(dis) > max_plane_distance)) {
+                    const double* R = st[scan].R;
+                    double nR[3];
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) nR[cc] = (-n3.x * R[cc] + -n3.y * R[3 + cc]) + -n3.z * R[6 + cc];
+                    J[0][0] = nR[1] * q.z - nR[2] * q.y;
+                    J[0][1] = nR[2] * q.x - nR[0] * q.z;
+                    J[0][2] = nR[0] * q.y - nR[1] * q.x;
+                    J[0][3] = n3.x; J[0][4] = n3.y; J[0][5] = n3.z;
+                    neg_e[0] = -dis;
                 }
             }
         }
@@ -937,7 +1070,7 @@ static bool launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         dim3 g2((a.max_n + 63) / 64, n_launch);
         hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, 12, 64, true>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                            a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
-                           a.search_stats, a.active);
+                           a.search_stats, a.active, a.same_mask, a.have_previous);
         hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(2048), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
                            a.alpha_eff, (unsigned int)a.tree_bytes + 16u, dummy, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count, a.search_stats);
         hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
@@ -960,14 +1093,14 @@ static bool launch_fast_kd(const SearchArgs& a, hipStream_t s) {
             dim3 g1((a.max_n + 15) / 16, n_launch);
             hipLaunchKernelGGL((icp_search_walk_kernel<K, D + 2, 12, 16>), g1, dim3(64), (D + 2) * 16 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                                a.alpha_eff, 0, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
-                               a.search_stats, a.active);
+                               a.search_stats, a.active, (unsigned long long*)nullptr, 0);
             return true;  // no redo launch: the 16-lane kernel answers its ties itself
         }
         const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
         dim3 g2((a.max_n + 63) / 64, n_launch);
 #define LOCGPU_WALK_LAUNCH(M) hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, M>), g2, dim3(64), DF * 64 * 8 + wpad, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, \
                                                  a.max_n, a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count,       \
-                                                 a.redo_list2, a.redo_count2, a.search_stats, a.active)
+                                                 a.redo_list2, a.redo_count2, a.search_stats, a.active, a.same_mask, a.have_previous)
         if (mode == 2) LOCGPU_WALK_LAUNCH(2);
         else if (mode == 12) LOCGPU_WALK_LAUNCH(12);
         else LOCGPU_WALK_LAUNCH(0);
@@ -1054,6 +1187,19 @@ bool launch_icp_search_list(const SearchArgs& a, const uint32_t* list, const uns
     return false;
 }
 
+// Does launch_icp_search(a) run the 64-lane walk kernel, the one that fills a.same_mask? (The fit/accumulate launcher must take the
+// same decision: the plane cache is only usable behind it.) Mirrors the choices of launch_icp_search / launch_fast_kd.
+bool icp_search_writes_same_mask(const SearchArgs& a) {
+    static const int walk = [] { const char* e = getenv("LOCGPU_WALK"); return e ? atoi(e) : 1; }();
+    static const int small = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); return e ? atoi(e) : 16; }();
+    static const bool cache_on = [] { const char* e = getenv("LOCGPU_PLANE_CACHE"); return !e || atoi(e) != 0; }();  // 0: A/B runs without the cache
+    if (!cache_on || !a.same_mask || a.k != 5 || a.depth > 64) return false;
+    if (a.visit_totals != nullptr || search_variant() != 0 || !a.redo_list || !a.redo_list2 || walk != 1) return false;
+    const int n_launch = a.active ? a.n_active : a.n_scans;
+    if ((size_t)((a.max_n + 63) / 64) * n_launch <= 2048 && small == 16) return false;  // the 16-lane one-scan kernel
+    return true;
+}
+
 bool launch_icp_search(const SearchArgs& a, hipStream_t s) {
     // Instrumented (visit-counting) runs and LOCGPU_SEARCH_VARIANT experiments use the exact one-pass kernel.
     const bool exact_only = a.visit_totals != nullptr || search_variant() != 0 || !a.redo_list;
@@ -1095,7 +1241,10 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
     int pts = forced > 0 ? forced : (total_blocks >= 8192 ? (method == 2 ? 4 : 8) : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1)));
     if (pts > 8) pts = 8;
     const dim3 grid((blocks + pts - 1) / pts, a.active ? a.n_active : a.n_scans);
-    if (method == 2)
+    if (method == 2 && a.plane_cache && a.same_mask)
+        hipLaunchKernelGGL(icp_plane_cached_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active,
+                           a.plane_cache, a.same_mask, a.use_cache);
+    else if (method == 2)
         hipLaunchKernelGGL(icp_plane_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
     else if (method == 1)
         hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);

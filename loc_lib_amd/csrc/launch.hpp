@@ -32,6 +32,11 @@ struct SearchArgs {
     // iterations hold a handful of scans: 460 k empty workgroups cost ≈96 µs per launch). nullptr = every scan.
     const int* active = nullptr;
     int n_active = 0;
+    // Plane cache (P2Plane batches, DESIGN.md §3 "K2"): the 64-lane walk kernel writes, per wave, the lanes whose five neighbour
+    // indices equal the previous iteration's (one 64-bit word per 64 queries, [n_scans][ceil(max_n/64)]); `have_previous` = the
+    // lists in nn are the previous iteration's of this very alignment (else every bit is 0). nullptr = not wanted.
+    unsigned long long* same_mask = nullptr;
+    int have_previous = 0;
     // instrumented pass only: bitmap over the tree's 8-byte slots (one bit each, zeroed by the caller, counted and cleared again
     // by launch_count_touched) — which slots this search launch reads at all
     uint32_t* touched = nullptr;
@@ -49,9 +54,16 @@ struct AccumArgs {
     double* partials;   // [n_scans][blocks_per_scan][kAccW]
     const int* active = nullptr;  // see SearchArgs
     int n_active = 0;
+    // Plane cache: the plane 4-vector of every point as fitted for the list it had then ([pitch] × 4 doubles; all zero = no plane),
+    // and the search stage's "same five indices as last time" bits. use_cache = the bits are valid for this launch.
+    double* plane_cache = nullptr;
+    const unsigned long long* same_mask = nullptr;
+    int use_cache = 0;
 };
 
 bool launch_icp_search(const SearchArgs& a, hipStream_t s);
+// true iff launch_icp_search(a) runs the kernel that fills a.same_mask (the plane cache of the fit kernel is usable behind it)
+bool icp_search_writes_same_mask(const SearchArgs& a);
 // exact tree traversal over a.redo_list only (the list is filled by a preceding fast / grid kernel)
 bool launch_icp_search_redo(const SearchArgs& a, hipStream_t s);
 // fast tree traversal (a.alpha_eff) over the queries in `list`, then the exact redo kernel for what it could not finish

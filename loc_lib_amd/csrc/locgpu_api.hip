@@ -112,6 +112,8 @@ static void free_batch(locgpu_batch* b) {
     if (b->d_counts) (void)hipFree(b->d_counts);
     if (b->d_state) (void)hipFree(b->d_state);
     if (b->d_nn) (void)hipFree(b->d_nn);
+    if (b->d_plane_cache) (void)hipFree(b->d_plane_cache);
+    if (b->d_same_mask) (void)hipFree(b->d_same_mask);
     if (b->d_partials) (void)hipFree(b->d_partials);
     if (b->d_hb) (void)hipFree(b->d_hb);
     if (b->d_acc) (void)hipFree(b->d_acc);
@@ -529,6 +531,11 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               hip_ok(ctx, hipMalloc((void**)&b->d_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipMalloc active") &&
               hip_ok(ctx, hipMemset(b->d_counts, 0, std::max(n_scans, 1) * sizeof(int)), "hipMemset counts") &&
               hip_ok(ctx, hipMemset(b->d_redo_count, 0, 2 * sizeof(unsigned int)), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
+    // plane cache of the P2Plane fit kernel: only for batches that can ever run the 64-lane search kernel (more than 2048 waves of
+    // queries); 32 B per point — 0.94 GB for 256 full scans, of 288 GB
+    if (ok && (size_t)((max_n + 63) / 64) * (size_t)n_scans > 2048)
+        ok = hip_ok(ctx, hipMalloc((void**)&b->d_plane_cache, b->pitch * 4 * sizeof(double)), "hipMalloc plane cache") &&
+             hip_ok(ctx, hipMalloc((void**)&b->d_same_mask, (size_t)n_scans * ((max_n + 63) / 64) * sizeof(unsigned long long)), "hipMalloc same-list mask");
     if (!ok) { free_batch(b); return LOCGPU_ERR_OOM; }
     *out = b;
     return LOCGPU_OK;
@@ -680,6 +687,7 @@ struct IterLauncher {
     bool replicated_on_comm_stream = false;  // the chunk's read-back must wait for the communication stream as well
     const int* active = nullptr;  // later chunks: the local scans still open (SearchArgs::active); nullptr = all
     int n_active = 0;
+    int iter = 0;            // index of the next iteration within its alignment (0 = the first: no previous neighbour lists)
     bool launch(int do_update);
     void collect_profile();
 };
@@ -724,6 +732,13 @@ bool IterLauncher::launch(int do_update) {
             }
             sa.touched = ctx->touched_words ? ctx->d_touched : nullptr;
         }
+        // plane cache (launch.hpp): wanted for P2Plane on batches that own one; usable when this launch runs the 64-lane walk kernel,
+        // trustworthy when the previous iteration of this alignment ran it as well
+        const bool want_cache = prm.method == LOCGPU_P2PLANE && b->d_plane_cache && !grid_mode && do_update;
+        sa.same_mask = want_cache ? b->d_same_mask : nullptr;
+        sa.have_previous = (want_cache && iter > 0 && b->cache_chain) ? 1 : 0;
+        const bool cached = want_cache && icp_search_writes_same_mask(sa);
+        if (!cached) { sa.same_mask = nullptr; sa.have_previous = 0; }
         const GridSearchScratch gsc{b->d_grid_qkey, b->d_grid_sorted};
         const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, gsc, s) : launch_icp_search(sa, s);
         if (!ok_search) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
@@ -732,6 +747,9 @@ bool IterLauncher::launch(int do_update) {
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
         AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
         aa.active = active; aa.n_active = n_active;
+        if (cached) { aa.plane_cache = b->d_plane_cache; aa.same_mask = b->d_same_mask; aa.use_cache = sa.have_previous; }
+        b->cache_chain = cached;
+        iter++;
         n_partial_blocks = launch_icp_accum(prm.method, aa, s);
     } else {
         mark(true);  // NDT has no separate search kernel: search slot stays empty
@@ -855,6 +873,8 @@ static int capture_chunk(locgpu_ctx* ctx, locgpu_batch* b, const GnParams& prm, 
     IterLauncher it{ctx, b, prm, k, alpha_eff};
     it.ndt = ndt;
     it.capturing = true;
+    it.iter = with_h2d ? 0 : kFirstChunk;  // the first graph starts an alignment, the second continues one
+    if (!with_h2d) b->cache_chain = b->d_plane_cache != nullptr && prm.method == LOCGPU_P2PLANE;  // captured behind the first graph's iterations (same launches, same kernels)
     for (int i = 0; ok && i < iters; ++i) ok = it.launch(1);
     ok = ok && hip_ok(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_total * sizeof(PoseState), hipMemcpyDeviceToHost, s), "capture D2H");
     const hipError_t e = hipStreamEndCapture(s, &graph);
@@ -899,6 +919,7 @@ static int enqueue_chunk(locgpu_ctx* ctx, locgpu_batch* b, bool first_chunk) {
     IterLauncher it{ctx, b, P.prm, P.k, P.alpha_eff};
     it.ndt = P.ndt;
     it.ev_used = P.ev_used;
+    it.iter = P.launched;
     static const bool use_active = [] { const char* e = getenv("LOCGPU_ACTIVE_LIST"); return !e || atoi(e) != 0; }();  // 0: every chunk launches every scan (A/B)
     if (!first_chunk && !P.ndt && b->n_scans > 1 && use_active) {
         // The host has just read every scan's flags (align_finish): launch the search and accumulate kernels of this chunk over the
@@ -937,6 +958,7 @@ static int align_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_pose
     P.graph = ctx->use_graph && !ctx->count_visits && !b->sharded && prm.max_iteration > 0;
     P.launched = 0;
     P.ev_used = 0;
+    b->cache_chain = false;
     P.init_poses.assign(init_poses, init_poses + 7 * (size_t)b->n_total);
     init_states(b, init_poses);
     // the search stage's work-list counters: zero once per alignment, whatever an earlier call that failed between a search and

@@ -602,6 +602,32 @@ def test_later_chunks_launch_only_the_open_scans(tmp_path):
         assert np.array_equal(outs["list"][name + "_flight"][:len(it)], outs["list"][name])
 
 
+def test_plane_cache_gives_the_uncached_kernels_bits(tmp_path):
+    """Round 4: on batches large enough for the 64-lane search kernel the P2Plane fit kernel keeps every point's plane 4-vector and refits
+    only the points whose five neighbour indices changed since the previous iteration (the search kernel leaves one bit per query).
+    A cached vector is what the same code computed from the same five leaves, so poses, iteration counts and H/B must equal the
+    uncached kernel's (LOCGPU_PLANE_CACHE=0) bit for bit — blocking, two in flight, under hipGraph replay, on repeated alignments of
+    one batch and with another method run on the batch in between."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, val in (("cache", "1"), ("plain", "0")):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_plane_cache_case.py"), f], env=dict(os.environ, LOCGPU_PLANE_CACHE=val),
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[tag] = np.load(f)
+    c, p = outs["cache"], outs["plain"]
+    assert c["it"].min() <= 3 and c["it"].max() > 8, c["it"]  # scans that stop at once and scans that outlive the first chunk
+    for name in ("pose", "it", "pose_again", "hb", "flight", "graph", "graph_again", "line", "pose_after_line"):
+        assert np.array_equal(c[name], p[name]), name
+    for name in ("pose_again", "graph", "graph_again", "pose_after_line"):
+        assert np.array_equal(c[name], c["pose"]), name
+    assert np.array_equal(c["flight"][:len(c["pose"])], c["pose"])
+
+
 # ----------------------------------------------------------------------------------------------- two alignments in flight
 def test_align_begin_end_two_batches_in_flight(gpu_ctx, api, small_world):
     """locgpu_*_align_batch_begin / locgpu_align_batch_end: two batches (different scans, ragged counts) begun back to back and ended
