@@ -208,13 +208,6 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     if (tid >= LANES || i >= counts[scan]) return;
     const size_t gi = (size_t)scan * max_n + i;
     const float4 p = load_once(&src[gi]);
-    // plane cache: the previous iteration's list of this query, read now (streamed, K coalesced dwords) and compared at the end
-    uint32_t prev_id[K];
-    const bool cmp_prev = LANES == 64 && same_mask != nullptr && have_previous != 0;  // wave-uniform
-    if (cmp_prev) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) prev_id[j] = __builtin_nontemporal_load(&nn[(size_t)j * nn_pitch + gi]);
-    }
     if (skip_nonfinite && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {  // pcl::isFinite, icp cpp:64 (P2P only)
 #pragma unroll
         for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = kInvalidSlot;
@@ -236,21 +229,26 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     }
     const bool deep = w.c3n == 1u;
     const bool slow = !deep && w.slow != 0u;
-    if (!deep && !slow) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
-    }
     if (LANES == 64 && same_mask != nullptr) {
-        // one word per wave: the lanes whose list is, index for index, the one the plane cache was filled for. A query finished by
-        // the deep pass, in the wave or by the redo kernel counts as changed (its list is written elsewhere): it is simply refitted.
-        bool same = cmp_prev && !deep && !slow;
-        if (cmp_prev) {
+        // Plane cache: one word per wave — the lanes whose list is, index for index, the previous iteration's (the one the fit kernel's
+        // cache was filled for). The old list is read HERE, at the end of the wave's life and right before it is overwritten (K
+        // coalesced dwords; read at the start, the loads sat in front of every tree load in the wave's in-order memory counter: +15 %
+        // search time). A query finished by the deep pass, in the wave or by the redo kernel counts as changed: it is simply refitted.
+        bool same = have_previous != 0 && !deep && !slow;
+        if (have_previous != 0) {
+            uint32_t prev_id[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) prev_id[j] = __builtin_nontemporal_load(&nn[(size_t)j * nn_pitch + gi]);
 #pragma unroll
             for (int j = 0; j < K; ++j) same = same && w.id[j] == prev_id[j];
         }
         const unsigned long long m = __ballot(same);
         if (__builtin_amdgcn_readfirstlane(tid) == tid)  // the first live lane of the wave
             same_mask[(size_t)scan * (size_t)((max_n + 63) >> 6) + blockIdx.x] = m;
+    }
+    if (!deep && !slow) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
     }
     wave_append(deep_list, deep_count, deep, (uint32_t)gi);
     if (LANES == 16) {
@@ -585,10 +583,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 //   2. the block's threads walk that list — full waves except the last: gather the five leaves, fit, residual check of the five
 //      (math_utils.h:112-136), and leave the 4-vector in the per-point cache in HBM (all zero = "no plane": k > size_, or the check failed;
 //      a fitted vector has unit length);
-//   3. every thread reads its points' vectors back (its own block wrote the new ones: visible after the barrier), forms residual and
-//      Jacobian (icp cpp:184-201) and the rows are summed exactly as in icp_plane_accum_kernel — same order, same bits.
+//   3. every thread takes its points' vectors — the fresh ones from LDS, the kept ones from the cache — forms residual and Jacobian
+//      (icp cpp:184-201) and the rows are summed exactly as in icp_plane_accum_kernel — same order, same bits.
 // A cached vector is the one the same code computed from the same five leaves: results equal the uncached kernel's bit for bit.
-constexpr int kPlaneCachePtsMax = 8;
+constexpr int kPlaneCachePts = 2;  // points per thread: 512 plane vectors (16 KB) stay in LDS between the fit and the residual stage
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_plane_cached_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
@@ -597,7 +595,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                                                                  const unsigned long long* __restrict__ same_mask, int use_cache) {
     __shared__ double s_row[8][kAccPad];
     __shared__ double s_slice[kBlock / 32][32];
-    __shared__ unsigned short s_todo[kPlaneCachePtsMax * kBlock];
+    __shared__ double s_n4[kPlaneCachePts * kBlock][4];  // the vectors fitted by this block, by point (a refit point is read back from here, not from HBM)
+    __shared__ unsigned short s_todo[kPlaneCachePts * kBlock];
     __shared__ int s_ntodo;
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;  // uniform per block
@@ -608,6 +607,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     if (tid == 0) s_ntodo = 0;
     __syncthreads();
     // ---- 1. which of the block's points need a fit
+    unsigned int refit_bits = 0;  // bit pp: this thread's pp-th point is (re)fitted by the block in stage 2
     const size_t mask_row = (size_t)scan * (size_t)((max_n + 63) >> 6);
 #pragma unroll 1
     for (int pp = 0; pp < kPlanePts; ++pp) {
@@ -615,6 +615,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const int i = base_i + off;
         bool todo = i < n_pts;
         if (todo && use_cache) todo = ((same_mask[mask_row + (size_t)(i >> 6)] >> (i & 63)) & 1ull) == 0ull;
+        refit_bits |= todo ? (1u << pp) : 0u;
         const unsigned long long m = __ballot(todo);
         if (m != 0ull) {
             const int lane = tid & 63;
@@ -630,7 +631,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const int n_todo = s_ntodo;
 #pragma unroll 1
     for (int t = tid; t < n_todo; t += kBlock) {
-        const size_t gi = scan_off + (size_t)(base_i + (int)s_todo[t]);
+        const int off = (int)s_todo[t];
+        const size_t gi = scan_off + (size_t)(base_i + off);
         uint32_t slot[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) slot[j] = __builtin_nontemporal_load(&nn[(size_t)j * nn_pitch + gi]);
@@ -651,8 +653,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         }
         double* c = plane_cache + 4 * gi;
         c[0] = n4[0]; c[1] = n4[1]; c[2] = n4[2]; c[3] = n4[3];
+        s_n4[off][0] = n4[0]; s_n4[off][1] = n4[1]; s_n4[off][2] = n4[2]; s_n4[off][3] = n4[3];
     }
-    __syncthreads();  // the block's own stores to plane_cache are visible to all of its threads from here on
+    __syncthreads();
     // ---- 3. residual, Jacobian, sums — as icp_plane_accum_kernel
     RowAccum ra;
     ra.init();
@@ -664,8 +667,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         double fitted = 0.0;
         if (i < n_pts) {
             const size_t gi = scan_off + (size_t)i;
-            const double* c = plane_cache + 4 * gi;
-            const double n40 = c[0], n41 = c[1], n42 = c[2], n43 = c[3];
+            double n40, n41, n42, n43;
+            if ((refit_bits >> pp) & 1u) {  // fitted a moment ago by this block: from LDS
+                const double* c = &s_n4[pp * kBlock + tid][0];
+                n40 = c[0]; n41 = c[1]; n42 = c[2]; n43 = c[3];
+            } else {                        // kept from an earlier iteration: from the cache
+                const double* c = plane_cache + 4 * gi;
+                n40 = c[0]; n41 = c[1]; n42 = c[2]; n43 = c[3];
+            }
             const float4 p = src[gi];
             if (!(n40 == 0.0 && n41 == 0.0 && n42 == 0.0 && n43 == 0.0)) {
                 fitted = 1.0;  // effective_num++ before the residual gate (icp cpp:184)
@@ -1187,13 +1196,19 @@ bool launch_icp_search_list(const SearchArgs& a, const uint32_t* list, const uns
     return false;
 }
 
+// LOCGPU_PLANE_CACHE (read once): 1 = on (default); 0 = off; experiments: 2 = the cached kernel's structure with every point refitted,
+// 3 = the search kernel marks unchanged lists but the plain fit kernel runs (prices the marking alone)
+int plane_cache_mode() {
+    static const int m = [] { const char* e = getenv("LOCGPU_PLANE_CACHE"); const int v = e ? atoi(e) : 1; return (v >= 0 && v <= 3) ? v : 1; }();
+    return m;
+}
+
 // Does launch_icp_search(a) run the 64-lane walk kernel, the one that fills a.same_mask? (The fit/accumulate launcher must take the
 // same decision: the plane cache is only usable behind it.) Mirrors the choices of launch_icp_search / launch_fast_kd.
 bool icp_search_writes_same_mask(const SearchArgs& a) {
     static const int walk = [] { const char* e = getenv("LOCGPU_WALK"); return e ? atoi(e) : 1; }();
     static const int small = [] { const char* e = getenv("LOCGPU_SMALL_LANES"); return e ? atoi(e) : 16; }();
-    static const bool cache_on = [] { const char* e = getenv("LOCGPU_PLANE_CACHE"); return !e || atoi(e) != 0; }();  // 0: A/B runs without the cache
-    if (!cache_on || !a.same_mask || a.k != 5 || a.depth > 64) return false;
+    if (plane_cache_mode() == 0 || !a.same_mask || a.k != 5 || a.depth > 64) return false;
     if (a.visit_totals != nullptr || search_variant() != 0 || !a.redo_list || !a.redo_list2 || walk != 1) return false;
     const int n_launch = a.active ? a.n_active : a.n_scans;
     if ((size_t)((a.max_n + 63) / 64) * n_launch <= 2048 && small == 16) return false;  // the 16-lane one-scan kernel
@@ -1240,6 +1255,7 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
     const long total_blocks = (long)blocks * a.n_scans;  // ALL scans of the batch, open or not: the split — hence the order of the sums — must not depend on a.active
     int pts = forced > 0 ? forced : (total_blocks >= 8192 ? (method == 2 ? 4 : 8) : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1)));
     if (pts > 8) pts = 8;
+    if (method == 2 && a.plane_cache && a.same_mask) pts = kPlaneCachePts;
     const dim3 grid((blocks + pts - 1) / pts, a.active ? a.n_active : a.n_scans);
     if (method == 2 && a.plane_cache && a.same_mask)
         hipLaunchKernelGGL(icp_plane_cached_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active,

@@ -64,6 +64,7 @@ struct AccumArgs {
 bool launch_icp_search(const SearchArgs& a, hipStream_t s);
 // true iff launch_icp_search(a) runs the kernel that fills a.same_mask (the plane cache of the fit kernel is usable behind it)
 bool icp_search_writes_same_mask(const SearchArgs& a);
+int plane_cache_mode();  // LOCGPU_PLANE_CACHE: 0 off, 1 on (default), 2 / 3 timing experiments (icp_kernels.hip)
 // exact tree traversal over a.redo_list only (the list is filled by a preceding fast / grid kernel)
 bool launch_icp_search_redo(const SearchArgs& a, hipStream_t s);
 // fast tree traversal (a.alpha_eff) over the queries in `list`, then the exact redo kernel for what it could not finish

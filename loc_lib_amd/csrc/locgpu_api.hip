@@ -747,7 +747,7 @@ bool IterLauncher::launch(int do_update) {
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
         AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
         aa.active = active; aa.n_active = n_active;
-        if (cached) { aa.plane_cache = b->d_plane_cache; aa.same_mask = b->d_same_mask; aa.use_cache = sa.have_previous; }
+        if (cached && plane_cache_mode() != 3) { aa.plane_cache = b->d_plane_cache; aa.same_mask = b->d_same_mask; aa.use_cache = plane_cache_mode() == 2 ? 0 : sa.have_previous; }
         b->cache_chain = cached;
         iter++;
         n_partial_blocks = launch_icp_accum(prm.method, aa, s);
