@@ -575,7 +575,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     ra.store(s_slice, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
 }
 
-// K2 with the PLANE CACHE (round 4; batches large enough for the 64-lane search kernel). FitPlane's 4-vector depends only on the five
+// K2 with the PLANE CACHE (round 4; OPT-IN with LOCGPU_PLANE_CACHE=1 — built, bit-identical, and a net LOSS on the
+// bench workload: per 256-scan step the fit kernel gains 0.15 ms (9.20 → 9.05: the fit is two thirds of the kernel, 30 % of the
+// point-iterations keep their list, and the compaction's own cost — barriers, scattered list loads, 32 B of cache traffic per point —
+// eats most of that), while the search kernel pays 2.0-2.4 ms for reading the previous lists back at the end of every wave
+// (profiles/experiments.md). Kept for the measurement, not selected by default.)
+// FitPlane's 4-vector depends only on the five
 // neighbour indices, and from the second iteration on a growing share of the points keeps its list (5 % / 13 % / 22 % / 36 % / 49 % / 60 % /
 // 69 % / 75 % in iterations 1…8 of the bench workload) — never a whole wave of them, so skipping the fit per lane saves nothing. Here
 // a block compacts the points that need a fit: the search kernel has left one bit per query ("same five indices as last time", same_mask),
@@ -1196,10 +1201,10 @@ bool launch_icp_search_list(const SearchArgs& a, const uint32_t* list, const uns
     return false;
 }
 
-// LOCGPU_PLANE_CACHE (read once): 1 = on (default); 0 = off; experiments: 2 = the cached kernel's structure with every point refitted,
-// 3 = the search kernel marks unchanged lists but the plain fit kernel runs (prices the marking alone)
+// LOCGPU_PLANE_CACHE (read once): 0 = off (DEFAULT: measured a net loss, see icp_plane_cached_accum_kernel), 1 = on; experiments: 2 = the
+// cached kernel's structure with every point refitted, 3 = the search kernel marks unchanged lists but the plain fit kernel runs
 int plane_cache_mode() {
-    static const int m = [] { const char* e = getenv("LOCGPU_PLANE_CACHE"); const int v = e ? atoi(e) : 1; return (v >= 0 && v <= 3) ? v : 1; }();
+    static const int m = [] { const char* e = getenv("LOCGPU_PLANE_CACHE"); const int v = e ? atoi(e) : 0; return (v >= 0 && v <= 3) ? v : 0; }();
     return m;
 }
 
