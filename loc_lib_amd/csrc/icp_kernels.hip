@@ -143,7 +143,7 @@ __global__ __launch_bounds__(BLK) void icp_search_fast_kernel(const uint2* __res
 // Every lane of the wave must call walk_query (wave-wide ballots inside); a lane without a query passes valid = false.
 template <int K, int ROWB, int MODE, bool STAMP = false>  // MODE 0: flat trips, 2: rounds, 12: rounds capped at two internal steps (default)
 __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const uint2* __restrict__ tree, Walk<K>& w, bool valid, float alpha_eff, int T, uint32_t dummy,
-                                           uint32_t col_addr, int cap) {
+                                           uint32_t col_addr, int cap, int stop_at = 0) {
 #pragma unroll
     for (int j = 0; j < K; ++j) { w.d[j] = __builtin_inff(); w.id[j] = kInvalidSlot; }
     w.slow = 0;
@@ -155,7 +155,7 @@ __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const ui
         w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = valid ? 1u : 0u;
     }
     if (MODE == 2) walk_rounds<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr, cap);
-    else if (MODE == 12) walk_rounds_capped<K, ROWB, 2, STAMP>(rsrc, w, alpha_eff, dummy, col_addr, cap);
+    else if (MODE == 12) walk_rounds_capped<K, ROWB, 2, STAMP>(rsrc, w, alpha_eff, dummy, col_addr, cap, stop_at);
     else do walk_trip<K, ROWB>(rsrc, w, alpha_eff, dummy, col_addr, cap); while (__ballot(w.cur != dummy || w.avail > 0) != 0ull);
 #pragma unroll
     for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;  // equal distances in the final set: heap pop order is layout-dependent
@@ -184,6 +184,38 @@ __device__ __forceinline__ bool walk_exact_in_wave(const uint2* __restrict__ tre
     return true;
 }
 
+// ---- straggler hand-over (round 4). A wave of the walk kernel stops once at most `stop_at` of its lanes still have work; those lanes
+// write what the traversal needs to go on — query, result set, position, flags and the live rows of their LDS stack — to a spill
+// record, and icp_search_walk_cont_kernel continues them, 64 to a wave. Same traversal, same order, same results; the rounds a wave
+// pays for its last few lanes are paid by full waves instead (paid rounds −20 % by simulation on per-query round counts of the bench
+// workload, tools/sim_wave_binning.py; restarting the stragglers from scratch instead of continuing them: −8 %).
+// Record of entry i of `cap`: hdr[i] = {query index, next slot, avail | slow << 16, c3n}, q[i] = query, set[j·cap + i] = {d_j, id_j},
+// stack[r·cap + i] = stack row r (r < avail). A straggler that finds the buffer full goes to the deep pass instead. (SpillBuf: launch.hpp)
+
+template <int K, int ROWB>
+__device__ __forceinline__ bool walk_spill(const SpillBuf& sp, const Walk<K>& w, uint32_t gi, uint32_t col_addr, bool active) {
+    const unsigned long long m = __ballot(active);
+    if (m == 0ull) return true;
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(sp.count, (unsigned int)__popcll(m));
+    base = (unsigned int)__shfl((int)base, leader, 64);
+    const unsigned int i = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+    const bool fits = i < sp.cap;  // per lane: the records [0, min(count, cap)) are all written, no holes
+    if (active && fits) {
+        sp.hdr[i] = uint4{gi, w.cur, (uint32_t)w.avail | (w.slow << 16), w.c3n};
+        sp.q[i] = float4{w.qx, w.qy, w.qz, 0.f};
+#pragma unroll
+        for (int j = 0; j < K; ++j) sp.set[(size_t)j * sp.cap + i] = uint2{__float_as_uint(w.d[j]), w.id[j]};
+        for (int r = 0; r < w.avail; ++r) {
+            const u32x2 row = *reinterpret_cast<lds_u32x2*>(col_addr + (uint32_t)r * ROWB);
+            sp.stack[(size_t)r * sp.cap + i] = uint2{row.x, row.y};
+        }
+    }
+    return fits;
+}
+
 // LANES = active lanes per wave = stack columns (64; 16 for launches that cannot fill the chip anyway: a wave's time is its
 // longest traversal, and with 128-byte rows every level fits in LDS — T = 0 — so that no query needs the deep pass).
 template <int K, int DF, int MODE, int LANES = 64, bool STAMP = false>
@@ -193,7 +225,8 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
                                                              unsigned int tree_bytes, uint32_t dummy, int skip_nonfinite, uint32_t* __restrict__ redo_list,
                                                              unsigned int* __restrict__ redo_count, uint32_t* __restrict__ deep_list,
                                                              unsigned int* __restrict__ deep_count, unsigned long long* __restrict__ search_stats,
-                                                             const int* __restrict__ active, unsigned long long* __restrict__ same_mask, int have_previous) {
+                                                             const int* __restrict__ active, unsigned long long* __restrict__ same_mask, int have_previous,
+                                                             SpillBuf spill, int stop_at) {
     extern __shared__ uint2 s_dyn[];
     constexpr int ROWB = LANES * 8;
     static_assert(DF * ROWB >= 64 * 2 * 8, "exact stack columns do not fit");
@@ -218,7 +251,15 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
     Walk<K> w;
     w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
-    walk_query<K, ROWB, MODE, STAMP>(rsrc, tree, w, true, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]), DF);  // DF rows: a stack that outgrows them → deep pass
+    walk_query<K, ROWB, MODE, STAMP>(rsrc, tree, w, true, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]), DF, stop_at);  // DF rows: a stack that outgrows them → deep pass
+    // lanes the loop left unfinished (stop_at > 0): to the continuation kernel, or — spill buffer full — to the deep pass
+    bool handed_over = false;
+    if (stop_at > 0) {
+        const bool unfinished = w.cur != dummy || w.avail > 0;
+        const bool fits = walk_spill<K, ROWB>(spill, w, (uint32_t)gi, (uint32_t)(size_t)(&s_dyn[tid]), unfinished);
+        if (unfinished && !fits) w.c3n = 1u;
+        handed_over = unfinished && fits;
+    }
     if (STAMP && search_stats) {
         // diagnostic build (LOCGPU_STAMP=1, MODE 12): rounds each lane needed against the rounds its wave ran — the kernel's lane
         // efficiency — and the per-query round counts behind the neighbour-list area of redo_list (2 x pitch entries in this build)
@@ -227,14 +268,14 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
         atomicAdd(&search_stats[13], (unsigned long long)w.wave_rounds);  // rounds paid by this lane's wave, summed over lanes
         redo_list[nn_pitch + gi] = w.rounds;
     }
-    const bool deep = w.c3n == 1u;
-    const bool slow = !deep && w.slow != 0u;
+    const bool deep = !handed_over && w.c3n == 1u;
+    const bool slow = !handed_over && !deep && w.slow != 0u;
     if (LANES == 64 && same_mask != nullptr) {
         // Plane cache: one word per wave — the lanes whose list is, index for index, the previous iteration's (the one the fit kernel's
         // cache was filled for). The old list is read HERE, at the end of the wave's life and right before it is overwritten (K
         // coalesced dwords; read at the start, the loads sat in front of every tree load in the wave's in-order memory counter: +15 %
         // search time). A query finished by the deep pass, in the wave or by the redo kernel counts as changed: it is simply refitted.
-        bool same = have_previous != 0 && !deep && !slow;
+        bool same = have_previous != 0 && !deep && !slow && !handed_over;
         if (have_previous != 0) {
             uint32_t prev_id[K];
 #pragma unroll
@@ -246,7 +287,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
         if (__builtin_amdgcn_readfirstlane(tid) == tid)  // the first live lane of the wave
             same_mask[(size_t)scan * (size_t)((max_n + 63) >> 6) + blockIdx.x] = m;
     }
-    if (!deep && !slow) {
+    if (!deep && !slow && !handed_over) {
 #pragma unroll
         for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
     }
@@ -303,6 +344,61 @@ __global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* _
 #pragma unroll
             for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = w.id[j];
         }
+        if (!walk_exact_in_wave<K>(tree, slow, w.qx, w.qy, w.qz, alpha_eff, s_dyn, nn, nn_pitch, gi, search_stats))
+            wave_append(redo_list, redo_count, slow, gi);
+    }
+}
+
+// Continuation of the walk kernel's stragglers (see SpillBuf): one-wave workgroups, grid-stride over the spill records, 64 to a wave;
+// every lane restores its query's registers and stack rows and goes on with the same loop to the end. Finished queries are handled
+// exactly as at the end of the walk kernel (list stored | deep pass | exact traversal for ties).
+template <int K, int DF, bool STAMP = false>
+__global__ __launch_bounds__(64) void icp_search_walk_cont_kernel(const uint2* __restrict__ tree, uint32_t* __restrict__ nn, size_t nn_pitch, float alpha_eff,
+                                                                  unsigned int tree_bytes, uint32_t dummy, SpillBuf spill, uint32_t* __restrict__ redo_list,
+                                                                  unsigned int* __restrict__ redo_count, uint32_t* __restrict__ deep_list,
+                                                                  unsigned int* __restrict__ deep_count, unsigned long long* __restrict__ search_stats) {
+    extern __shared__ uint2 s_dyn[];
+    constexpr int ROWB = 64 * 8;
+    if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();  // see icp_search_walk_kernel
+    const unsigned int n = min(*spill.count, spill.cap);
+    const int tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
+    const uint32_t col_addr = (uint32_t)(size_t)(&s_dyn[tid]);
+    for (unsigned int r0 = blockIdx.x * 64u; r0 < n; r0 += gridDim.x * 64u) {
+        const unsigned int i = r0 + (unsigned int)tid;
+        const bool valid = i < n;
+        Walk<K> w;
+        uint32_t gi = 0;
+        w.qx = w.qy = w.qz = 0.f;
+        w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { w.d[j] = __builtin_inff(); w.id[j] = kInvalidSlot; }
+        if (valid) {
+            const uint4 h = spill.hdr[i];
+            const float4 q = spill.q[i];
+            gi = h.x; w.cur = h.y; w.avail = (int)(h.z & 0xFFFFu); w.slow = h.z >> 16; w.c3n = h.w;
+            w.qx = q.x; w.qy = q.y; w.qz = q.z;
+#pragma unroll
+            for (int j = 0; j < K; ++j) { const uint2 e = spill.set[(size_t)j * spill.cap + i]; w.d[j] = as_f32(e.x); w.id[j] = e.y; }
+            for (int r = 0; r < w.avail; ++r) {
+                const uint2 row = spill.stack[(size_t)r * spill.cap + i];
+                *reinterpret_cast<lds_u32x2*>(col_addr + (uint32_t)r * ROWB) = u32x2{row.x, row.y};
+            }
+        }
+        walk_rounds_capped<K, ROWB, 2, STAMP>(rsrc, w, alpha_eff, dummy, col_addr, DF, 0);
+#pragma unroll
+        for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;
+        if (STAMP && search_stats && valid) {
+            atomicAdd(&search_stats[4], (unsigned long long)w.rounds);
+            atomicAdd(&search_stats[13], (unsigned long long)w.wave_rounds);
+        }
+        const bool deep = valid && w.c3n == 1u;
+        const bool slow = valid && !deep && w.slow != 0u;
+        if (valid && !deep && !slow) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
+        }
+        wave_append(deep_list, deep_count, deep, gi);
         if (!walk_exact_in_wave<K>(tree, slow, w.qx, w.qy, w.qz, alpha_eff, s_dyn, nn, nn_pitch, gi, search_stats))
             wave_append(redo_list, redo_count, slow, gi);
     }
@@ -875,7 +971,7 @@ __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restri
     const int scan = blockIdx.x;
     // The search stage's work-list counters (fast kernel → redo kernel) are consumed by now: zero them for the next iteration's
     // search instead of paying two fill launches per iteration (a single-scan alignment is launch-latency bound).
-    if (list_counts && scan == 0 && threadIdx.x < 2) list_counts[threadIdx.x] = 0u;
+    if (list_counts && scan == 0 && threadIdx.x < 4) list_counts[threadIdx.x] = 0u;
     if (st[scan].done) return;
     const double col_total = reduce_partials(partials + (size_t)scan * blocks_per_scan * kAccW, blocks_per_scan, true, s_sum);
     if (threadIdx.x < kAccW) s_sum[0][threadIdx.x] = col_total;
@@ -1056,7 +1152,8 @@ static bool no_static_lds() {
 }
 template <int K, int D, int DF>
 static bool walk_kernels_ok_kdf() {
-    return no_static_lds<icp_search_walk_kernel<K, DF, 0>>() && no_static_lds<icp_search_walk_kernel<K, DF, 2>>() && no_static_lds<icp_search_walk_kernel<K, DF, 12>>();
+    return no_static_lds<icp_search_walk_kernel<K, DF, 0>>() && no_static_lds<icp_search_walk_kernel<K, DF, 2>>() && no_static_lds<icp_search_walk_kernel<K, DF, 12>>() &&
+           no_static_lds<icp_search_walk_cont_kernel<K, DF>>();
 }
 template <int K, int D>
 static bool walk_kernels_ok_kd() {
@@ -1082,9 +1179,14 @@ static bool launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
         const int n_launch = a.active ? a.n_active : a.n_scans;
         dim3 g2((a.max_n + 63) / 64, n_launch);
+        static const int stop_env_s = [] { const char* e = getenv("LOCGPU_WALK_STOP"); return e ? atoi(e) : 8; }();
+        const int stop_at_s = (stop_env_s > 0 && stop_env_s < 32 && a.spill.hdr != nullptr && (size_t)g2.x * g2.y >= walk_stop_min_waves()) ? stop_env_s : 0;  // as the shipped launch below
         hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, 12, 64, true>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                            a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
-                           a.search_stats, a.active, a.same_mask, a.have_previous);
+                           a.search_stats, a.active, a.same_mask, a.have_previous, a.spill, stop_at_s);
+        if (stop_at_s > 0)
+            hipLaunchKernelGGL((icp_search_walk_cont_kernel<K, DF, true>), dim3(8192), dim3(64), DF * 64 * 8, s, a.tree, a.nn, a.nn_pitch, a.alpha_eff, (unsigned int)a.tree_bytes + 16u,
+                               dummy, a.spill, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats);
         hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(2048), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
                            a.alpha_eff, (unsigned int)a.tree_bytes + 16u, dummy, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count, a.search_stats);
         hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
@@ -1107,18 +1209,25 @@ static bool launch_fast_kd(const SearchArgs& a, hipStream_t s) {
             dim3 g1((a.max_n + 15) / 16, n_launch);
             hipLaunchKernelGGL((icp_search_walk_kernel<K, D + 2, 12, 16>), g1, dim3(64), (D + 2) * 16 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                                a.alpha_eff, 0, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
-                               a.search_stats, a.active, (unsigned long long*)nullptr, 0);
+                               a.search_stats, a.active, (unsigned long long*)nullptr, 0, SpillBuf{}, 0);
             return true;  // no redo launch: the 16-lane kernel answers its ties itself
         }
         const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
         dim3 g2((a.max_n + 63) / 64, n_launch);
+        // straggler hand-over (SpillBuf): only where the launch is long enough for one more kernel behind it to pay
+        static const int stop_env = [] { const char* e = getenv("LOCGPU_WALK_STOP"); return e ? atoi(e) : 8; }();  // lanes left when a wave stops; 0 = off
+        const bool hand_over = mode == 12 && stop_env > 0 && stop_env < 32 && a.spill.hdr != nullptr && (size_t)g2.x * g2.y >= walk_stop_min_waves();
+        const int stop_at = hand_over ? stop_env : 0;
 #define LOCGPU_WALK_LAUNCH(M) hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, M>), g2, dim3(64), DF * 64 * 8 + wpad, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, \
                                                  a.max_n, a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count,       \
-                                                 a.redo_list2, a.redo_count2, a.search_stats, a.active, a.same_mask, a.have_previous)
+                                                 a.redo_list2, a.redo_count2, a.search_stats, a.active, a.same_mask, a.have_previous, a.spill, stop_at)
         if (mode == 2) LOCGPU_WALK_LAUNCH(2);
         else if (mode == 12) LOCGPU_WALK_LAUNCH(12);
         else LOCGPU_WALK_LAUNCH(0);
 #undef LOCGPU_WALK_LAUNCH
+        if (hand_over)
+            hipLaunchKernelGGL((icp_search_walk_cont_kernel<K, DF>), dim3(8192), dim3(64), DF * 64 * 8, s, a.tree, a.nn, a.nn_pitch, a.alpha_eff, (unsigned int)a.tree_bytes + 16u,
+                               dummy, a.spill, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats);
         // 2048 one-wave blocks of 17 KB LDS are all resident at once (nine fit a CU): the first iteration's ≈140 k deep queries take one
         // traversal per wave instead of two or three in sequence (search 18.07 → 17.80 ms per 256-scan step; 4608: 17.96)
         static const int deep_grid = [] { const char* e = getenv("LOCGPU_DEEP_GRID"); return e ? atoi(e) : 2048; }();
@@ -1199,6 +1308,13 @@ bool launch_icp_search_list(const SearchArgs& a, const uint32_t* list, const uns
     if (a.k == 1) return launch_fast_list_k<1>(a, list, n_list, s);
     if (a.k == 5) return launch_fast_list_k<5>(a, list, n_list, s);
     return false;
+}
+
+// Waves of queries from which a search launch hands its stragglers over to the continuation kernel (one more launch must pay for
+// itself); LOCGPU_WALK_STOP_MIN_WAVES lowers it for the parity tests.
+size_t walk_stop_min_waves() {
+    static const size_t v = [] { const char* e = getenv("LOCGPU_WALK_STOP_MIN_WAVES"); return e ? (size_t)atoll(e) : (size_t)16384; }();
+    return v;
 }
 
 // LOCGPU_PLANE_CACHE (read once): 0 = off (DEFAULT: measured a net loss, see icp_plane_cached_accum_kernel), 1 = on; experiments: 2 = the

@@ -9,6 +9,16 @@ namespace locgpu {
 
 struct GnParams;
 
+// Spill records of the search kernel's stragglers (icp_kernels.hip, "straggler hand-over"): entry i of `cap`.
+struct SpillBuf {
+    uint4* hdr = nullptr;    // {query index, next slot, avail | slow << 16, c3n}
+    float4* q = nullptr;     // the query
+    uint2* set = nullptr;    // [5][cap] {d_j, id_j}
+    uint2* stack = nullptr;  // [rows][cap] the stack rows below avail
+    unsigned int cap = 0;
+    unsigned int* count = nullptr;
+};
+
 struct SearchArgs {
     const uint2* tree;
     size_t tree_bytes;
@@ -37,6 +47,7 @@ struct SearchArgs {
     // lists in nn are the previous iteration's of this very alignment (else every bit is 0). nullptr = not wanted.
     unsigned long long* same_mask = nullptr;
     int have_previous = 0;
+    SpillBuf spill;  // straggler hand-over of the 64-lane walk kernel; hdr == nullptr = none
     // instrumented pass only: bitmap over the tree's 8-byte slots (one bit each, zeroed by the caller, counted and cleared again
     // by launch_count_touched) — which slots this search launch reads at all
     uint32_t* touched = nullptr;
@@ -64,6 +75,7 @@ struct AccumArgs {
 bool launch_icp_search(const SearchArgs& a, hipStream_t s);
 // true iff launch_icp_search(a) runs the kernel that fills a.same_mask (the plane cache of the fit kernel is usable behind it)
 bool icp_search_writes_same_mask(const SearchArgs& a);
+size_t walk_stop_min_waves();  // search launches of at least this many waves hand their stragglers over (LOCGPU_WALK_STOP_MIN_WAVES)
 int plane_cache_mode();  // LOCGPU_PLANE_CACHE: 0 off, 1 on (default), 2 / 3 timing experiments (icp_kernels.hip)
 // exact tree traversal over a.redo_list only (the list is filled by a preceding fast / grid kernel)
 bool launch_icp_search_redo(const SearchArgs& a, hipStream_t s);

@@ -112,6 +112,7 @@ static void free_batch(locgpu_batch* b) {
     if (b->d_counts) (void)hipFree(b->d_counts);
     if (b->d_state) (void)hipFree(b->d_state);
     if (b->d_nn) (void)hipFree(b->d_nn);
+    if (b->d_spill) (void)hipFree(b->d_spill);
     if (b->d_plane_cache) (void)hipFree(b->d_plane_cache);
     if (b->d_same_mask) (void)hipFree(b->d_same_mask);
     if (b->d_partials) (void)hipFree(b->d_partials);
@@ -524,16 +525,23 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               hip_ok(ctx, hipMalloc((void**)&b->d_hb, (size_t)n_total * 44 * sizeof(double)), "hipMalloc hb") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_list, (getenv("LOCGPU_STAMP") ? 2 : 1) * std::max<size_t>(b->pitch, 1) * sizeof(uint32_t)), "hipMalloc redo") &&  // diagnostic build: + per-query trip counts
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_list2, std::max<size_t>(b->pitch, 1) * sizeof(uint32_t)), "hipMalloc redo2") &&  // deep pass / grid search: second work list
-              hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, 2 * sizeof(unsigned int)), "hipMalloc redo") &&
+              hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, 4 * sizeof(unsigned int)), "hipMalloc redo") &&  // [0] redo list, [1] deep list, [2] spill records, [3] spare
               hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_total * sizeof(PoseState)), "hipHostMalloc state") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_total * 44 * sizeof(double)), "hipHostMalloc hb") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipHostMalloc active") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipMalloc active") &&
               hip_ok(ctx, hipMemset(b->d_counts, 0, std::max(n_scans, 1) * sizeof(int)), "hipMemset counts") &&
-              hip_ok(ctx, hipMemset(b->d_redo_count, 0, 2 * sizeof(unsigned int)), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
-    // plane cache of the P2Plane fit kernel: only for batches that can ever run the 64-lane search kernel (more than 2048 waves of
-    // queries); 32 B per point — 0.94 GB for 256 full scans, of 288 GB
-    if (ok && (size_t)((max_n + 63) / 64) * (size_t)n_scans > 2048)
+              hip_ok(ctx, hipMemset(b->d_redo_count, 0, 4 * sizeof(unsigned int)), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
+    // Spill records of the search kernel's stragglers (launch.hpp SpillBuf): batches of at least 16384 waves of queries; at most
+    // 8 of a wave's 64 lanes are handed over by default (LOCGPU_WALK_STOP), room for 10: 16 + 16 + 40 + 8 x 24 rows = 264 B per
+    // record — 1.2 GB for 256 full scans, of 288 GB
+    if (ok && (size_t)((max_n + 63) / 64) * (size_t)n_scans >= walk_stop_min_waves()) {
+        b->spill_cap = (unsigned int)std::min<size_t>(b->pitch / 64 * 10 + 1024, 0x7FFFFFFFull);
+        ok = hip_ok(ctx, hipMalloc(&b->d_spill, (size_t)b->spill_cap * kSpillRecordBytes), "hipMalloc spill records");
+    }
+    // plane cache of the P2Plane fit kernel (opt-in, LOCGPU_PLANE_CACHE=1): only for batches that can ever run the 64-lane search kernel
+    // (more than 2048 waves of queries); 32 B per point — 0.94 GB for 256 full scans
+    if (ok && plane_cache_mode() != 0 && (size_t)((max_n + 63) / 64) * (size_t)n_scans > 2048)
         ok = hip_ok(ctx, hipMalloc((void**)&b->d_plane_cache, b->pitch * 4 * sizeof(double)), "hipMalloc plane cache") &&
              hip_ok(ctx, hipMalloc((void**)&b->d_same_mask, (size_t)n_scans * ((max_n + 63) / 64) * sizeof(unsigned long long)), "hipMalloc same-list mask");
     if (!ok) { free_batch(b); return LOCGPU_ERR_OOM; }
@@ -722,6 +730,16 @@ bool IterLauncher::launch(int do_update) {
         if (grid_mode && !b->d_grid_qkey) { fail(ctx, LOCGPU_ERR_INVALID, "grid search: work list missing (ensure_grid_lists was not called)"); return false; }
         sa.redo_list2 = b->d_redo_list2;
         sa.active = active; sa.n_active = n_active;
+        if (b->d_spill) {
+            char* base = (char*)b->d_spill;
+            const size_t cap = b->spill_cap;
+            sa.spill.hdr = (uint4*)base;
+            sa.spill.q = (float4*)(base + cap * 16);
+            sa.spill.set = (uint2*)(base + cap * 32);
+            sa.spill.stack = (uint2*)(base + cap * 72);
+            sa.spill.cap = b->spill_cap;
+            sa.spill.count = b->d_redo_count + 2;
+        }
         if (sa.visit_totals && !capturing) {  // instrumented pass: which tree slots does this launch read at all? (bench.py: compulsory bytes)
             const size_t words = (ctx->tree_slots + 2 + 31) / 32;
             if (words > ctx->touched_words) {
@@ -963,7 +981,7 @@ static int align_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_pose
     init_states(b, init_poses);
     // the search stage's work-list counters: zero once per alignment, whatever an earlier call that failed between a search and
     // its solve kernel left behind (the solve kernel re-zeroes them after every search)
-    if (!ndt) LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 2 * sizeof(unsigned int), b->stream));
+    if (!ndt) LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 4 * sizeof(unsigned int), b->stream));
     if (P.graph) { const int rc = ensure_graphs(ctx, b, prm, k, alpha_eff, ndt); if (rc != LOCGPU_OK) return rc; }
     if (prm.max_iteration > 0) { const int rc = enqueue_chunk(ctx, b, true); if (rc != LOCGPU_OK) return rc; }
     P.active = true;
@@ -1152,7 +1170,7 @@ int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* poses, c
     { const int urc = batch_ready(ctx, b); if (urc != LOCGPU_OK) return urc; }
     if (b->pending.active) return fail(ctx, LOCGPU_ERR_INVALID, "icp_hb_batch: an alignment of this batch has been begun and not finished");
     init_states(b, poses);
-    LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 2 * sizeof(unsigned int), b->stream));
+    LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 4 * sizeof(unsigned int), b->stream));
     LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, b->stream));
     IterLauncher it{ctx, b, prm, k, alpha_eff};
     if (!it.launch(0)) return LOCGPU_ERR_NO_DEVICE;

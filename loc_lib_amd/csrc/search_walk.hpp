@@ -332,8 +332,12 @@ __device__ __forceinline__ void walk_rounds(__amdgpu_buffer_rsrc_t rsrc, Walk<K>
 // Capped rounds: like walk_rounds, but a round runs at most C internal steps; a lane that has not reached its leaf by then sits
 // out the next leaf stage (x = +inf, pop switched off) and keeps descending after it. Between the flat loop (C = 1, both blocks
 // every trip) and the rounds loop (C = ∞: every round waits for the wave's longest descent).
+// stop_at (round 4): the loop ends once at most `stop_at` lanes of the wave still have work — a wave runs until its slowest lane is done,
+// and the last few lanes of nearly every wave are what half of the rounds are paid for (lane efficiency 0.53). The lanes left over
+// keep their state in w and in their stack rows: the caller spills it and a continuation kernel picks them up, 64 stragglers to a
+// wave, with this very function (it reloads the node at w.cur first). 0 = run to the end.
 template <int K, int ROWB, int C, bool STAMP = false>
-__device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr, int cap) {
+__device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr, int cap, int stop_at = 0) {
     const float qx = w.qx, qy = w.qy, qz = w.qz;
     uint32_t cur = w.cur;
     int avail = w.avail;
@@ -418,7 +422,7 @@ __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, 
                 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
             }
         }
-    } while (__ballot(cur != dummy || avail > 0) != 0ull);
+    } while (__popcll(__ballot(cur != dummy || avail > 0)) > stop_at);
 #pragma unroll
     for (int j = 0; j < K; ++j) { w.d[j] = d[j]; w.id[j] = id[j]; }
     w.slow = slow; w.c3n = c3n; w.cur = cur; w.avail = avail;

@@ -444,6 +444,26 @@ def test_search_parity_at_other_stack_depths(rows):
     assert " passed" in out.stdout
 
 
+# ----------------------------------------------------------------------------------------------- straggler hand-over
+@pytest.mark.parametrize("stop,rows", [("8", "15"), ("24", "15"), ("8", "12")])
+def test_search_parity_with_the_straggler_handover(stop, rows):
+    """Round 4: a wave of the 64-lane search kernel stops once at most LOCGPU_WALK_STOP of its lanes still have work and hands those
+    queries — registers and the live rows of their LDS stacks — to a continuation kernel that packs 64 of them to a wave. Same
+    traversal, so the index-list / H,B / alignment parity tests must pass unchanged; LOCGPU_WALK_STOP_MIN_WAVES=2049 switches the
+    hand-over on for every launch of the batch kernel (by default only launches of 16384 waves or more use it), 24 lanes makes a
+    third of the queries travel, 12 stack rows add the deep pass and the overflow rule on top."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LOCGPU_WALK_STOP=stop, LOCGPU_WALK_STOP_MIN_WAVES="2049", LOCGPU_FAST_STACK=rows)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_configs.py"),
+                          "-q", "-m", "gpu", "-x", "-k", "hot_search or bench_config_parity or later_chunks or (align and not sharded and not ndt and not handover)"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
+    assert " passed" in out.stdout
+
+
 # ----------------------------------------------------------------------------------------------- measurement hooks
 def test_profile_modes_and_marshalled_scans():
     """locgpu_profile_enable: 1 times all three stages, 2 only the search stage (what bench.py uses inside its timed region); a
