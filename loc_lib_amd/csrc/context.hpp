@@ -99,6 +99,7 @@ struct locgpu_batch {
     // spill records of the search kernel's stragglers (launch.hpp SpillBuf; large batches only)
     void* d_spill = nullptr;
     unsigned int spill_cap = 0;
+    size_t spill_waves = 0;
     // plane cache of the P2Plane fit kernel (batches large enough for the 64-lane search kernel; launch.hpp): per point the plane
     // 4-vector fitted for the list it had then, per 64 queries the "same list as last iteration" bits of the search kernel
     double* d_plane_cache = nullptr;             // [pitch][4]

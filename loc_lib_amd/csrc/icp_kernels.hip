@@ -190,20 +190,18 @@ __device__ __forceinline__ bool walk_exact_in_wave(const uint2* __restrict__ tre
 // pays for its last few lanes are paid by full waves instead (paid rounds −20 % by simulation on per-query round counts of the bench
 // workload, tools/sim_wave_binning.py; restarting the stragglers from scratch instead of continuing them: −8 %).
 // Record of entry i of `cap`: hdr[i] = {query index, next slot, avail | slow << 16, c3n}, q[i] = query, set[j·cap + i] = {d_j, id_j},
-// stack[r·cap + i] = stack row r (r < avail). A straggler that finds the buffer full goes to the deep pass instead. (SpillBuf: launch.hpp)
+// stack[r·cap + i] = stack row r (r < avail). Wave g of a launch owns the entries [g·stop_at, (g + 1)·stop_at) and writes how many
+// it used to n[g] (SpillBuf: launch.hpp): no counter is shared, and the continuation's waves are ≈80 % full instead of packed.
 
 template <int K, int ROWB>
-__device__ __forceinline__ bool walk_spill(const SpillBuf& sp, const Walk<K>& w, uint32_t gi, uint32_t col_addr, bool active) {
+__device__ __forceinline__ void walk_spill(const SpillBuf& sp, const Walk<K>& w, uint32_t gi, uint32_t col_addr, bool active, unsigned int region, int per_region) {
+    // No shared counter: one atomic per wave on one address serialises (≈3.5 ns each: +1.6 ms on a 460 k-wave launch, measured).
+    // Region `region` of the buffer belongs to this wave alone; it holds at most per_region (= stop_at) stragglers.
     const unsigned long long m = __ballot(active);
-    if (m == 0ull) return true;
     const int lane = (int)__lane_id();
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(sp.count, (unsigned int)__popcll(m));
-    base = (unsigned int)__shfl((int)base, leader, 64);
-    const unsigned int i = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-    const bool fits = i < sp.cap;  // per lane: the records [0, min(count, cap)) are all written, no holes
-    if (active && fits) {
+    if (lane == (int)__builtin_amdgcn_readfirstlane(lane)) sp.n[region] = (unsigned int)__popcll(m);  // 0 for a wave that finished: the continuation skips it
+    if (active) {
+        const size_t i = (size_t)region * (size_t)per_region + (size_t)__popcll(m & ((1ull << lane) - 1ull));
         sp.hdr[i] = uint4{gi, w.cur, (uint32_t)w.avail | (w.slow << 16), w.c3n};
         sp.q[i] = float4{w.qx, w.qy, w.qz, 0.f};
 #pragma unroll
@@ -213,7 +211,6 @@ __device__ __forceinline__ bool walk_spill(const SpillBuf& sp, const Walk<K>& w,
             sp.stack[(size_t)r * sp.cap + i] = uint2{row.x, row.y};
         }
     }
-    return fits;
 }
 
 // LANES = active lanes per wave = stack columns (64; 16 for launches that cannot fill the chip anyway: a wave's time is its
@@ -235,30 +232,29 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     // (lds_stack_starts_at_zero); this is the last line of defence — wrong neighbours or an endless loop otherwise.
     if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;  // later chunks of an alignment launch only the scans still open
-    if (st[scan].done) return;
     const int tid = threadIdx.x;
+    // straggler hand-over: this wave's count is written by lane 0 — here for a wave that leaves at once, again in walk_spill (the
+    // live lanes of a wave are a prefix of it, so lane 0 is among them)
+    if (stop_at > 0 && tid == 0) spill.n[blockIdx.y * gridDim.x + blockIdx.x] = 0u;
+    if (st[scan].done) return;
     const int i = blockIdx.x * LANES + tid;
     if (tid >= LANES || i >= counts[scan]) return;
     const size_t gi = (size_t)scan * max_n + i;
     const float4 p = load_once(&src[gi]);
-    if (skip_nonfinite && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {  // pcl::isFinite, icp cpp:64 (P2P only)
-#pragma unroll
-        for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = kInvalidSlot;
-        return;
-    }
-    if (search_stats) atomicAdd(&search_stats[0], 1ull);
+    // pcl::isFinite, icp cpp:64 (P2P only): such a point has no neighbours; its lane stays in the wave with nothing to do (the list
+    // it stores at the end is the empty one)
+    const bool finite = !skip_nonfinite || (isfinite(p.x) && isfinite(p.y) && isfinite(p.z));
+    if (search_stats && finite) atomicAdd(&search_stats[0], 1ull);
     const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
     Walk<K> w;
     w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
-    walk_query<K, ROWB, MODE, STAMP>(rsrc, tree, w, true, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]), DF, stop_at);  // DF rows: a stack that outgrows them → deep pass
-    // lanes the loop left unfinished (stop_at > 0): to the continuation kernel, or — spill buffer full — to the deep pass
+    walk_query<K, ROWB, MODE, STAMP>(rsrc, tree, w, finite, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]), DF, stop_at);  // DF rows: a stack that outgrows them → deep pass
+    // lanes the loop left unfinished (stop_at > 0): to the continuation kernel
     bool handed_over = false;
     if (stop_at > 0) {
-        const bool unfinished = w.cur != dummy || w.avail > 0;
-        const bool fits = walk_spill<K, ROWB>(spill, w, (uint32_t)gi, (uint32_t)(size_t)(&s_dyn[tid]), unfinished);
-        if (unfinished && !fits) w.c3n = 1u;
-        handed_over = unfinished && fits;
+        handed_over = w.cur != dummy || w.avail > 0;
+        walk_spill<K, ROWB>(spill, w, (uint32_t)gi, (uint32_t)(size_t)(&s_dyn[tid]), handed_over, blockIdx.y * gridDim.x + blockIdx.x, stop_at);
     }
     if (STAMP && search_stats) {
         // diagnostic build (LOCGPU_STAMP=1, MODE 12): rounds each lane needed against the rounds its wave ran — the kernel's lane
@@ -354,54 +350,55 @@ __global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* _
 // exactly as at the end of the walk kernel (list stored | deep pass | exact traversal for ties).
 template <int K, int DF, bool STAMP = false>
 __global__ __launch_bounds__(64) void icp_search_walk_cont_kernel(const uint2* __restrict__ tree, uint32_t* __restrict__ nn, size_t nn_pitch, float alpha_eff,
-                                                                  unsigned int tree_bytes, uint32_t dummy, SpillBuf spill, uint32_t* __restrict__ redo_list,
-                                                                  unsigned int* __restrict__ redo_count, uint32_t* __restrict__ deep_list,
-                                                                  unsigned int* __restrict__ deep_count, unsigned long long* __restrict__ search_stats) {
+                                                                  unsigned int tree_bytes, uint32_t dummy, SpillBuf spill, unsigned int n_regions, int per_region,
+                                                                  uint32_t* __restrict__ redo_list, unsigned int* __restrict__ redo_count,
+                                                                  uint32_t* __restrict__ deep_list, unsigned int* __restrict__ deep_count,
+                                                                  unsigned long long* __restrict__ search_stats) {
     extern __shared__ uint2 s_dyn[];
     constexpr int ROWB = 64 * 8;
     if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();  // see icp_search_walk_kernel
-    const unsigned int n = min(*spill.count, spill.cap);
     const int tid = threadIdx.x;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
     const uint32_t col_addr = (uint32_t)(size_t)(&s_dyn[tid]);
-    for (unsigned int r0 = blockIdx.x * 64u; r0 < n; r0 += gridDim.x * 64u) {
-        const unsigned int i = r0 + (unsigned int)tid;
-        const bool valid = i < n;
-        Walk<K> w;
-        uint32_t gi = 0;
-        w.qx = w.qy = w.qz = 0.f;
-        w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = 0;
+    // entry i of the buffer: region i / per_region (one walk-kernel wave), its (i % per_region)-th straggler
+    const size_t i = (size_t)blockIdx.x * 64u + (size_t)tid;
+    const unsigned int region = (unsigned int)(i / (unsigned int)per_region);
+    const bool valid = region < n_regions && (unsigned int)(i % (unsigned int)per_region) < spill.n[region];
+    if (__ballot(valid) == 0ull) return;
+    Walk<K> w;
+    uint32_t gi = 0;
+    w.qx = w.qy = w.qz = 0.f;
+    w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = 0;
 #pragma unroll
-        for (int j = 0; j < K; ++j) { w.d[j] = __builtin_inff(); w.id[j] = kInvalidSlot; }
-        if (valid) {
-            const uint4 h = spill.hdr[i];
-            const float4 q = spill.q[i];
-            gi = h.x; w.cur = h.y; w.avail = (int)(h.z & 0xFFFFu); w.slow = h.z >> 16; w.c3n = h.w;
-            w.qx = q.x; w.qy = q.y; w.qz = q.z;
+    for (int j = 0; j < K; ++j) { w.d[j] = __builtin_inff(); w.id[j] = kInvalidSlot; }
+    if (valid) {
+        const uint4 h = spill.hdr[i];
+        const float4 q = spill.q[i];
+        gi = h.x; w.cur = h.y; w.avail = (int)(h.z & 0xFFFFu); w.slow = h.z >> 16; w.c3n = h.w;
+        w.qx = q.x; w.qy = q.y; w.qz = q.z;
 #pragma unroll
-            for (int j = 0; j < K; ++j) { const uint2 e = spill.set[(size_t)j * spill.cap + i]; w.d[j] = as_f32(e.x); w.id[j] = e.y; }
-            for (int r = 0; r < w.avail; ++r) {
-                const uint2 row = spill.stack[(size_t)r * spill.cap + i];
-                *reinterpret_cast<lds_u32x2*>(col_addr + (uint32_t)r * ROWB) = u32x2{row.x, row.y};
-            }
+        for (int j = 0; j < K; ++j) { const uint2 e = spill.set[(size_t)j * spill.cap + i]; w.d[j] = as_f32(e.x); w.id[j] = e.y; }
+        for (int r = 0; r < w.avail; ++r) {
+            const uint2 row = spill.stack[(size_t)r * spill.cap + i];
+            *reinterpret_cast<lds_u32x2*>(col_addr + (uint32_t)r * ROWB) = u32x2{row.x, row.y};
         }
-        walk_rounds_capped<K, ROWB, 2, STAMP>(rsrc, w, alpha_eff, dummy, col_addr, DF, 0);
-#pragma unroll
-        for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;
-        if (STAMP && search_stats && valid) {
-            atomicAdd(&search_stats[4], (unsigned long long)w.rounds);
-            atomicAdd(&search_stats[13], (unsigned long long)w.wave_rounds);
-        }
-        const bool deep = valid && w.c3n == 1u;
-        const bool slow = valid && !deep && w.slow != 0u;
-        if (valid && !deep && !slow) {
-#pragma unroll
-            for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
-        }
-        wave_append(deep_list, deep_count, deep, gi);
-        if (!walk_exact_in_wave<K>(tree, slow, w.qx, w.qy, w.qz, alpha_eff, s_dyn, nn, nn_pitch, gi, search_stats))
-            wave_append(redo_list, redo_count, slow, gi);
     }
+    walk_rounds_capped<K, ROWB, 2, STAMP>(rsrc, w, alpha_eff, dummy, col_addr, DF, 0);
+#pragma unroll
+    for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;
+    if (STAMP && search_stats && valid) {
+        atomicAdd(&search_stats[4], (unsigned long long)w.rounds);
+        atomicAdd(&search_stats[13], (unsigned long long)w.wave_rounds);
+    }
+    const bool deep = valid && w.c3n == 1u;
+    const bool slow = valid && !deep && w.slow != 0u;
+    if (valid && !deep && !slow) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
+    }
+    wave_append(deep_list, deep_count, deep, gi);
+    if (!walk_exact_in_wave<K>(tree, slow, w.qx, w.qy, w.qz, alpha_eff, s_dyn, nn, nn_pitch, gi, search_stats))
+        wave_append(redo_list, redo_count, slow, gi);
 }
 
 // The fast traversal over a LIST of queries (grid mode: what the tile kernel could not settle, with alpha_eff = 1). One-wave
@@ -1180,13 +1177,16 @@ static bool launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         const int n_launch = a.active ? a.n_active : a.n_scans;
         dim3 g2((a.max_n + 63) / 64, n_launch);
         static const int stop_env_s = [] { const char* e = getenv("LOCGPU_WALK_STOP"); return e ? atoi(e) : 8; }();
-        const int stop_at_s = (stop_env_s > 0 && stop_env_s < 32 && a.spill.hdr != nullptr && (size_t)g2.x * g2.y >= walk_stop_min_waves()) ? stop_env_s : 0;  // as the shipped launch below
+        const int stop_at_s = (stop_env_s > 0 && stop_env_s < 32 && a.spill.hdr != nullptr && (size_t)g2.x * g2.y >= walk_stop_min_waves() &&
+                               (size_t)g2.x * g2.y * stop_env_s <= a.spill.cap) ? stop_env_s : 0;  // as the shipped launch below
         hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, 12, 64, true>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                            a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2,
                            a.search_stats, a.active, a.same_mask, a.have_previous, a.spill, stop_at_s);
-        if (stop_at_s > 0)
-            hipLaunchKernelGGL((icp_search_walk_cont_kernel<K, DF, true>), dim3(8192), dim3(64), DF * 64 * 8, s, a.tree, a.nn, a.nn_pitch, a.alpha_eff, (unsigned int)a.tree_bytes + 16u,
-                               dummy, a.spill, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats);
+        if (stop_at_s > 0) {
+            const unsigned int n_regions = g2.x * g2.y;
+            hipLaunchKernelGGL((icp_search_walk_cont_kernel<K, DF, true>), dim3((unsigned int)(((size_t)n_regions * stop_at_s + 63) / 64)), dim3(64), DF * 64 * 8, s, a.tree, a.nn, a.nn_pitch,
+                               a.alpha_eff, (unsigned int)a.tree_bytes + 16u, dummy, a.spill, n_regions, stop_at_s, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats);
+        }
         hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(2048), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
                            a.alpha_eff, (unsigned int)a.tree_bytes + 16u, dummy, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count, a.search_stats);
         hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
@@ -1216,7 +1216,8 @@ static bool launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         dim3 g2((a.max_n + 63) / 64, n_launch);
         // straggler hand-over (SpillBuf): only where the launch is long enough for one more kernel behind it to pay
         static const int stop_env = [] { const char* e = getenv("LOCGPU_WALK_STOP"); return e ? atoi(e) : 8; }();  // lanes left when a wave stops; 0 = off
-        const bool hand_over = mode == 12 && stop_env > 0 && stop_env < 32 && a.spill.hdr != nullptr && (size_t)g2.x * g2.y >= walk_stop_min_waves();
+        const bool hand_over = mode == 12 && stop_env > 0 && stop_env < 32 && a.spill.hdr != nullptr && (size_t)g2.x * g2.y >= walk_stop_min_waves() &&
+                               (size_t)g2.x * g2.y * stop_env <= a.spill.cap;
         const int stop_at = hand_over ? stop_env : 0;
 #define LOCGPU_WALK_LAUNCH(M) hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, M>), g2, dim3(64), DF * 64 * 8 + wpad, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, \
                                                  a.max_n, a.alpha_eff, Tw, (unsigned int)a.tree_bytes + 16u, dummy, a.skip_nonfinite, a.redo_list, a.redo_count,       \
@@ -1225,9 +1226,12 @@ static bool launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         else if (mode == 12) LOCGPU_WALK_LAUNCH(12);
         else LOCGPU_WALK_LAUNCH(0);
 #undef LOCGPU_WALK_LAUNCH
-        if (hand_over)
-            hipLaunchKernelGGL((icp_search_walk_cont_kernel<K, DF>), dim3(8192), dim3(64), DF * 64 * 8, s, a.tree, a.nn, a.nn_pitch, a.alpha_eff, (unsigned int)a.tree_bytes + 16u,
-                               dummy, a.spill, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats);
+        if (hand_over) {
+            const unsigned int n_regions = g2.x * g2.y;
+            const unsigned int cont_waves = (unsigned int)(((size_t)n_regions * stop_at + 63) / 64);
+            hipLaunchKernelGGL((icp_search_walk_cont_kernel<K, DF>), dim3(cont_waves), dim3(64), DF * 64 * 8, s, a.tree, a.nn, a.nn_pitch, a.alpha_eff, (unsigned int)a.tree_bytes + 16u,
+                               dummy, a.spill, n_regions, stop_at, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats);
+        }
         // 2048 one-wave blocks of 17 KB LDS are all resident at once (nine fit a CU): the first iteration's ≈140 k deep queries take one
         // traversal per wave instead of two or three in sequence (search 18.07 → 17.80 ms per 256-scan step; 4608: 17.96)
         static const int deep_grid = [] { const char* e = getenv("LOCGPU_DEEP_GRID"); return e ? atoi(e) : 2048; }();

@@ -9,14 +9,15 @@ namespace locgpu {
 
 struct GnParams;
 
-// Spill records of the search kernel's stragglers (icp_kernels.hip, "straggler hand-over"): entry i of `cap`.
+// Spill records of the search kernel's stragglers (icp_kernels.hip, "straggler hand-over"): `cap` entries; wave g of a launch owns
+// the entries [g·stop_at, (g + 1)·stop_at) and n[g] says how many of them it filled.
 struct SpillBuf {
-    uint4* hdr = nullptr;    // {query index, next slot, avail | slow << 16, c3n}
-    float4* q = nullptr;     // the query
-    uint2* set = nullptr;    // [5][cap] {d_j, id_j}
-    uint2* stack = nullptr;  // [rows][cap] the stack rows below avail
+    uint4* hdr = nullptr;       // {query index, next slot, avail | slow << 16, c3n}
+    float4* q = nullptr;        // the query
+    uint2* set = nullptr;       // [5][cap] {d_j, id_j}
+    uint2* stack = nullptr;     // [rows][cap] the stack rows below avail
+    unsigned int* n = nullptr;  // [waves] stragglers of each wave
     unsigned int cap = 0;
-    unsigned int* count = nullptr;
 };
 
 struct SearchArgs {

@@ -532,12 +532,18 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               hip_ok(ctx, hipMalloc((void**)&b->d_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipMalloc active") &&
               hip_ok(ctx, hipMemset(b->d_counts, 0, std::max(n_scans, 1) * sizeof(int)), "hipMemset counts") &&
               hip_ok(ctx, hipMemset(b->d_redo_count, 0, 4 * sizeof(unsigned int)), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
-    // Spill records of the search kernel's stragglers (launch.hpp SpillBuf): batches of at least 16384 waves of queries; at most
-    // 8 of a wave's 64 lanes are handed over by default (LOCGPU_WALK_STOP), room for 10: 16 + 16 + 40 + 8 x 24 rows = 264 B per
-    // record — 1.2 GB for 256 full scans, of 288 GB
+    // Spill records of the search kernel's stragglers (launch.hpp SpillBuf): batches of at least 16384 waves of queries; every wave
+    // owns room for the lanes it may hand over (LOCGPU_WALK_STOP, default 8): 16 + 16 + 40 + 8 x 24 rows = 264 B per record —
+    // 0.97 GB for 256 full scans, of 288 GB — plus one counter per wave
     if (ok && (size_t)((max_n + 63) / 64) * (size_t)n_scans >= walk_stop_min_waves()) {
-        b->spill_cap = (unsigned int)std::min<size_t>(b->pitch / 64 * 10 + 1024, 0x7FFFFFFFull);
-        ok = hip_ok(ctx, hipMalloc(&b->d_spill, (size_t)b->spill_cap * kSpillRecordBytes), "hipMalloc spill records");
+        static const int stop_env = [] { const char* e = getenv("LOCGPU_WALK_STOP"); return e ? atoi(e) : 8; }();
+        const size_t waves = (size_t)((max_n + 63) / 64) * (size_t)n_scans;
+        const size_t cap = waves * (size_t)std::min(std::max(stop_env, 8), 31);
+        if (cap < 0x7FFFFFFFull) {
+            b->spill_cap = (unsigned int)cap;
+            b->spill_waves = waves;
+            ok = hip_ok(ctx, hipMalloc(&b->d_spill, cap * kSpillRecordBytes + waves * sizeof(unsigned int)), "hipMalloc spill records");
+        }
     }
     // plane cache of the P2Plane fit kernel (opt-in, LOCGPU_PLANE_CACHE=1): only for batches that can ever run the 64-lane search kernel
     // (more than 2048 waves of queries); 32 B per point — 0.94 GB for 256 full scans
@@ -737,8 +743,8 @@ bool IterLauncher::launch(int do_update) {
             sa.spill.q = (float4*)(base + cap * 16);
             sa.spill.set = (uint2*)(base + cap * 32);
             sa.spill.stack = (uint2*)(base + cap * 72);
+            sa.spill.n = (unsigned int*)(base + cap * kSpillRecordBytes);
             sa.spill.cap = b->spill_cap;
-            sa.spill.count = b->d_redo_count + 2;
         }
         if (sa.visit_totals && !capturing) {  // instrumented pass: which tree slots does this launch read at all? (bench.py: compulsory bytes)
             const size_t words = (ctx->tree_slots + 2 + 31) / 32;
