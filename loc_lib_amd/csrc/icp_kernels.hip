@@ -184,7 +184,7 @@ __device__ __forceinline__ bool walk_exact_in_wave(const uint2* __restrict__ tre
     return true;
 }
 
-// ---- straggler hand-over (round 4). A wave of the walk kernel stops once at most `stop_at` of its lanes still have work; those lanes
+// ---- straggler hand-over (round 4; OPT-IN, LOCGPU_WALK_STOP=8 — see walk_stop_lanes() for why it is off). A wave of the walk kernel stops once at most `stop_at` of its lanes still have work; those lanes
 // write what the traversal needs to go on — query, result set, position, flags and the live rows of their LDS stack — to a spill
 // record, and icp_search_walk_cont_kernel continues them, 64 to a wave. Same traversal, same order, same results; the rounds a wave
 // pays for its last few lanes are paid by full waves instead (paid rounds −20 % by simulation on per-query round counts of the bench
@@ -1176,7 +1176,7 @@ static bool launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
         const int n_launch = a.active ? a.n_active : a.n_scans;
         dim3 g2((a.max_n + 63) / 64, n_launch);
-        static const int stop_env_s = [] { const char* e = getenv("LOCGPU_WALK_STOP"); return e ? atoi(e) : 8; }();
+        static const int stop_env_s = walk_stop_lanes();
         const int stop_at_s = (stop_env_s > 0 && stop_env_s < 32 && a.spill.hdr != nullptr && (size_t)g2.x * g2.y >= walk_stop_min_waves() &&
                                (size_t)g2.x * g2.y * stop_env_s <= a.spill.cap) ? stop_env_s : 0;  // as the shipped launch below
         hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, 12, 64, true>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
@@ -1215,7 +1215,7 @@ static bool launch_fast_kd(const SearchArgs& a, hipStream_t s) {
         const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
         dim3 g2((a.max_n + 63) / 64, n_launch);
         // straggler hand-over (SpillBuf): only where the launch is long enough for one more kernel behind it to pay
-        static const int stop_env = [] { const char* e = getenv("LOCGPU_WALK_STOP"); return e ? atoi(e) : 8; }();  // lanes left when a wave stops; 0 = off
+        static const int stop_env = walk_stop_lanes();  // lanes left when a wave stops; 0 = off (the default)
         const bool hand_over = mode == 12 && stop_env > 0 && stop_env < 32 && a.spill.hdr != nullptr && (size_t)g2.x * g2.y >= walk_stop_min_waves() &&
                                (size_t)g2.x * g2.y * stop_env <= a.spill.cap;
         const int stop_at = hand_over ? stop_env : 0;
@@ -1312,6 +1312,15 @@ bool launch_icp_search_list(const SearchArgs& a, const uint32_t* list, const uns
     if (a.k == 1) return launch_fast_list_k<1>(a, list, n_list, s);
     if (a.k == 5) return launch_fast_list_k<5>(a, list, n_list, s);
     return false;
+}
+
+// LOCGPU_WALK_STOP = lanes a wave of the 64-lane search kernel leaves to the continuation kernel (straggler hand-over, see SpillBuf).
+// DEFAULT 0 = off: built for round 4 and measured a net LOSS on the bench workload — the walk kernel gains nothing (14.3 vs 14.5 ms
+// per 256-scan step at 8 lanes: what the saved rounds are worth, the spill costs) and the continuation adds 1.9 ms
+// (profiles/experiments.md). Kept opt-in with its parity tests so that the measurement can be repeated.
+int walk_stop_lanes() {
+    static const int v = [] { const char* e = getenv("LOCGPU_WALK_STOP"); const int x = e ? atoi(e) : 0; return (x > 0 && x < 32) ? x : 0; }();
+    return v;
 }
 
 // Waves of queries from which a search launch hands its stragglers over to the continuation kernel (one more launch must pay for

@@ -76,6 +76,7 @@ struct AccumArgs {
 bool launch_icp_search(const SearchArgs& a, hipStream_t s);
 // true iff launch_icp_search(a) runs the kernel that fills a.same_mask (the plane cache of the fit kernel is usable behind it)
 bool icp_search_writes_same_mask(const SearchArgs& a);
+int walk_stop_lanes();         // LOCGPU_WALK_STOP: lanes a wave hands over to the continuation kernel; 0 (default) = no hand-over
 size_t walk_stop_min_waves();  // search launches of at least this many waves hand their stragglers over (LOCGPU_WALK_STOP_MIN_WAVES)
 int plane_cache_mode();  // LOCGPU_PLANE_CACHE: 0 off, 1 on (default), 2 / 3 timing experiments (icp_kernels.hip)
 // exact tree traversal over a.redo_list only (the list is filled by a preceding fast / grid kernel)

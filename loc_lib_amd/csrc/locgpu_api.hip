@@ -532,13 +532,12 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               hip_ok(ctx, hipMalloc((void**)&b->d_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipMalloc active") &&
               hip_ok(ctx, hipMemset(b->d_counts, 0, std::max(n_scans, 1) * sizeof(int)), "hipMemset counts") &&
               hip_ok(ctx, hipMemset(b->d_redo_count, 0, 4 * sizeof(unsigned int)), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
-    // Spill records of the search kernel's stragglers (launch.hpp SpillBuf): batches of at least 16384 waves of queries; every wave
-    // owns room for the lanes it may hand over (LOCGPU_WALK_STOP, default 8): 16 + 16 + 40 + 8 x 24 rows = 264 B per record —
-    // 0.97 GB for 256 full scans, of 288 GB — plus one counter per wave
-    if (ok && (size_t)((max_n + 63) / 64) * (size_t)n_scans >= walk_stop_min_waves()) {
-        static const int stop_env = [] { const char* e = getenv("LOCGPU_WALK_STOP"); return e ? atoi(e) : 8; }();
+    // Spill records of the search kernel's stragglers (launch.hpp SpillBuf; opt-in with LOCGPU_WALK_STOP): batches of at least 16384
+    // waves of queries; every wave owns room for the lanes it may hand over: 16 + 16 + 40 + 8 x 24 rows = 264 B per record — 0.97 GB
+    // for 256 full scans at 8 lanes — plus one counter per wave
+    if (ok && walk_stop_lanes() > 0 && (size_t)((max_n + 63) / 64) * (size_t)n_scans >= walk_stop_min_waves()) {
         const size_t waves = (size_t)((max_n + 63) / 64) * (size_t)n_scans;
-        const size_t cap = waves * (size_t)std::min(std::max(stop_env, 8), 31);
+        const size_t cap = waves * (size_t)walk_stop_lanes();
         if (cap < 0x7FFFFFFFull) {
             b->spill_cap = (unsigned int)cap;
             b->spill_waves = waves;

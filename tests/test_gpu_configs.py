@@ -445,12 +445,13 @@ def test_search_parity_at_other_stack_depths(rows):
 
 
 # ----------------------------------------------------------------------------------------------- straggler hand-over
-@pytest.mark.parametrize("stop,rows", [("8", "15"), ("24", "15"), ("8", "12")])
+@pytest.mark.parametrize("stop,rows", [("8", "15"), ("24", "12")])
 def test_search_parity_with_the_straggler_handover(stop, rows):
-    """Round 4: a wave of the 64-lane search kernel stops once at most LOCGPU_WALK_STOP of its lanes still have work and hands those
+    """Round 4 (opt-in, LOCGPU_WALK_STOP: built on the evidence of the per-query round counts, measured a net loss on the bench workload and
+    therefore off by default — profiles/experiments.md; these tests keep the measurement repeatable): a wave of the 64-lane search kernel stops once at most LOCGPU_WALK_STOP of its lanes still have work and hands those
     queries — registers and the live rows of their LDS stacks — to a continuation kernel that packs 64 of them to a wave. Same
     traversal, so the index-list / H,B / alignment parity tests must pass unchanged; LOCGPU_WALK_STOP_MIN_WAVES=2049 switches the
-    hand-over on for every launch of the batch kernel (by default only launches of 16384 waves or more use it), 24 lanes makes a
+    hand-over on for every launch of the batch kernel (otherwise only launches of 16384 waves or more use it), 24 lanes makes a
     third of the queries travel, 12 stack rows add the deep pass and the overflow rule on top."""
     import os
     import subprocess
