@@ -3,6 +3,7 @@
 
   filters   resident voxel filter / crop box / NaN removal on a 115 200-pt scan and on the 10 M-pt map, beside the CPU
             oracle's time for the same call (1 thread), with the algorithmic bytes of DESIGN.md §3b
+  inc_ndt   SetIncNdtTargetCloud on resident clouds (35 k and 115 k points), beside the oracle's list + map loop; tables compared bit for bit
   stream    BASELINE.json configs[4]: the Lio loop — per scan upload → removeNaN → voxel filter → ICP against the local map;
             every `--kf-every` scans transform + submap update + target re-ingest — with a per-stage wall-time breakdown
 
@@ -93,6 +94,42 @@ def filters_section(ctx, locref, map_points, reps):
     return out
 
 
+def inc_ndt_section(ctx, locref, reps):
+    """SetIncNdtTargetCloud (ndt_registration.cpp:150-183): a stream of keyframe-sized clouds into ONE incremental voxel map, resident
+    cloud in, per call — 35 k-pt (a voxel-filtered keyframe) and 115 k-pt (a raw scan) clouds, reference-default capacity 100 000 voxels
+    (device path) and a small capacity that makes the LRU evict on every call. CPU = the oracle's list + map loop, same clouds."""
+    out = {}
+    for name, n_pts, cap in (("35k_cap100000", 35000, 100000), ("115k_cap100000", 115200, 100000), ("115k_cap20000_evicting", 115200, 20000)):
+        clouds = []
+        for s in range(reps + 1):
+            c = xyzi(synth.make_scan(s))
+            truth = synth.make_pose(s)[0]
+            w = locref.transform_cloud_f64(truth, c, is_dense=True)  # world frame, like Lio::AddCloud's keyframes
+            clouds.append(np.ascontiguousarray(w[np.linspace(0, len(w) - 1, n_pts).astype(np.int64)]))
+        opts = api.ndt_opts(method=api.INCREMENTAL_NDT, capacity=cap, voxel_size=1.0)
+        dev = [api.Cloud(ctx, c) for c in clouds]
+        ctx.ndt_set_target_cloud(dev[0], opts)  # first call: buffers are grown here
+        t0 = time.perf_counter()
+        for d in dev[1:]:
+            ctx.ndt_set_target_cloud(d, opts)
+        t_gpu = (time.perf_counter() - t0) / reps
+        ref = locref.Ndt(method=api.INCREMENTAL_NDT, capacity=cap, voxel_size=1.0)
+        ref.set_target(clouds[0][:, :3])
+        t0 = time.perf_counter()
+        for c in clouds[1:]:
+            ref.set_target(c[:, :3])
+        t_cpu = (time.perf_counter() - t0) / reps
+        kg, mug, ig = ctx.ndt_dump()
+        ko, muo, io = ref.dump()
+        og, oo = np.lexsort(kg.T[::-1]), np.lexsort(ko.T[::-1])
+        same = bool(kg.shape == ko.shape and np.array_equal(kg[og], ko[oo]) and np.array_equal(mug[og], muo[oo]) and np.array_equal(ig[og].reshape(len(og), -1), np.asarray(io)[oo].reshape(len(oo), -1)))
+        out["inc_ndt_ingest_" + name] = dict(points=n_pts, capacity=cap, voxels=int(ctx.ndt_target_info()["num_voxels"]), calls=reps, gpu_ms=t_gpu * 1e3, cpu_ms=t_cpu * 1e3,
+                                              table_bit_identical_to_oracle=same, mpoints_per_s=n_pts / t_gpu / 1e6)
+        for d in dev:
+            d.close()
+    return out
+
+
 def stream_section(ctx, locref, n_scans, kf_every, num_kfs, scan_leaf, map_leaf, check, async_target=False):
     """Lio::AddCloud (lio.cpp:206-306) with the matcher and the filters on the GPU; poses start from the perturbed truth."""
     opts = api.icp_opts(api.P2PLANE)
@@ -154,7 +191,7 @@ def main():
     ap.add_argument("--scan-leaf", type=float, default=0.5)
     ap.add_argument("--map-leaf", type=float, default=0.5)
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--only", choices=["filters", "stream"])
+    ap.add_argument("--only", choices=["filters", "stream", "inc_ndt"])
     ap.add_argument("--async-target", action="store_true", help="stream section: only with locgpu_icp_set_target_cloud_async (host tree build on a worker thread)")
     ap.add_argument("--blocking-target", action="store_true", help="stream section: only with the blocking locgpu_icp_set_target_cloud")
     ap.add_argument("--graph", action="store_true", help="stream section: replay the captured hipGraph of the Gauss–Newton iterations (BASELINE configs[4])")
@@ -162,9 +199,11 @@ def main():
     from oracle import locref  # timed CPU baseline and checker only
     api.build()
     ctx = api.Context(0)
-    if a.only != "stream":
+    if a.only in (None, "filters"):
         print(json.dumps({"filters": filters_section(ctx, locref, a.map_points, a.reps)}))
-    if a.only != "filters":
+    if a.only in (None, "inc_ndt"):
+        print(json.dumps({"inc_ndt": inc_ndt_section(ctx, locref, a.reps)}))
+    if a.only in (None, "stream"):
         ctx.graph_enable(a.graph)
         # a host-latency-bound loop on a shared box: one untimed pass (it grows the library's buffers and carries the oracle check),
         # then five passes: the MEDIAN is reported and every pass is kept. Twice: with the keyframe's SetInputTarget
