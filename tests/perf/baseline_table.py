@@ -82,10 +82,10 @@ def main():
     rows.append(row_from_bench("3a: vs 10M-pt map, P2Plane (64 scans per step)", run_bench("--scans-per-gpu", "64", "--traffic", "none", *steps)))
     rows.append(row_from_bench("3b: vs 10M-pt map, direct NDT (64 scans per step)", run_bench("--scans-per-gpu", "64", "--method", "ndt", "--traffic", "none", *steps)))
     rows.append(row_from_bench("3c: vs 10M-pt map, P2Plane (32 scans per step: what one of eight ranks holds of configs[3])", run_bench("--scans-per-gpu", "32", "--traffic", "none", *steps)))
-    rows.append(row_from_bench("4: 256 scans vs 10M-pt map, P2Plane, one GPU (the default bench line)", run_bench(*steps)))
+    rows.append(row_from_bench("4: 256 scans vs 10M-pt map, P2Plane, one GPU (the default bench line: three alignments in flight)", run_bench(*steps)))
     fast = ["--no-cpu-baseline", "--traffic", "none"]
-    rows.append(row_from_bench("4p: the same with two alignments in flight (--pipeline 2)", run_bench("--pipeline", "2", *fast, *steps)))
-    rows.append(row_from_bench("4q: the same with three alignments in flight (--pipeline 3)", run_bench("--pipeline", "3", *fast, *steps)))
+    rows.append(row_from_bench("4p: the same with one alignment at a time (--pipeline 1)", run_bench("--pipeline", "1", *fast, *steps)))
+    rows.append(row_from_bench("4q: the same with two alignments in flight (--pipeline 2)", run_bench("--pipeline", "2", *fast, *steps)))
     for n in (256, 64, 32):
         rows.append(row_from_bench("4s: configs[3] as written on ONE rank: %d scans in all, sharded batch, RCCL all-reduce every iteration" % n,
                                    run_bench("--scaling", "strong", "--total-scans", str(n), *fast, "--steps", str(max(10, 640 // n)), "--warmup", "2")))
