@@ -106,7 +106,6 @@ struct locgpu_batch {
     unsigned long long* d_same_mask = nullptr;   // [n_scans][ceil(max_n / 64)]
     bool cache_chain = false;                    // the previous iteration of the running alignment filled the cache
     double* d_partials = nullptr;  // [n_scans][blocks_per_scan][kAccW]
-    int* d_tickets = nullptr;      // [n_scans] fused solve: blocks of a scan that have stored their partial row (zero between launches)
     double* d_hb = nullptr;        // [n_scans][44]
     uint32_t* d_redo_list = nullptr;      // [pitch]
     unsigned int* d_redo_count = nullptr;  // [2]: the two lists' counters

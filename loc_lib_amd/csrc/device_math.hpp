@@ -22,18 +22,6 @@ __device__ __forceinline__ D3 cross3(const D3& a, const D3& b) {
 }
 
 // Per-scan pose state kept in HBM between Gauss–Newton iterations.
-struct GnParams {
-    int method;              // locgpu_icp_method, 3 = direct NDT, 4 = incremental NDT
-    int max_iteration;
-    int min_effective_pts;
-    double eps;
-    double max_nn_distance, max_plane_distance, max_line_distance;
-    bool operator==(const GnParams& o) const {  // field by field: the struct has padding bytes
-        return method == o.method && max_iteration == o.max_iteration && min_effective_pts == o.min_effective_pts && eps == o.eps &&
-               max_nn_distance == o.max_nn_distance && max_plane_distance == o.max_plane_distance && max_line_distance == o.max_line_distance;
-    }
-};
-
 struct PoseState {
     double q[4];   // x y z w  (Sophus::SE3d::data() order)
     double t[3];

@@ -594,151 +594,6 @@ struct RowAccum {
     }
 };
 
-// Sum of the block partials of one scan, per column, in a fixed order (chunk c takes rows c, c + 8, …; the chunks are then added in
-// order). Eight loads are in flight per thread: a single-scan alignment has 450 rows, and a row-by-row load → add chain made this the
-// longest part of the solve kernel. Returns the column total in threads 0..kAccW-1 (0 elsewhere). Ends with the block synchronised.
-__device__ __forceinline__ double reduce_partials(const double* __restrict__ rows, int blocks_per_scan, bool mine, double (*s_sum)[kAccW]) {
-    const int col = threadIdx.x & (kAccW - 1), chunk = threadIdx.x / kAccW;
-    constexpr int kChunks = kBlock / kAccW;
-    double s = 0.0;
-    if (mine && col < 28) {
-        for (int b = chunk; b < blocks_per_scan; b += kChunks * 8) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = b + u * kChunks;
-                v[u] = idx < blocks_per_scan ? rows[(size_t)idx * kAccW + col] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-    }
-    s_sum[chunk][col] = s;
-    __syncthreads();
-    double t = 0.0;
-    if (threadIdx.x < kAccW) {
-        t = s_sum[0][threadIdx.x];
-#pragma unroll
-        for (int c = 1; c < kChunks; ++c) t += s_sum[c][threadIdx.x];
-    }
-    __syncthreads();
-    return t;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K3: one 256-thread block per scan. Sums the block partials in a fixed order, then thread 0 runs the
-// reference's checks and update (icp_registration.cpp:204-211 + 362-375; ndt_registration.cpp:435-459).
-// hb_out (optional): per scan 44 doubles = H (36, row-major), B (6), effective_num, ok.
-// The solve step for ONE scan by one 256-thread block (every thread of the block must call it): the body of gn_solve_kernel, also
-// run by the last block of a fused accumulate launch (solve_if_last_block).
-__device__ __forceinline__ void gn_solve_block(const double* __restrict__ partials, int blocks_per_scan, PoseState* __restrict__ st, int scan, const GnParams& prm,
-                                               int do_update, double* __restrict__ hb_out) {
-    __shared__ double s_sum[kBlock / kAccW][kAccW];
-    __shared__ double s_lu[36 + 6];
-    const double col_total = reduce_partials(partials + (size_t)scan * blocks_per_scan * kAccW, blocks_per_scan, true, s_sum);
-    if (threadIdx.x < kAccW) s_sum[0][threadIdx.x] = col_total;
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    double tot[28];
-    for (int v = 0; v < 28; ++v) tot[v] = s_sum[0][v];
-    double H[36], B[6], dx[6] = {0, 0, 0, 0, 0, 0};
-    int o = 0;
-    for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) { H[6 * i + j] = tot[o]; H[6 * j + i] = tot[o]; ++o; }
-    for (int i = 0; i < 6; ++i) B[i] = tot[21 + i];
-    const long long eff = (long long)tot[27];
-    PoseState& ps = st[scan];
-    bool ok;
-    const double det = lu6_det_solve(H, B, dx, s_lu);  // LU workspace in LDS: its pivoting indexes rows dynamically
-    if (prm.method == 3) {
-        // direct NDT: det(H)==0 is tested FIRST and aborts the whole alignment (ndt cpp:435-436)
-        if (det == 0.0) {
-            ps.status = 1; ps.done = 1; ps.iterations += 1; ps.last_eff = eff;
-            if (hb_out) { for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i]; for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i]; hb_out[44 * scan + 42] = (double)eff; hb_out[44 * scan + 43] = 0.0; }
-            return;
-        }
-        ok = eff >= prm.min_effective_pts;
-    } else if (prm.method == 4) {
-        // incremental NDT: too few accepted residuals ⇒ `result_pose = pose; return false` (ndt cpp:349-353); no det(H) test
-        ok = eff >= prm.min_effective_pts;
-        if (!ok) {
-            ps.status = 2; ps.done = 1; ps.iterations += 1; ps.last_eff = eff;
-            if (hb_out) { for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i]; for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i]; hb_out[44 * scan + 42] = (double)eff; hb_out[44 * scan + 43] = 0.0; }
-            return;
-        }
-    } else {
-        ok = (eff >= prm.min_effective_pts) && !(det == 0.0);
-    }
-    if (hb_out) {
-        for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i];
-        for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i];
-        hb_out[44 * scan + 42] = (double)eff;
-        hb_out[44 * scan + 43] = ok ? 1.0 : 0.0;
-    }
-    ps.last_eff = eff;
-    if (!do_update) return;
-    ps.iterations += 1;
-    if (ok) {
-        if (prm.method == 0)
-            for (int i = 0; i < 6; ++i) dx[i] = dx[i] / 16;  // dx = H.inverse()/16 * err (icp cpp:287)
-        se3_apply_update(ps.q, ps.t, dx);
-        quat_to_R(ps.q, ps.R);
-        double n2 = 0.0;
-        for (int i = 0; i < 6; ++i) n2 += dx[i] * dx[i];
-        const double nrm = sqrt(n2);
-        ps.last_dx_norm = nrm;
-        if (nrm < prm.eps) { ps.converged = 1; ps.done = 1; }
-    }
-    if (ps.iterations >= prm.max_iteration) ps.done = 1;
-}
-
-__global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restrict__ partials, int blocks_per_scan, PoseState* __restrict__ st,
-                                                          GnParams prm, int do_update, double* __restrict__ hb_out, unsigned int* __restrict__ list_counts) {
-    const int scan = blockIdx.x;
-    // The search stage's work-list counters (fast kernel → redo kernel) are consumed by now: zero them for the next iteration's
-    // search instead of paying two fill launches per iteration (a single-scan alignment is launch-latency bound).
-    if (list_counts && scan == 0 && threadIdx.x < 4) list_counts[threadIdx.x] = 0u;
-    if (st[scan].done) return;
-    gn_solve_block(partials, blocks_per_scan, st, scan, prm, do_update, hb_out);
-}
-
-// Fused form (round 4, non-sharded ICP batches): the accumulate kernel's blocks take a ticket per scan once their partial row is
-// stored; the block that draws the last one runs the solve step at once — one dispatch less per Gauss–Newton iteration (≈5 µs of
-// the ≈58 µs a single-scan iteration takes). Same reduction, same order, same bits as gn_solve_kernel. Release / acquire at agent
-// scope around the ticket (MI355X_MICROARCH.md, inter-workgroup visibility): the rows come from other CUs and other XCDs.
-struct FusedSolve {
-    int* tickets;               // [n_scans], zero between launches (the last block puts its scan's ticket back)
-    PoseState* st;              // the same array the kernel reads as `st`
-    GnParams prm;
-    int do_update;
-    double* hb_out;
-    unsigned int* list_counts;  // the search stage's work-list counters: zeroed here (they are consumed by now)
-};
-__device__ __forceinline__ void fused_prologue(const FusedSolve& f) {
-    if (f.tickets && f.list_counts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) f.list_counts[threadIdx.x] = 0u;
-}
-// Every thread of the block calls it after the block's partial row has been stored (by threads < 28 of this very block).
-__device__ __forceinline__ void solve_if_last_block(const FusedSolve& f, const double* __restrict__ partials, int scan) {
-    if (!f.tickets) return;
-    __shared__ int s_last;
-    __syncthreads();  // the row's stores have been issued by their threads
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int t = __hip_atomic_fetch_add(&f.tickets[scan], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == (int)gridDim.x - 1 ? 1 : 0;
-        if (s_last) {
-            __hip_atomic_store(&f.tickets[scan], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-    __syncthreads();
-    if (!s_last) return;
-    gn_solve_block(partials, (int)gridDim.x, f.st, scan, f.prm, f.do_update, f.hb_out);
-}
-
-
 // R·hat(q), coefficient order of the oracle's left-to-right 3×3 product (zeros of hat() drop out exactly).
 __device__ __forceinline__ void R_hat(const double* R, const D3& q, double (&Rh)[3][3]) {
 #pragma unroll
@@ -755,10 +610,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                  double max_plane_distance, double* __restrict__ partials, int kPlanePts,
-                                                                 const int* __restrict__ active, FusedSolve fs) {
+                                                                 const int* __restrict__ active) {
     __shared__ double s_row[8][kAccPad];
     __shared__ double s_slice[kBlock / 32][32];
-    fused_prologue(fs);
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;  // uniform per block
     const int tid = threadIdx.x;
@@ -812,7 +666,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         ra.add<1>(s_row, J, neg_e, fitted);
     }
     ra.store(s_slice, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
-    solve_if_last_block(fs, partials, scan);
 }
 
 // K2 with the PLANE CACHE (round 4; OPT-IN with LOCGPU_PLANE_CACHE=1 — built, bit-identical, and a net LOSS on the
@@ -837,13 +690,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                  double max_plane_distance, double* __restrict__ partials, int kPlanePts,
                                                                  const int* __restrict__ active, double* __restrict__ plane_cache,
-                                                                 const unsigned long long* __restrict__ same_mask, int use_cache, FusedSolve fs) {
+                                                                 const unsigned long long* __restrict__ same_mask, int use_cache) {
     __shared__ double s_row[8][kAccPad];
     __shared__ double s_slice[kBlock / 32][32];
     __shared__ double s_n4[kPlaneCachePts * kBlock][4];  // the vectors fitted by this block, by point (a refit point is read back from here, not from HBM)
     __shared__ unsigned short s_todo[kPlaneCachePts * kBlock];
     __shared__ int s_ntodo;
-    fused_prologue(fs);
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;  // uniform per block
     const int tid = threadIdx.x;
@@ -944,7 +796,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         ra.add<1>(s_row, J, neg_e, fitted);
     }
     ra.store(s_slice, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
-    solve_if_last_block(fs, partials, scan);
 }
 
 // K2', P2P: CaculateMatrixHAndBP2P (icp_registration.cpp:57-103), including the /16 on the rotation block.
@@ -952,8 +803,7 @@ __global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                  double max_nn_distance, double* __restrict__ partials, int pts,
-                                                                 const int* __restrict__ active, FusedSolve fs) {
-    fused_prologue(fs);
+                                                                 const int* __restrict__ active) {
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;
     double acc[28];
@@ -987,7 +837,6 @@ __global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __
     }
     }
     block_reduce_store<28>(acc, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
-    solve_if_last_block(fs, partials, scan);
 }
 
 // K2', P2Line: CaculateMatrixHAndBP2Line (icp_registration.cpp:105-159) + math::FitLine (math_utils.h:138-163).
@@ -995,10 +844,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                                                                 const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                 const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                 double max_line_distance, double* __restrict__ partials, int pts,
-                                                                const int* __restrict__ active, FusedSolve fs) {
+                                                                const int* __restrict__ active) {
     __shared__ double s_row[8][kAccPad];
     __shared__ double s_slice[kBlock / 32][32];
-    fused_prologue(fs);
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;
     RowAccum ra;
@@ -1076,7 +924,107 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
     ra.add<3>(s_row, J, neg_e, fitted);
     }
     ra.store(s_slice, partials + ((size_t)scan * gridDim.x + blockIdx.x) * kAccW);
-    solve_if_last_block(fs, partials, scan);
+}
+
+// Sum of the block partials of one scan, per column, in a fixed order (chunk c takes rows c, c + 8, …; the chunks are then added in
+// order). Eight loads are in flight per thread: a single-scan alignment has 450 rows, and a row-by-row load → add chain made this the
+// longest part of the solve kernel. Returns the column total in threads 0..kAccW-1 (0 elsewhere). Ends with the block synchronised.
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ rows, int blocks_per_scan, bool mine, double (*s_sum)[kAccW]) {
+    const int col = threadIdx.x & (kAccW - 1), chunk = threadIdx.x / kAccW;
+    constexpr int kChunks = kBlock / kAccW;
+    double s = 0.0;
+    if (mine && col < 28) {
+        for (int b = chunk; b < blocks_per_scan; b += kChunks * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = b + u * kChunks;
+                v[u] = idx < blocks_per_scan ? rows[(size_t)idx * kAccW + col] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    }
+    s_sum[chunk][col] = s;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x < kAccW) {
+        t = s_sum[0][threadIdx.x];
+#pragma unroll
+        for (int c = 1; c < kChunks; ++c) t += s_sum[c][threadIdx.x];
+    }
+    __syncthreads();
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: one 256-thread block per scan. Sums the block partials in a fixed order, then thread 0 runs the
+// reference's checks and update (icp_registration.cpp:204-211 + 362-375; ndt_registration.cpp:435-459).
+// hb_out (optional): per scan 44 doubles = H (36, row-major), B (6), effective_num, ok.
+__global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restrict__ partials, int blocks_per_scan, PoseState* __restrict__ st,
+                                                          GnParams prm, int do_update, double* __restrict__ hb_out, unsigned int* __restrict__ list_counts) {
+    __shared__ double s_sum[kBlock / kAccW][kAccW];
+    __shared__ double s_lu[36 + 6];
+    const int scan = blockIdx.x;
+    // The search stage's work-list counters (fast kernel → redo kernel) are consumed by now: zero them for the next iteration's
+    // search instead of paying two fill launches per iteration (a single-scan alignment is launch-latency bound).
+    if (list_counts && scan == 0 && threadIdx.x < 4) list_counts[threadIdx.x] = 0u;
+    if (st[scan].done) return;
+    const double col_total = reduce_partials(partials + (size_t)scan * blocks_per_scan * kAccW, blocks_per_scan, true, s_sum);
+    if (threadIdx.x < kAccW) s_sum[0][threadIdx.x] = col_total;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double tot[28];
+    for (int v = 0; v < 28; ++v) tot[v] = s_sum[0][v];
+    double H[36], B[6], dx[6] = {0, 0, 0, 0, 0, 0};
+    int o = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { H[6 * i + j] = tot[o]; H[6 * j + i] = tot[o]; ++o; }
+    for (int i = 0; i < 6; ++i) B[i] = tot[21 + i];
+    const long long eff = (long long)tot[27];
+    PoseState& ps = st[scan];
+    bool ok;
+    const double det = lu6_det_solve(H, B, dx, s_lu);  // LU workspace in LDS: its pivoting indexes rows dynamically
+    if (prm.method == 3) {
+        // direct NDT: det(H)==0 is tested FIRST and aborts the whole alignment (ndt cpp:435-436)
+        if (det == 0.0) {
+            ps.status = 1; ps.done = 1; ps.iterations += 1; ps.last_eff = eff;
+            if (hb_out) { for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i]; for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i]; hb_out[44 * scan + 42] = (double)eff; hb_out[44 * scan + 43] = 0.0; }
+            return;
+        }
+        ok = eff >= prm.min_effective_pts;
+    } else if (prm.method == 4) {
+        // incremental NDT: too few accepted residuals ⇒ `result_pose = pose; return false` (ndt cpp:349-353); no det(H) test
+        ok = eff >= prm.min_effective_pts;
+        if (!ok) {
+            ps.status = 2; ps.done = 1; ps.iterations += 1; ps.last_eff = eff;
+            if (hb_out) { for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i]; for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i]; hb_out[44 * scan + 42] = (double)eff; hb_out[44 * scan + 43] = 0.0; }
+            return;
+        }
+    } else {
+        ok = (eff >= prm.min_effective_pts) && !(det == 0.0);
+    }
+    if (hb_out) {
+        for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i];
+        for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i];
+        hb_out[44 * scan + 42] = (double)eff;
+        hb_out[44 * scan + 43] = ok ? 1.0 : 0.0;
+    }
+    ps.last_eff = eff;
+    if (!do_update) return;
+    ps.iterations += 1;
+    if (ok) {
+        if (prm.method == 0)
+            for (int i = 0; i < 6; ++i) dx[i] = dx[i] / 16;  // dx = H.inverse()/16 * err (icp cpp:287)
+        se3_apply_update(ps.q, ps.t, dx);
+        quat_to_R(ps.q, ps.R);
+        double n2 = 0.0;
+        for (int i = 0; i < 6; ++i) n2 += dx[i] * dx[i];
+        const double nrm = sqrt(n2);
+        ps.last_dx_norm = nrm;
+        if (nrm < prm.eps) { ps.converged = 1; ps.done = 1; }
+    }
+    if (ps.iterations >= prm.max_iteration) ps.done = 1;
 }
 
 // First half of gn_solve_kernel for sharded batches (see launch.hpp): one block per GLOBAL scan.
@@ -1443,16 +1391,15 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
     if (pts > 8) pts = 8;
     if (method == 2 && a.plane_cache && a.same_mask) pts = kPlaneCachePts;
     const dim3 grid((blocks + pts - 1) / pts, a.active ? a.n_active : a.n_scans);
-    const FusedSolve fs{a.tickets, a.st_solve, a.prm, a.do_update, a.hb_out, a.list_counts};  // tickets == nullptr: the solve step is a launch of its own
     if (method == 2 && a.plane_cache && a.same_mask)
         hipLaunchKernelGGL(icp_plane_cached_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active,
-                           a.plane_cache, a.same_mask, a.use_cache, fs);
+                           a.plane_cache, a.same_mask, a.use_cache);
     else if (method == 2)
-        hipLaunchKernelGGL(icp_plane_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active, fs);
+        hipLaunchKernelGGL(icp_plane_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
     else if (method == 1)
-        hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active, fs);
+        hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
     else
-        hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active, fs);
+        hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
     return (int)grid.x;
 }
 

@@ -25,6 +25,17 @@ constexpr int kAccW = 32;          // doubles per block partial: 21 H (upper) + 
 constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
 constexpr int kSearchStatSlots = 16 + 2 * 64;  // [0..15] counters, then two 64-bin histograms of the LOCGPU_STAMP diagnostic build
 
+struct GnParams {
+    int method;              // locgpu_icp_method, 3 = direct NDT, 4 = incremental NDT
+    int max_iteration;
+    int min_effective_pts;
+    double eps;
+    double max_nn_distance, max_plane_distance, max_line_distance;
+    bool operator==(const GnParams& o) const {  // field by field: the struct has padding bytes
+        return method == o.method && max_iteration == o.max_iteration && min_effective_pts == o.min_effective_pts && eps == o.eps &&
+               max_nn_distance == o.max_nn_distance && max_plane_distance == o.max_plane_distance && max_line_distance == o.max_line_distance;
+    }
+};
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __uint_as_float(u); }
 

@@ -7,6 +7,8 @@
 
 namespace locgpu {
 
+struct GnParams;
+
 // Spill records of the search kernel's stragglers (icp_kernels.hip, "straggler hand-over"): `cap` entries; wave g of a launch owns
 // the entries [g·stop_at, (g + 1)·stop_at) and n[g] says how many of them it filled.
 struct SpillBuf {
@@ -69,14 +71,6 @@ struct AccumArgs {
     double* plane_cache = nullptr;
     const unsigned long long* same_mask = nullptr;
     int use_cache = 0;
-    // Fused solve (non-sharded batches): the block that stores a scan's last partial row runs the solve step at once instead of a
-    // gn_solve launch behind the kernel (icp_kernels.hip, solve_if_last_block). tickets == nullptr: not fused.
-    int* tickets = nullptr;         // [n_scans], zero between launches
-    PoseState* st_solve = nullptr;  // = st, writable
-    GnParams prm{};
-    int do_update = 0;
-    double* hb_out = nullptr;
-    unsigned int* list_counts = nullptr;
 };
 
 bool launch_icp_search(const SearchArgs& a, hipStream_t s);

@@ -68,10 +68,6 @@ std::string g_create_err;
 // `done` flag), so running ahead costs ≈2 µs per empty launch while a host round trip costs tens of µs: the first chunk covers the
 // typical alignment (7-8 iterations with the reference's eps), later ones are shorter.
 constexpr int kFirstChunk = 8, kNextChunk = 4;
-// A one-scan alignment follows its first chunk with chunks of two: there a chunk boundary (read-back, host, relaunch ≈ 35 µs) costs
-// about what two idle iterations do (3 dispatches of ≈4.6 µs each), and nine iterations — the common case beyond eight — then pay
-// 35 + 15 µs instead of 35 + 45 (tools/single_scan_trace.py).
-inline int next_chunk(const locgpu_batch* b) { return b->n_total == 1 ? 2 : kNextChunk; }
 }  // namespace
 
 namespace locgpu {
@@ -120,7 +116,6 @@ static void free_batch(locgpu_batch* b) {
     if (b->d_plane_cache) (void)hipFree(b->d_plane_cache);
     if (b->d_same_mask) (void)hipFree(b->d_same_mask);
     if (b->d_partials) (void)hipFree(b->d_partials);
-    if (b->d_tickets) (void)hipFree(b->d_tickets);
     if (b->d_hb) (void)hipFree(b->d_hb);
     if (b->d_acc) (void)hipFree(b->d_acc);
     if (b->d_redo_list) (void)hipFree(b->d_redo_list);
@@ -535,8 +530,6 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_total * 44 * sizeof(double)), "hipHostMalloc hb") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipHostMalloc active") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipMalloc active") &&
-              hip_ok(ctx, hipMalloc((void**)&b->d_tickets, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipMalloc tickets") &&
-              hip_ok(ctx, hipMemset(b->d_tickets, 0, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipMemset tickets") &&
               hip_ok(ctx, hipMemset(b->d_counts, 0, std::max(n_scans, 1) * sizeof(int)), "hipMemset counts") &&
               hip_ok(ctx, hipMemset(b->d_redo_count, 0, 4 * sizeof(unsigned int)), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
     // Spill records of the search kernel's stragglers (launch.hpp SpillBuf; opt-in with LOCGPU_WALK_STOP): batches of at least 16384
@@ -729,7 +722,6 @@ bool IterLauncher::launch(int do_update) {
     };
     mark(true);
     int n_partial_blocks = b->blocks_per_scan;
-    bool fused = false;  // the accumulate kernel's last block ran the solve step (launch.hpp AccumArgs::tickets)
     PoseState* st_local = b->d_state + b->first;  // kernels index the scans this rank holds: 0..n_scans-1
     if (b->n_scans == 0) {
         mark(true);  // nothing local: this rank only takes part in the exchange below
@@ -781,9 +773,6 @@ bool IterLauncher::launch(int do_update) {
         if (cached && plane_cache_mode() != 3) { aa.plane_cache = b->d_plane_cache; aa.same_mask = b->d_same_mask; aa.use_cache = plane_cache_mode() == 2 ? 0 : sa.have_previous; }
         b->cache_chain = cached;
         iter++;
-        static const bool fuse_env = [] { const char* e = getenv("LOCGPU_FUSED_SOLVE"); return !e || atoi(e) != 0; }();  // 0: the solve step as its own launch (A/B)
-        fused = fuse_env && !b->sharded;
-        if (fused) { aa.tickets = b->d_tickets; aa.st_solve = st_local; aa.prm = prm; aa.do_update = do_update; aa.hb_out = b->d_hb; aa.list_counts = b->d_redo_count; }
         n_partial_blocks = launch_icp_accum(prm.method, aa, s);
     } else {
         mark(true);  // NDT has no separate search kernel: search slot stays empty
@@ -842,7 +831,7 @@ bool IterLauncher::launch(int do_update) {
             if (!direct && (!hip_ok(ctx, hipEventRecord(b->ev_reduced, cs), "sharded: hipEventRecord") || !hip_ok(ctx, hipStreamWaitEvent(s, b->ev_reduced, 0), "sharded: hipStreamWaitEvent"))) return false;
         }
         launch_gn_solve(acc, 1, b->d_state, b->n_total, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s);
-    } else if (!fused) {
+    } else {
         launch_gn_solve(b->d_partials, n_partial_blocks, b->d_state, b->n_scans, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s);
     }
     mark();
@@ -932,7 +921,7 @@ static int ensure_graphs(locgpu_ctx* ctx, locgpu_batch* b, const GnParams& prm, 
     if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
     if (b->graph_exec_next) { (void)hipGraphExecDestroy(b->graph_exec_next); b->graph_exec_next = nullptr; }
     int rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, first, true, &b->graph_exec);
-    if (rc == LOCGPU_OK && prm.max_iteration > first) rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, next_chunk(b), false, &b->graph_exec_next);
+    if (rc == LOCGPU_OK && prm.max_iteration > first) rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, kNextChunk, false, &b->graph_exec_next);
     if (rc != LOCGPU_OK) return rc;
     b->graph_prm = prm; b->graph_k = k; b->graph_alpha = alpha_eff; b->graph_ndt = ndt; b->graph_target = target;
     b->graph_epoch = ctx->target_epoch;
@@ -946,7 +935,7 @@ static int enqueue_chunk(locgpu_ctx* ctx, locgpu_batch* b, bool first_chunk) {
     if (P.graph) {
         // kernels of a finished scan return at once and the solve kernel stops at max_iteration, so a whole chunk is always safe
         LOCGPU_HIP(ctx, hipGraphLaunch(first_chunk ? b->graph_exec : b->graph_exec_next, s));
-        P.launched += first_chunk ? std::min(kFirstChunk, P.prm.max_iteration) : next_chunk(b);
+        P.launched += first_chunk ? std::min(kFirstChunk, P.prm.max_iteration) : kNextChunk;
         return LOCGPU_OK;
     }
     if (first_chunk) LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, s));
@@ -969,7 +958,7 @@ static int enqueue_chunk(locgpu_ctx* ctx, locgpu_batch* b, bool first_chunk) {
             it.n_active = na;
         }
     }
-    const int todo = std::min(first_chunk ? kFirstChunk : next_chunk(b), P.prm.max_iteration - P.launched);
+    const int todo = std::min(first_chunk ? kFirstChunk : kNextChunk, P.prm.max_iteration - P.launched);
     for (int c = 0; c < todo; ++c)
         if (!it.launch(1)) return LOCGPU_ERR_NO_DEVICE;
     P.ev_used = it.ev_used;
