@@ -68,6 +68,10 @@ std::string g_create_err;
 // `done` flag), so running ahead costs ≈2 µs per empty launch while a host round trip costs tens of µs: the first chunk covers the
 // typical alignment (7-8 iterations with the reference's eps), later ones are shorter.
 constexpr int kFirstChunk = 8, kNextChunk = 4;
+// A one-scan alignment follows its first chunk with chunks of two: there a chunk boundary (read-back, host, relaunch ≈ 35 µs) costs
+// about what two idle iterations do (3 dispatches of ≈4.6 µs each), and nine iterations — the common case beyond eight — then pay
+// 35 + 15 µs instead of 35 + 45 (tools/single_scan_trace.py).
+inline int next_chunk(const locgpu_batch* b) { return b->n_total == 1 ? 2 : kNextChunk; }
 }  // namespace
 
 namespace locgpu {
@@ -921,7 +925,7 @@ static int ensure_graphs(locgpu_ctx* ctx, locgpu_batch* b, const GnParams& prm, 
     if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
     if (b->graph_exec_next) { (void)hipGraphExecDestroy(b->graph_exec_next); b->graph_exec_next = nullptr; }
     int rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, first, true, &b->graph_exec);
-    if (rc == LOCGPU_OK && prm.max_iteration > first) rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, kNextChunk, false, &b->graph_exec_next);
+    if (rc == LOCGPU_OK && prm.max_iteration > first) rc = capture_chunk(ctx, b, prm, k, alpha_eff, ndt, next_chunk(b), false, &b->graph_exec_next);
     if (rc != LOCGPU_OK) return rc;
     b->graph_prm = prm; b->graph_k = k; b->graph_alpha = alpha_eff; b->graph_ndt = ndt; b->graph_target = target;
     b->graph_epoch = ctx->target_epoch;
@@ -935,7 +939,7 @@ static int enqueue_chunk(locgpu_ctx* ctx, locgpu_batch* b, bool first_chunk) {
     if (P.graph) {
         // kernels of a finished scan return at once and the solve kernel stops at max_iteration, so a whole chunk is always safe
         LOCGPU_HIP(ctx, hipGraphLaunch(first_chunk ? b->graph_exec : b->graph_exec_next, s));
-        P.launched += first_chunk ? std::min(kFirstChunk, P.prm.max_iteration) : kNextChunk;
+        P.launched += first_chunk ? std::min(kFirstChunk, P.prm.max_iteration) : next_chunk(b);
         return LOCGPU_OK;
     }
     if (first_chunk) LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, s));
@@ -958,7 +962,7 @@ static int enqueue_chunk(locgpu_ctx* ctx, locgpu_batch* b, bool first_chunk) {
             it.n_active = na;
         }
     }
-    const int todo = std::min(first_chunk ? kFirstChunk : kNextChunk, P.prm.max_iteration - P.launched);
+    const int todo = std::min(first_chunk ? kFirstChunk : next_chunk(b), P.prm.max_iteration - P.launched);
     for (int c = 0; c < todo; ++c)
         if (!it.launch(1)) return LOCGPU_ERR_NO_DEVICE;
     P.ev_used = it.ev_used;
