@@ -260,6 +260,12 @@ LOCGPU_API int locgpu_debug_batch_nn(locgpu_ctx* ctx, locgpu_batch* batch, int k
  * removeNaN: survivors in input order). VoxelGrid's float32 centroid sums run in input order (PCL's order inside a voxel is
  * whatever its unstable std::sort leaves, so the last bits of a centroid are not defined by PCL itself).
  * `intensity_offset` = byte offset of the float32 intensity inside a point (pcl::PointXYZI: 16), or LOCGPU_NO_INTENSITY.
+ *
+ * Two contexts on one GPU as a two-stage front-end (round 4): the calls of one context are strictly sequential (one caller thread,
+ * like the reference's matcher), but a cloud of context A may be the SOURCE of locgpu_icp_align_cloud / locgpu_ndt_align_cloud and
+ * the scan of locgpu_submap_add_keyframe on context B of the same GPU (B's stream is ordered behind what A has enqueued; A must
+ * not modify the cloud while B uses it). A caller thread that uploads and filters scan i+1 on A while another matches scan i on B
+ * overlaps the two stages — the poses are the sequential loop's, bit for bit (tests/test_gpu_filters.py, pipelined streaming loop).
  * ===================================================================================================================== */
 typedef struct locgpu_cloud locgpu_cloud;
 typedef struct locgpu_submap locgpu_submap;

@@ -261,8 +261,9 @@ void locgpu_submap_destroy(locgpu_submap* m) {
 int locgpu_submap_add_keyframe(locgpu_submap* m, const locgpu_cloud* scan, const double pose[7]) {
     if (!m) return LOCGPU_ERR_INVALID;
     locgpu_ctx* ctx = m->ctx;
-    if (!scan || scan->ctx != ctx) return fail(ctx, LOCGPU_ERR_INVALID, "submap_add_keyframe: bad cloud");
+    if (!scan || !scan->ctx) return fail(ctx, LOCGPU_ERR_INVALID, "submap_add_keyframe: bad cloud");
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    if (cloud_input_ready(ctx, scan) != hipSuccess) return fail(ctx, LOCGPU_ERR_INVALID, "submap_add_keyframe: the cloud belongs to a context on another GPU");
     // key_frame_scan = transformPointCloud(scan, pose.matrix())   lio.cpp:278-279
     locgpu_cloud* kf = new_cloud(ctx);
     hipError_t e;

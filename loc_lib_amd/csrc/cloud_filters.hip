@@ -396,6 +396,15 @@ hipError_t cloud_reserve(locgpu_cloud* c, size_t n, bool keep) {
     return hipSuccess;
 }
 
+hipError_t cloud_input_ready(locgpu_ctx* ctx, const locgpu_cloud* c) {
+    if (!c || !c->ctx) return hipErrorInvalidValue;
+    if (c->ctx == ctx) return hipSuccess;
+    if (c->ctx->device != ctx->device) return hipErrorInvalidValue;
+    if (!ctx->foreign_ev) LOCGPU_TRY(hipEventCreateWithFlags(&ctx->foreign_ev, hipEventDisableTiming));
+    LOCGPU_TRY(hipEventRecord(ctx->foreign_ev, c->ctx->stream));
+    return hipStreamWaitEvent(ctx->stream, ctx->foreign_ev, 0);
+}
+
 hipError_t cloud_stage(locgpu_ctx* ctx, size_t n, float4** out) {
     FilterScratch* S = scratch(ctx);
     if (S->stage_busy) {  // an upload returned with its copy still in flight (cloud_stage_release)

@@ -46,6 +46,11 @@ struct FilterScratch {
     size_t stage_cap = 0;
 };
 
+// A cloud as a READ-ONLY input of context `ctx` (matcher source, keyframe, target): its own context's clouds need nothing (one
+// stream); a cloud of ANOTHER context on the same GPU is accepted too — a front-end that uploads and filters scan i+1 on one
+// context while another matches scan i — and `ctx`'s stream is then ordered behind everything the owning context has enqueued so
+// far. The caller must not let the owner modify the cloud while it is in use here. Returns hipErrorInvalidValue for another device.
+hipError_t cloud_input_ready(locgpu_ctx* ctx, const locgpu_cloud* c);
 void filters_free(locgpu_ctx* ctx);
 hipError_t cloud_reserve(locgpu_cloud* c, size_t n, bool keep);
 hipError_t cloud_stage(locgpu_ctx* ctx, size_t n, float4** out);

@@ -27,6 +27,7 @@ struct locgpu_ctx {
     hipStream_t slot_stream[kSlots] = {};
     int next_slot = 0;
     hipStream_t copy_stream = nullptr;  // host → HBM copies of the batch uploader
+    hipEvent_t foreign_ev = nullptr;    // ordering behind another context's stream when one of ITS clouds is an input here (cloud_input_ready)
     hipStream_t comm_stream = nullptr;  // every collective of the context, in host order (one communicator, one stream: no two at once)
     locgpu::Uploader* up = nullptr;     // host → HBM staging shared by the context's batches (batch_upload.hpp)
     locgpu::PendingTarget* pending_target = nullptr;  // locgpu_icp_set_target_cloud_async: a host tree build still running (locgpu_api.hip)

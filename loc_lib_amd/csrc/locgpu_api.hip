@@ -221,6 +221,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     if (ctx->comm) { (void)rccl().CommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->foreign_ev) (void)hipEventDestroy(ctx->foreign_ev);
     if (ctx->d_tree) (void)hipFree(ctx->d_tree);
     if (ctx->d_leaf_slots) (void)hipFree(ctx->d_leaf_slots);
     if (ctx->d_bfnn) (void)hipFree(ctx->d_bfnn);
@@ -1572,7 +1573,8 @@ int locgpu_icp_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const doubl
     float alpha_eff;
     int rc = check_icp(ctx, opts, prm, k, alpha_eff);
     if (rc != LOCGPU_OK) return rc;
-    if (!src || src->ctx != ctx || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "icp_align_cloud: bad arguments");
+    if (!src || !src->ctx || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "icp_align_cloud: bad arguments");
+    if (cloud_input_ready(ctx, src) != hipSuccess) return fail(ctx, LOCGPU_ERR_INVALID, "icp_align_cloud: the cloud belongs to a context on another GPU");
     locgpu_batch* b = nullptr;
     rc = single_batch_dev(ctx, src->d, src->n, &b);
     if (rc != LOCGPU_OK) return rc;
@@ -1583,7 +1585,8 @@ int locgpu_ndt_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const doubl
     GnParams prm{};
     int rc = check_ndt(ctx, prm);
     if (rc != LOCGPU_OK) return rc;
-    if (!src || src->ctx != ctx || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_cloud: bad arguments");
+    if (!src || !src->ctx || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_cloud: bad arguments");
+    if (cloud_input_ready(ctx, src) != hipSuccess) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_cloud: the cloud belongs to a context on another GPU");
     locgpu_batch* b = nullptr;
     rc = single_batch_dev(ctx, src->d, src->n, &b);
     if (rc != LOCGPU_OK) return rc;

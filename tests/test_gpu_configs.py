@@ -120,6 +120,105 @@ def test_streaming_loop_matches_oracle(api, locref, synth, graph, async_target):
         ctx.close()
 
 
+def test_streaming_loop_as_a_two_stage_pipeline(api, locref, synth):
+    """Round 4: the same loop as a two-stage front-end — one thread uploads and filters scan i+1 on context A while the caller matches
+    scan i (and keeps the keyframe map) on context B of the same GPU; A's clouds are read by B (locgpu.h, "Two contexts on one GPU").
+    Every pose equals the sequential loop's bit for bit and the oracle's to 1e-8."""
+    import queue
+    import threading
+    n_scans, kf_every = 9, 3
+
+    def prepared(s):
+        scan = xyzi(synth.make_scan(s))
+        scan[s::997, 1] = np.nan
+        return scan
+
+    def sequential():
+        ctx = api.Context(0)
+        opts = api.icp_opts(api.P2PLANE)
+        sub = api.Submap(ctx, 3, 0.5)
+        raw, filt = api.Cloud(ctx), api.Cloud(ctx)
+        poses = []
+        for s in range(n_scans):
+            truth, init = synth.make_pose(s)
+            raw.upload(prepared(s), is_dense=False)
+            raw.voxel_filter(0.5, out=filt)
+            if s == 0:
+                pose, kf_src = truth, filt
+            else:
+                pose, _ = ctx.icp_align_cloud(filt, init, opts)
+                kf_src = raw
+            if s % kf_every == 0:
+                sub.add_keyframe(kf_src, pose)
+                ctx.icp_set_target_cloud(sub.cloud())
+            poses.append(pose)
+        ctx.close()
+        return np.stack(poses)
+
+    def pipelined():
+        ctx_f, ctx_m = api.Context(0), api.Context(0)
+        opts = api.icp_opts(api.P2PLANE)
+        sub = api.Submap(ctx_m, 3, 0.5)
+        pairs = [(api.Cloud(ctx_f), api.Cloud(ctx_f)) for _ in range(3)]  # the filter stage runs at most two scans ahead
+        free, ready = queue.Queue(), queue.Queue()
+        for p in pairs:
+            free.put(p)
+        errors = []
+
+        def stage_filter():
+            try:
+                for s in range(n_scans):
+                    raw, filt = free.get()
+                    raw.upload(prepared(s), is_dense=False)
+                    raw.voxel_filter(0.5, out=filt)
+                    ready.put((s, raw, filt))
+            except Exception as e:  # surfaced by the consumer
+                errors.append(e)
+                ready.put(None)
+
+        th = threading.Thread(target=stage_filter)
+        th.start()
+        poses = []
+        for _ in range(n_scans):
+            item = ready.get()
+            assert item is not None, errors
+            s, raw, filt = item
+            truth, init = synth.make_pose(s)
+            if s == 0:
+                pose, kf_src = truth, filt
+            else:
+                pose, _ = ctx_m.icp_align_cloud(filt, init, opts)   # a cloud of ctx_f as the source of ctx_m's matcher
+                kf_src = raw
+            if s % kf_every == 0:
+                sub.add_keyframe(kf_src, pose)                       # … and as the keyframe of ctx_m's local map
+                ctx_m.icp_set_target_cloud(sub.cloud())
+            poses.append(pose)
+            free.put((raw, filt))
+        th.join()
+        for raw, filt in pairs:
+            raw.close(); filt.close()
+        ctx_f.close(); ctx_m.close()
+        return np.stack(poses)
+
+    a, b = sequential(), pipelined()
+    assert np.array_equal(a, b)
+    # and the oracle, on the last scan (the whole chain of keyframes feeds it)
+    lm = locref.LocalMap(3, 0.5, order=locref.SORT_STABLE)
+    icp_ref = locref.Icp(method=locref.P2PLANE)
+    for s in range(n_scans):
+        scan = prepared(s)
+        want_filt = locref.voxel_grid(scan, False, 0.5, order=locref.SORT_STABLE)
+        truth, init = synth.make_pose(s)
+        pose = truth if s == 0 else icp_ref.align(want_filt, init)["pose"]
+        if s > 0:
+            dt, dr = pose_delta(a[s], pose)
+            assert dt < 1e-8 and dr < 1e-8, (s, dt, dr)
+        if s % kf_every == 0:
+            src, dense = (want_filt, True) if s == 0 else (scan, False)
+            lm.add_keyframe(locref.transform_cloud_f64(a[s], src, is_dense=dense), is_dense=dense)
+            icp_ref.set_target(lm.cloud()[:, :3])
+
+
 def test_graph_mode_with_grid_search(gpu_ctx, api, small_world):
     """hipGraph capture of the exact grid search (its second work list must exist before the capture starts)."""
     m, s, init = small_world["map"], small_world["scan10k"], small_world["init_pose"]
