@@ -36,6 +36,7 @@ locgpu_cloud* new_cloud(locgpu_ctx* ctx) {
 void free_cloud(locgpu_cloud* c) {
     if (!c) return;
     if (c->d) (void)hipFree(c->d);
+    if (c->ready) (void)hipEventDestroy(c->ready);
     delete c;
 }
 
@@ -137,7 +138,9 @@ int locgpu_cloud_upload(locgpu_cloud* c, const void* pts, size_t n, size_t strid
     if (!c) return LOCGPU_ERR_INVALID;
     if ((n && !pts) || !layout_ok(stride_bytes, intensity_offset)) return fail(c->ctx, LOCGPU_ERR_INVALID, "cloud_upload: bad arguments");
     LOCGPU_HIP(c->ctx, hipSetDevice(c->ctx->device));
-    return upload(c, pts, n, stride_bytes, intensity_offset, is_dense);
+    const int rc = upload(c, pts, n, stride_bytes, intensity_offset, is_dense);
+    if (rc == LOCGPU_OK) (void)cloud_mark_ready(c);
+    return rc;
 }
 
 int locgpu_cloud_info(const locgpu_cloud* c, size_t* n, int* is_dense) {
@@ -165,6 +168,7 @@ int locgpu_cloud_copy(const locgpu_cloud* in, locgpu_cloud* out) {
     if (e != hipSuccess) return hip_fail(ctx, e, "cloud_copy");
     out->n = in->n;
     out->is_dense = in->is_dense;
+    (void)cloud_mark_ready(out);
     return LOCGPU_OK;
 }
 
@@ -173,6 +177,7 @@ int locgpu_cloud_remove_nan(const locgpu_cloud* in, locgpu_cloud* out) {
     if (!same_ctx(in, out)) return fail(in->ctx, LOCGPU_ERR_INVALID, "cloud_remove_nan: clouds of different contexts");
     LOCGPU_HIP(in->ctx, hipSetDevice(in->ctx->device));
     const hipError_t e = remove_nan_dev(in->ctx, in, out);
+    if (e == hipSuccess) (void)cloud_mark_ready(out);
     return e == hipSuccess ? LOCGPU_OK : hip_fail(in->ctx, e, "cloud_remove_nan");
 }
 
@@ -185,6 +190,7 @@ int locgpu_cloud_voxel_filter(const locgpu_cloud* in, float leaf, locgpu_cloud* 
     const hipError_t e = voxel_filter_dev(in->ctx, in, leaf, out, &status);
     if (e != hipSuccess) return hip_fail(in->ctx, e, "cloud_voxel_filter");
     if (passthrough) *passthrough = status == 1 ? 1 : 0;
+    (void)cloud_mark_ready(out);
     return LOCGPU_OK;
 }
 
@@ -193,6 +199,7 @@ int locgpu_cloud_crop_box(const locgpu_cloud* in, const float min_xyz[3], const 
     if (!same_ctx(in, out) || !min_xyz || !max_xyz) return fail(in->ctx, LOCGPU_ERR_INVALID, "cloud_crop_box: bad arguments");
     LOCGPU_HIP(in->ctx, hipSetDevice(in->ctx->device));
     const hipError_t e = crop_box_dev(in->ctx, in, min_xyz, max_xyz, out);
+    if (e == hipSuccess) (void)cloud_mark_ready(out);
     return e == hipSuccess ? LOCGPU_OK : hip_fail(in->ctx, e, "cloud_crop_box");
 }
 
@@ -201,6 +208,7 @@ int locgpu_cloud_transform(const locgpu_cloud* in, const double pose[7], locgpu_
     if (!same_ctx(in, out) || !pose) return fail(in->ctx, LOCGPU_ERR_INVALID, "cloud_transform: bad arguments");
     LOCGPU_HIP(in->ctx, hipSetDevice(in->ctx->device));
     const hipError_t e = transform_dev(in->ctx, in, pose, out);
+    if (e == hipSuccess) (void)cloud_mark_ready(out);
     return e == hipSuccess ? LOCGPU_OK : hip_fail(in->ctx, e, "cloud_transform");
 }
 
@@ -210,6 +218,7 @@ int locgpu_cloud_append(locgpu_cloud* dst, const locgpu_cloud* src) {
     if (dst->n + src->n > 0x7FFFFF00u) return fail(dst->ctx, LOCGPU_ERR_INVALID, "cloud_append: more than 2^31 points");
     LOCGPU_HIP(dst->ctx, hipSetDevice(dst->ctx->device));
     const hipError_t e = append_dev(dst->ctx, dst, src);
+    if (e == hipSuccess) (void)cloud_mark_ready(dst);
     return e == hipSuccess ? LOCGPU_OK : hip_fail(dst->ctx, e, "cloud_append");
 }
 
@@ -332,6 +341,8 @@ int locgpu_cloud_loam_extract(const locgpu_cloud* in, const uint8_t* ring, int n
     const hipError_t e = loam_extract_dev(ctx, in, ring, num_scan, edge, surf, &too_long);
     if (e != hipSuccess) return hip_fail(ctx, e, "cloud_loam_extract");
     if (too_long) return fail(ctx, LOCGPU_ERR_INVALID, "cloud_loam_extract: a ring has more than 6 x 2048 points");
+    (void)cloud_mark_ready(edge);
+    (void)cloud_mark_ready(surf);
     return LOCGPU_OK;
 }
 

@@ -396,10 +396,19 @@ hipError_t cloud_reserve(locgpu_cloud* c, size_t n, bool keep) {
     return hipSuccess;
 }
 
+hipError_t cloud_mark_ready(locgpu_cloud* c) {
+    if (!c || !c->ctx) return hipErrorInvalidValue;
+    if (!c->ready) LOCGPU_TRY(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+    return hipEventRecord(c->ready, c->ctx->stream);
+}
+
 hipError_t cloud_input_ready(locgpu_ctx* ctx, const locgpu_cloud* c) {
     if (!c || !c->ctx) return hipErrorInvalidValue;
     if (c->ctx == ctx) return hipSuccess;
     if (c->ctx->device != ctx->device) return hipErrorInvalidValue;
+    // behind the call that produced the cloud — not behind whatever its owner has enqueued since (a filter stage running a scan
+    // ahead would otherwise hold the matcher back: the two stages would take turns instead of overlapping)
+    if (c->ready) return hipStreamWaitEvent(ctx->stream, c->ready, 0);
     if (!ctx->foreign_ev) LOCGPU_TRY(hipEventCreateWithFlags(&ctx->foreign_ev, hipEventDisableTiming));
     LOCGPU_TRY(hipEventRecord(ctx->foreign_ev, c->ctx->stream));
     return hipStreamWaitEvent(ctx->stream, ctx->foreign_ev, 0);

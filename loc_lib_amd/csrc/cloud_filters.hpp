@@ -14,6 +14,7 @@ struct locgpu_cloud {
     float4* d = nullptr;
     size_t n = 0, cap = 0;
     int is_dense = 1;
+    hipEvent_t ready = nullptr;  // recorded on the owner's stream behind the last call that wrote the cloud (cloud_mark_ready): what ANOTHER context waits for
 };
 
 namespace locgpu {
@@ -51,6 +52,8 @@ struct FilterScratch {
 // context while another matches scan i — and `ctx`'s stream is then ordered behind everything the owning context has enqueued so
 // far. The caller must not let the owner modify the cloud while it is in use here. Returns hipErrorInvalidValue for another device.
 hipError_t cloud_input_ready(locgpu_ctx* ctx, const locgpu_cloud* c);
+// Called by the owner's entry points behind every call that wrote `c`: records c->ready on the owner's stream.
+hipError_t cloud_mark_ready(locgpu_cloud* c);
 void filters_free(locgpu_ctx* ctx);
 hipError_t cloud_reserve(locgpu_cloud* c, size_t n, bool keep);
 hipError_t cloud_stage(locgpu_ctx* ctx, size_t n, float4** out);
