@@ -229,6 +229,35 @@ def stream_pipelined_section(n_scans, kf_every, num_kfs, scan_leaf, map_leaf, as
     return dict(scans=n_scans, scans_per_s=n_scans / wall, ms_per_scan_wall=wall / n_scans * 1e3, async_target=bool(async_target)), np.stack(poses)
 
 
+def cpp_stream_section(n_scans, kf_every, num_kfs, leaf, passes=5, workdir="/tmp"):
+    """configs[4] driven from C++ (tests/cpp/stream_pipeline.cpp, built by __graft_entry__.build()): the sequential loop and the
+    two-stage pipeline, same scans, poses compared bit for bit. No Python between the calls: what a slam_demo front-end would see."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "stream_pipeline")
+    scans = np.stack([xyzi(synth.make_scan(s)) for s in range(n_scans)])
+    poses = np.stack([np.concatenate(synth.make_pose(s)) for s in range(n_scans)])
+    f_scans, f_poses = os.path.join(workdir, "locgpu_stream_scans.bin"), os.path.join(workdir, "locgpu_stream_poses.bin")
+    scans.astype(np.float32).tofile(f_scans)
+    poses.astype(np.float64).tofile(f_poses)
+    out = {}
+    got = {}
+    for mode, name in ((0, "sequential"), (1, "two_stage_pipeline")):
+        f_out = os.path.join(workdir, "locgpu_stream_out_%d.bin" % mode)
+        r = subprocess.run([exe, f_scans, f_poses, str(n_scans), str(scans.shape[1]), str(kf_every), str(num_kfs), str(leaf), str(mode), str(passes), f_out],
+                           capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError("stream_pipeline mode %d failed: %s" % (mode, r.stderr[-500:]))
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        rates = sorted(j["scans_per_s_all_passes"])
+        out[name] = dict(scans_per_s=rates[len(rates) // 2], scans_per_s_all_passes=j["scans_per_s_all_passes"])
+        got[mode] = np.fromfile(f_out, dtype=np.float64).reshape(n_scans, 7)
+    out["poses_identical"] = bool(np.array_equal(got[0], got[1]))
+    out["reported"] = "median of %d passes after one untimed pass; scans / wall time of the whole loop, C++ caller (tests/cpp/stream_pipeline.cpp)" % passes
+    for fn in (f_scans, f_poses):
+        os.remove(fn)
+    return out, got[0]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--map-points", type=int, default=10_000_000)
@@ -239,7 +268,7 @@ def main():
     ap.add_argument("--scan-leaf", type=float, default=0.5)
     ap.add_argument("--map-leaf", type=float, default=0.5)
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--only", choices=["filters", "stream", "inc_ndt"])
+    ap.add_argument("--only", choices=["filters", "stream", "inc_ndt", "cpp_stream"])
     ap.add_argument("--async-target", action="store_true", help="stream section: only with locgpu_icp_set_target_cloud_async (host tree build on a worker thread)")
     ap.add_argument("--blocking-target", action="store_true", help="stream section: only with the blocking locgpu_icp_set_target_cloud")
     ap.add_argument("--graph", action="store_true", help="stream section: replay the captured hipGraph of the Gauss–Newton iterations (BASELINE configs[4])")
@@ -251,6 +280,8 @@ def main():
         print(json.dumps({"filters": filters_section(ctx, locref, a.map_points, a.reps)}))
     if a.only in (None, "inc_ndt"):
         print(json.dumps({"inc_ndt": inc_ndt_section(ctx, locref, a.reps)}))
+    if a.only in (None, "cpp_stream"):
+        print(json.dumps({"cpp_stream": cpp_stream_section(a.scans, a.kf_every, a.num_kfs, a.scan_leaf)[0]}))
     if a.only in (None, "stream"):
         ctx.graph_enable(a.graph)
         # a host-latency-bound loop on a shared box: one untimed pass (it grows the library's buffers and carries the oracle check),

@@ -219,6 +219,35 @@ def test_streaming_loop_as_a_two_stage_pipeline(api, locref, synth):
             icp_ref.set_target(lm.cloud()[:, :3])
 
 
+def test_cpp_streaming_loop_sequential_and_pipelined(api, synth, tmp_path):
+    """configs[4] from C++ through the C ABI (tests/cpp/stream_pipeline.cpp): the sequential loop and the two-stage pipeline give the
+    same poses bit for bit, and they are the poses of the Python-driven loop above (same entry points, same order)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "perf"))
+    import pipeline_microbench as pm
+    assert os.path.exists(os.path.join(root, "tests", "cpp", "stream_pipeline")), "run __graft_entry__.build() first"
+    res, poses = pm.cpp_stream_section(9, 3, 3, 0.5, passes=1, workdir=str(tmp_path))
+    assert res["poses_identical"], res
+    ctx = api.Context(0)
+    try:
+        opts = api.icp_opts(api.P2PLANE)
+        sub = api.Submap(ctx, 3, 0.5)
+        raw, filt = api.Cloud(ctx), api.Cloud(ctx)
+        for s in range(9):
+            truth, init = synth.make_pose(s)
+            raw.upload(xyzi(synth.make_scan(s)), is_dense=False)
+            raw.voxel_filter(0.5, out=filt)
+            pose = truth if s == 0 else ctx.icp_align_cloud(filt, init, opts)[0]
+            if s % 3 == 0:
+                sub.add_keyframe(filt if s == 0 else raw, pose)
+                ctx.icp_set_target_cloud(sub.cloud())
+            assert np.array_equal(pose, poses[s]), s
+    finally:
+        ctx.close()
+
+
 def test_graph_mode_with_grid_search(gpu_ctx, api, small_world):
     """hipGraph capture of the exact grid search (its second work list must exist before the capture starts)."""
     m, s, init = small_world["map"], small_world["scan10k"], small_world["init_pose"]
