@@ -50,16 +50,17 @@ int main(int argc, char** argv) {
     opts.method = LOCGPU_P2PLANE;
     std::vector<double> out((size_t)n_scans * 7);
     std::vector<double> rates;
+    locgpu_ctx *ctx_m = nullptr, *ctx_f = nullptr;  // the matcher instances live as long as the front-end does
+    CHECK(locgpu_create(0, &ctx_m));
+    if (mode == 1) CHECK(locgpu_create(0, &ctx_f)); else ctx_f = ctx_m;
+    const int n_pairs = mode == 1 ? 3 : 1;
+    std::vector<Pair> pairs(n_pairs);
+    for (auto& p : pairs) { CHECK(locgpu_cloud_create(ctx_f, &p.raw)); CHECK(locgpu_cloud_create(ctx_f, &p.filt)); p.scan = -1; }
     for (int pass = 0; pass <= passes; ++pass) {  // pass 0 is untimed: the library's buffers grow there
-        locgpu_ctx *ctx_m = nullptr, *ctx_f = nullptr;
-        CHECK(locgpu_create(0, &ctx_m));
-        if (mode == 1) CHECK(locgpu_create(0, &ctx_f)); else ctx_f = ctx_m;
         locgpu_submap* sub = nullptr;
         CHECK(locgpu_submap_create(ctx_m, num_kfs, leaf, &sub));
-        const int n_pairs = mode == 1 ? 3 : 1;
-        std::vector<Pair> pairs(n_pairs);
         Channel free_ch, ready_ch;
-        for (auto& p : pairs) { CHECK(locgpu_cloud_create(ctx_f, &p.raw)); CHECK(locgpu_cloud_create(ctx_f, &p.filt)); p.scan = -1; free_ch.put(p); }
+        for (auto& p : pairs) free_ch.put(p);
         auto filter_one = [&](Pair p, int s) {
             CHECK(locgpu_cloud_upload(p.raw, scans.data() + (size_t)s * pts * 4, pts, 16, 12, 0));
             CHECK(locgpu_cloud_voxel_filter(p.raw, leaf, p.filt, nullptr));
@@ -88,11 +89,11 @@ int main(int argc, char** argv) {
         if (mode == 1) stage.join();
         const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (pass > 0) rates.push_back(n_scans / wall);
-        for (auto& p : pairs) { locgpu_cloud_destroy(p.raw); locgpu_cloud_destroy(p.filt); }
         locgpu_submap_destroy(sub);
-        if (mode == 1) locgpu_destroy(ctx_f);
-        locgpu_destroy(ctx_m);
     }
+    for (auto& p : pairs) { locgpu_cloud_destroy(p.raw); locgpu_cloud_destroy(p.filt); }
+    if (mode == 1) locgpu_destroy(ctx_f);
+    locgpu_destroy(ctx_m);
     f = std::fopen(argv[10], "wb");
     if (!f || std::fwrite(out.data(), 8, out.size(), f) != out.size()) { std::perror(argv[10]); return 2; }
     std::fclose(f);
