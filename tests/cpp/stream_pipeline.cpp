@@ -61,9 +61,14 @@ int main(int argc, char** argv) {
         CHECK(locgpu_submap_create(ctx_m, num_kfs, leaf, &sub));
         Channel free_ch, ready_ch;
         for (auto& p : pairs) free_ch.put(p);
+        double t_filter = 0.0, t_match = 0.0, t_kf = 0.0, t_wait = 0.0;  // seconds inside the calls of each stage (STREAM_PIPELINE_TIMES=1 prints them)
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
         auto filter_one = [&](Pair p, int s) {
+            const auto ta = now();
             CHECK(locgpu_cloud_upload(p.raw, scans.data() + (size_t)s * pts * 4, pts, 16, 12, 0));
             CHECK(locgpu_cloud_voxel_filter(p.raw, leaf, p.filt, nullptr));
+            t_filter += secs(ta, now());
             p.scan = s;
             return p;
         };
@@ -71,24 +76,33 @@ int main(int argc, char** argv) {
         std::thread stage;
         if (mode == 1) stage = std::thread([&] { for (int s = 0; s < n_scans; ++s) ready_ch.put(filter_one(free_ch.get(), s)); });
         for (int s = 0; s < n_scans; ++s) {
+            const auto tw = now();
             const Pair p = mode == 1 ? ready_ch.get() : filter_one(free_ch.get(), s);
+            if (mode == 1) t_wait += secs(tw, now());
             const double* truth = &poses[(size_t)s * 14];
             const double* init = truth + 7;
             double* pose = &out[(size_t)s * 7];
             const locgpu_cloud* kf_src = p.raw;  // later keyframes keep the RAW scan (lio.cpp:279)
+            const auto tm = now();
             if (s == 0) { std::memcpy(pose, truth, 56); kf_src = p.filt; }  // the first frame seeds the map with the FILTERED scan (lio.cpp:238-256)
             else CHECK(locgpu_icp_align_cloud(ctx_m, p.filt, init, &opts, pose, nullptr));
+            const auto tk = now();
+            t_match += secs(tm, tk);
             if (s % kf_every == 0) {
                 CHECK(locgpu_submap_add_keyframe(sub, kf_src, pose));
                 locgpu_cloud* map = nullptr;
                 CHECK(locgpu_submap_cloud(sub, &map));
                 CHECK(locgpu_icp_set_target_cloud_async(ctx_m, map));
+                t_kf += secs(tk, now());
             }
             free_ch.put(p);
         }
         if (mode == 1) stage.join();
         const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (pass > 0) rates.push_back(n_scans / wall);
+        if (pass == passes && std::getenv("STREAM_PIPELINE_TIMES"))
+            std::fprintf(stderr, "per scan [ms]: wall %.3f | upload + filter %.3f | match %.3f | keyframe + target %.3f | matcher thread waiting for a filtered scan %.3f\n",
+                         1e3 * wall / n_scans, 1e3 * t_filter / n_scans, 1e3 * t_match / n_scans, 1e3 * t_kf / n_scans, 1e3 * t_wait / n_scans);
         locgpu_submap_destroy(sub);
     }
     for (auto& p : pairs) { locgpu_cloud_destroy(p.raw); locgpu_cloud_destroy(p.filt); }
