@@ -13,11 +13,18 @@ timeout 200 python bench.py --steps 20 --warmup 5 --pipeline 1 --no-cpu-baseline
 timeout 200 python bench.py --scaling strong --steps 20 --warmup 5 --no-cpu-baseline --traffic none 2>/dev/null | grep '^{' > $O/bench_strong_1rank_line.json
 timeout 200 python tools/latency_microbench.py 2>/dev/null | grep '^{' > $O/latency.json
 timeout 400 python3 tools/collect_pmc.py --out $O/pmc_kernels.md --scans 64 > /dev/null 2>&1
-timeout 400 python tests/perf/pipeline_microbench.py 2>/dev/null | grep '^{' > $O/pipeline.json
+timeout 600 python tests/perf/pipeline_microbench.py 2>/dev/null | grep '^{' > $O/pipeline.json
 timeout 1500 python3 tests/perf/baseline_table.py --out $O/baseline_table.json > $O/baseline_table.md 2>/dev/null
 timeout 300 python3 tools/iter_trace.py --out $O/iteration_trace.txt > /dev/null 2>&1
 timeout 300 python3 tools/single_scan_trace.py --out $O/single_scan_trace.txt > /dev/null 2>&1
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --traffic none > /dev/null 2>&1
 cp $O/prof/*/bench_kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null || cp $O/prof/bench_kernel_stats.csv $O/bench_kernel_stats.csv; rm -rf $O/prof
+cd $R
+timeout 600 python tools/ndt_determinism.py --reps 5000 > $O/ndt_determinism.log 2>&1
+timeout 500 python tools/fuzz_search.py --cases 300 --seed 4 > $O/fuzz_search.log 2>&1
+timeout 300 python tools/fuzz_ndt.py --cases 300 --seed 4 > $O/fuzz_ndt.log 2>&1
+timeout 300 python tools/fuzz_align.py --cases 40 > $O/fuzz_align.log 2>&1
+timeout 200 python tools/fuzz_hb.py > $O/fuzz_hb.log 2>&1
+tail -2 $O/ndt_determinism.log $O/fuzz_search.log $O/fuzz_ndt.log $O/fuzz_align.log $O/fuzz_hb.log
 ls -la $O
