@@ -20,6 +20,9 @@ timeout 300 python3 tools/single_scan_trace.py --out $O/single_scan_trace.txt > 
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --traffic none > /dev/null 2>&1
 cp $O/prof/*/bench_kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null || cp $O/prof/bench_kernel_stats.csv $O/bench_kernel_stats.csv; rm -rf $O/prof
+# the same with ONE alignment in flight: launch durations that do not overlap — what roofline.avg_launch_ms (measured on non-overlapped steps) must agree with
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --pipeline 1 --no-cpu-baseline --traffic none > /dev/null 2>&1
+cp $O/prof/*/bench_kernel_stats.csv $O/bench_pipeline1_kernel_stats.csv 2>/dev/null || cp $O/prof/bench_kernel_stats.csv $O/bench_pipeline1_kernel_stats.csv; rm -rf $O/prof
 cd $R
 timeout 600 python tools/ndt_determinism.py --reps 5000 > $O/ndt_determinism.log 2>&1
 timeout 500 python tools/fuzz_search.py --cases 300 --seed 4 > $O/fuzz_search.log 2>&1
