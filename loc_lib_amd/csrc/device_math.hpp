@@ -253,6 +253,107 @@ __device__ __forceinline__ void plane_null_vector(const D3 (&nb)[5], double (&n4
     n4[0] = w0 * rw; n4[1] = w1 * rw; n4[2] = w2 * rw; n4[3] = w3 * rw;
 }
 
+// The same vector as plane_null_vector — the right singular vector of the smallest singular value of A = [x y z 1] — for about
+// two thirds of its instructions (round 4; the fit kernel is bound by instruction issue and this is two thirds of it).
+// With c = the centroid and Q = P − 1cᵀ the centred neighbours (Qᵀ1 = 0), A·(a, d) = Q·a + (c·a + d)·1, so
+//     ‖A n‖² = aᵀSa + 5t²   with S = QᵀQ, t = c·a + d,   under   ‖a‖² + (t − c·a)² = 1:
+// a generalised eigenproblem diag(S, 5)·x = μ·(diag(I, 0) + wwᵀ)·x, w = (c, −1), that needs only the 3×3 eigen-decomposition of S
+// (three Jacobi pairs per sweep instead of six, on the triangular factor of the centred 5×3 matrix — small singular values to high
+// relative accuracy, like the 4-column scheme) and the smallest root of its secular equation
+//     1 = μ·( Σₖ gₖ²/(λₖ − μ) + 1/5 ),   gₖ = c·uₖ,   0 < μ < λ₁ = min λₖ.
+// Multiplied by Πλₖ·Π(λₖ − μ) it is a polynomial Ψ(μ), symmetric in the three poles and free of divisions (a plane through the
+// origin puts the root right below λ₁: Ψ has no pole there). Newton on Ψ from the root of the one-pole model (the two far poles
+// frozen at μ = 0; hardware-precision 1/x and 1/√x are enough for a first guess) takes 2.3 iterations on average and about 4 for the
+// worst lane of a wave; it stops when a step is below 1e-8·μ — quadratic convergence makes the iterate behind that step exact to
+// rounding. Then a ∝ Σₖ gₖ/(λₖ − μ)·uₖ and d ∝ −1/5 − c·a/μ, again multiplied out, normalised at the end (the sign is free).
+// Against a long-double Jacobi SVD on 65 536 synthetic neighbourhoods up to 500 m from the origin — planes through the origin,
+// nearly collinear neighbourhoods and noise down to 20 nm included (tools/ubench/plane_fit_accuracy.hip) — |Δn4| ≤ 7e-13.
+// Neighbourhoods whose centred matrix has (numerically) rank < 3 — five exactly coplanar, collinear or coincident neighbours — and
+// anything that does not come out finite return false: the caller runs plane_null_vector, whose rules for those cases are the
+// ones shared with the CPU checker.
+__device__ __forceinline__ bool plane_null_vector_secular(const D3 (&nb)[5], double (&n4)[4]) {
+#pragma clang fp contract(fast)
+    const double cx = ((nb[0].x + nb[1].x) + (nb[2].x + nb[3].x) + nb[4].x) * 0.2, cy = ((nb[0].y + nb[1].y) + (nb[2].y + nb[3].y) + nb[4].y) * 0.2,
+                 cz = ((nb[0].z + nb[1].z) + (nb[2].z + nb[3].z) + nb[4].z) * 0.2;
+    double a[3][5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { a[0][j] = nb[j].x - cx; a[1][j] = nb[j].y - cy; a[2][j] = nb[j].z - cz; }
+    double l[3][3];  // l[k][i] = R(k, i) of Q = Q̂R: column k of Rᵀ
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double nrm2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) nrm2 += a[k][i] * a[k][i];
+        const double rn = nrm2 > 0.0 ? rsqrt_refined(nrm2) : 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) l[k][i] = 0.0;
+        l[k][k] = nrm2 * rn;
+        double q[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) q[i] = a[k][i] * rn;
+#pragma unroll
+        for (int j = k + 1; j < 3; ++j) {
+            double r = 0.0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) r += q[i] * a[j][i];
+            l[k][j] = r;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) a[j][i] -= r * q[i];
+        }
+    }
+    double unused[3][3];
+    double sn[3];
+    jacobi_svd_onesided<3, 3, false>(l, unused, sn);  // columns l[k] = σₖ·uₖ, sn[k] = σₖ² = λₖ
+    const double mx = fmax(sn[0], fmax(sn[1], sn[2]));
+    const bool b0 = sn[0] <= sn[1] && sn[0] <= sn[2], b1 = !b0 && sn[1] <= sn[2];
+    const double l1 = b0 ? sn[0] : (b1 ? sn[1] : sn[2]);
+    if (!(l1 > 1e-20 * mx)) return false;  // rank < 3 (also NaN): the 4-column scheme decides
+    // everything below is scaled by λ₀λ₁λ₂: Gₖ = (c·lₖ)²·λⱼλₗ = gₖ²·Πλ (lₖ = σₖuₖ), S3 = Πλ — no division by a λ
+    const double cl0 = (cx * l[0][0] + cy * l[0][1]) + cz * l[0][2], cl1 = (cx * l[1][0] + cy * l[1][1]) + cz * l[1][2],
+                 cl2 = (cx * l[2][0] + cy * l[2][1]) + cz * l[2][2];
+    const double s12 = sn[1] * sn[2], s02 = sn[0] * sn[2], s01 = sn[0] * sn[1];
+    const double S3 = s01 * sn[2], S3_5 = 0.2 * S3;
+    const double G0 = (cl0 * cl0) * s12, G1 = (cl1 * cl1) * s02, G2 = (cl2 * cl2) * s01;
+    double mu;
+    {   // first guess: R·μ² − (g₁² + R·λ₁ + 1)·μ + λ₁ = 0 with R = Σ_far gₖ²/λₖ + 1/5, smaller root in its stable form
+        const double iS = __builtin_amdgcn_rcp(S3);
+        const double i0 = __builtin_amdgcn_rcp(sn[0]), i1 = __builtin_amdgcn_rcp(sn[1]), i2 = __builtin_amdgcn_rcp(sn[2]);
+        const double r0 = (G0 * iS) * i0, r1 = (G1 * iS) * i1, r2 = (G2 * iS) * i2;  // gₖ²/λₖ
+        const double g1 = (b0 ? G0 : (b1 ? G1 : G2)) * iS;
+        const double R = ((b0 ? 0.0 : r0) + (b1 ? 0.0 : r1)) + ((b0 || b1 ? r2 : 0.0) + 0.2);
+        const double B = (g1 + R * l1) + 1.0;
+        const double disc = fmax(B * B - 4.0 * (R * l1), 0.0);
+        mu = (2.0 * l1) * __builtin_amdgcn_rcp(B + disc * __builtin_amdgcn_rsq(fmax(disc, 1e-300)));
+        mu = fmin(mu, 0.999999 * l1);
+    }
+#pragma unroll 1
+    for (int it = 0; it < 16; ++it) {
+        const double e0 = sn[0] - mu, e1 = sn[1] - mu, e2 = sn[2] - mu;
+        const double p01 = e0 * e1, p02 = e0 * e2, p12 = e1 * e2;
+        const double E = p01 * e2;
+        const double u = ((G0 * p12 + G1 * p02) + G2 * p01) + S3_5 * E;
+        const double psi = mu * u - S3 * E;
+        const double dE = -((p01 + p02) + p12);
+        const double du = S3_5 * dE - ((G0 * (e1 + e2) + G1 * (e0 + e2)) + G2 * (e0 + e1));
+        const double dpsi = (u + mu * du) - S3 * dE;
+        double nu = mu - psi * __builtin_amdgcn_rcp(dpsi);
+        if (!(nu > 0.0 && nu < l1)) nu = 0.5 * (mu + (psi < 0.0 ? l1 : 0.0));  // Newton left the interval: bisect towards the root's side
+        const bool done = fabs(nu - mu) <= 1e-8 * nu;
+        mu = nu;
+        if (done) break;
+    }
+    const double e0 = sn[0] - mu, e1 = sn[1] - mu, e2 = sn[2] - mu;
+    const double w0 = (cl0 * s12) * (e1 * e2), w1 = (cl1 * s02) * (e0 * e2), w2 = (cl2 * s01) * (e0 * e1);
+    const double ax = (w0 * l[0][0] + w1 * l[1][0]) + w2 * l[2][0], ay = (w0 * l[0][1] + w1 * l[1][1]) + w2 * l[2][1],
+                 az = (w0 * l[0][2] + w1 * l[1][2]) + w2 * l[2][2];
+    const double d = -S3_5 * ((e0 * e1) * e2) - ((cx * ax + cy * ay) + cz * az);
+    const double nn = (ax * ax + ay * ay) + (az * az + d * d);
+    if (!(nn > 1e-290 && nn < 1e290)) return false;  // not finite, or scaled out of range: the 4-column scheme decides
+    const double rn = rsqrt_refined(nn);
+    n4[0] = ax * rn; n4[1] = ay * rn; n4[2] = az * rn; n4[3] = d * rn;
+    return true;
+}
+
 // Right singular vector of the LARGEST singular value of the 5×3 matrix of centred neighbours — the line direction
 // math::FitLine takes from JacobiSVD (math_utils.h:152-154: V.col(0)), up to its sign, which cancels in H and B. Same scheme
 // as plane_null_vector: R from modified Gram–Schmidt, one-sided Jacobi on the columns of Rᵀ; the dominant right singular

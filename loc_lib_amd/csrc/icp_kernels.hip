@@ -606,6 +606,8 @@ __device__ __forceinline__ void R_hat(const double* R, const D3& q, double (&Rh)
 
 
 // K2, P2Plane: IcpRegistration::CaculateMatrixHAndBP2Plane (icp_registration.cpp:161-213) + math::FitPlane (math_utils.h:112-136).
+// FIT: 0 = plane_null_vector (4-column one-sided Jacobi), 1 = plane_null_vector_secular with the former as its fall-back.
+template <int FIT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_plane_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
@@ -636,7 +638,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
                 for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, slot[j]);
                 double n4[4];
-                plane_null_vector(nb, n4);
+                if constexpr (FIT == 1) {
+                    if (!plane_null_vector_secular(nb, n4)) plane_null_vector(nb, n4);
+                } else {
+                    plane_null_vector(nb, n4);
+                }
                 const D3 n3{n4[0], n4[1], n4[2]};
                 bool fit = true;
 #pragma unroll
@@ -685,6 +691,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 //      (icp cpp:184-201) and the rows are summed exactly as in icp_plane_accum_kernel — same order, same bits.
 // A cached vector is the one the same code computed from the same five leaves: results equal the uncached kernel's bit for bit.
 constexpr int kPlaneCachePts = 2;  // points per thread: 512 plane vectors (16 KB) stay in LDS between the fit and the residual stage
+template <int FIT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void icp_plane_cached_accum_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
@@ -739,7 +746,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             D3 nb[5];
 #pragma unroll
             for (int j = 0; j < 5; ++j) nb[j] = leaf_point(tree, slot[j]);
-            plane_null_vector(nb, n4);
+            if constexpr (FIT == 1) {
+                if (!plane_null_vector_secular(nb, n4)) plane_null_vector(nb, n4);
+            } else {
+                plane_null_vector(nb, n4);
+            }
             const D3 n3{n4[0], n4[1], n4[2]};
             bool fit = true;
 #pragma unroll
@@ -1330,6 +1341,15 @@ size_t walk_stop_min_waves() {
     return v;
 }
 
+// LOCGPU_PLANE_FIT (read once): 1 = secular-equation fit (plane_null_vector_secular), 0 = the 4-column Jacobi fit.
+int plane_fit_mode() {
+    static const int mode = [] {
+        const char* e = getenv("LOCGPU_PLANE_FIT");
+        return e && *e ? atoi(e) : 1;
+    }();
+    return mode;
+}
+
 // LOCGPU_PLANE_CACHE (read once): 0 = off (DEFAULT: measured a net loss, see icp_plane_cached_accum_kernel), 1 = on; experiments: 2 = the
 // cached kernel's structure with every point refitted, 3 = the search kernel marks unchanged lists but the plain fit kernel runs
 int plane_cache_mode() {
@@ -1391,12 +1411,19 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
     if (pts > 8) pts = 8;
     if (method == 2 && a.plane_cache && a.same_mask) pts = kPlaneCachePts;
     const dim3 grid((blocks + pts - 1) / pts, a.active ? a.n_active : a.n_scans);
-    if (method == 2 && a.plane_cache && a.same_mask)
-        hipLaunchKernelGGL(icp_plane_cached_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active,
-                           a.plane_cache, a.same_mask, a.use_cache);
-    else if (method == 2)
-        hipLaunchKernelGGL(icp_plane_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
-    else if (method == 1)
+    if (method == 2 && a.plane_cache && a.same_mask) {
+        if (plane_fit_mode() == 1)
+            hipLaunchKernelGGL(icp_plane_cached_accum_kernel<1>, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts,
+                               a.active, a.plane_cache, a.same_mask, a.use_cache);
+        else
+            hipLaunchKernelGGL(icp_plane_cached_accum_kernel<0>, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts,
+                               a.active, a.plane_cache, a.same_mask, a.use_cache);
+    } else if (method == 2) {
+        if (plane_fit_mode() == 1)
+            hipLaunchKernelGGL(icp_plane_accum_kernel<1>, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
+        else
+            hipLaunchKernelGGL(icp_plane_accum_kernel<0>, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
+    } else if (method == 1)
         hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
     else
         hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);

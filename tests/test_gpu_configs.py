@@ -751,6 +751,34 @@ def test_later_chunks_launch_only_the_open_scans(tmp_path):
         assert np.array_equal(outs["list"][name + "_flight"][:len(it)], outs["list"][name])
 
 
+def test_secular_plane_fit_agrees_with_the_four_column_fit(tmp_path):
+    """Round 4: the P2Plane fit kernel finds FitPlane's 4-vector (math_utils.h:112-136) from the 3×3 eigen-decomposition of the centred
+    neighbours plus the secular equation of the homogeneous column (device_math.hpp plane_null_vector_secular; LOCGPU_PLANE_FIT=1, the
+    default) instead of a 4-column one-sided Jacobi SVD (LOCGPU_PLANE_FIT=0). Both compute the same singular vector to rounding: on a
+    ragged eight-scan batch the iteration counts are equal, poses agree to 1e-10, and one H/B evaluation (each at its own poses, which
+    differ by ~1e-13) to 1e-9 of its scale with equal effective_num / ok. (Each against the CPU checker: test_gpu_parity.py and
+    tools/fuzz_hb.py run with the default.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, val in (("secular", "1"), ("jacobi4", "0")):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_plane_cache_case.py"), f],
+                           env=dict(os.environ, LOCGPU_PLANE_FIT=val, LOCGPU_PLANE_CACHE="0"), capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[tag] = np.load(f)
+    a, b = outs["secular"], outs["jacobi4"]
+    assert np.array_equal(a["it"], b["it"]), (a["it"], b["it"])
+    assert np.abs(a["pose"] - b["pose"]).max() < 1e-10
+    hb_a, hb_b = np.asarray(a["hb"]), np.asarray(b["hb"])
+    assert not np.array_equal(hb_a, hb_b)  # two different routes to the vector: equal bits would mean the switch did nothing
+    scale = np.abs(hb_b[:, :36]).max(axis=1, keepdims=True)
+    assert (np.abs(hb_a[:, :42] - hb_b[:, :42]) <= 1e-9 * scale).all()
+    assert np.array_equal(hb_a[:, 42:44], hb_b[:, 42:44])  # effective_num, ok
+
+
 def test_plane_cache_gives_the_uncached_kernels_bits(tmp_path):
     """Round 4 (opt-in, LOCGPU_PLANE_CACHE=1: built for VERDICT r3 item 5, measured slower than the plain kernels on the bench workload and
     therefore not the default — the parity claim below is what keeps the measurement honest).
