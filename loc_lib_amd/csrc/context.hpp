@@ -30,6 +30,7 @@ struct locgpu_ctx {
     hipEvent_t foreign_ev = nullptr;    // ordering behind another context's stream when one of ITS clouds is an input here (cloud_input_ready)
     hipStream_t comm_stream = nullptr;  // every collective of the context, in host order (one communicator, one stream: no two at once)
     locgpu::Uploader* up = nullptr;     // host → HBM staging shared by the context's batches (batch_upload.hpp)
+    locgpu::PendingTarget* target_scratch = nullptr;  // the previous ingest's host buffers, kept for the next one (locgpu_api.hip)
     locgpu::PendingTarget* pending_target = nullptr;  // locgpu_icp_set_target_cloud_async: a host tree build still running (locgpu_api.hip)
     std::string err;
 
@@ -106,6 +107,7 @@ struct locgpu_batch {
     double* d_plane_cache = nullptr;             // [pitch][4]
     unsigned long long* d_same_mask = nullptr;   // [n_scans][ceil(max_n / 64)]
     bool cache_chain = false;                    // the previous iteration of the running alignment filled the cache
+    int last_iterations = -1;                    // one-scan batches: iterations of the previous alignment run on this batch (-1: none yet) — sizes the next first chunk
     double* d_partials = nullptr;  // [n_scans][blocks_per_scan][kAccW]
     double* d_hb = nullptr;        // [n_scans][44]
     uint32_t* d_redo_list = nullptr;      // [pitch]

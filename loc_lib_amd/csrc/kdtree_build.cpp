@@ -16,6 +16,7 @@
 // A 16-byte load at a leaf's slot therefore returns the whole point.
 #include "kdtree_build.hpp"
 
+#include <immintrin.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -24,6 +25,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -35,8 +37,11 @@ struct Local {  // per-task counters (shared atomics on every leaf cost more tha
     int depth = 0;
 };
 
+// A point travels with its index: every node's points are CONTIGUOUS 16-byte records in the reference's order (the stable
+// partition keeps it), so each pass streams its range instead of gathering through an index list.
+struct alignas(16) Rec { float x, y, z; int32_t id; };
+
 struct Builder {
-    const float* pts;  // packed xyz, 3 floats per point
     std::atomic<int64_t> leaves{0};
     std::atomic<int> depth{0};
     void merge(const Local& l) {
@@ -45,45 +50,64 @@ struct Builder {
         while (l.depth > d && !depth.compare_exchange_weak(d, l.depth, std::memory_order_relaxed)) {}
     }
 
-    // Split [idx, idx+len) the way FindSplitAxisAndThresh does. Returns false for the degenerate case.
-    bool split(int32_t* idx, int32_t* tmp, size_t len, int& axis, float& th, size_t& n_left) const {
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        for (size_t i = 0; i < len; ++i) {
-            const float* p = pts + 3 * (size_t)idx[i];
-            sx = sx + p[0]; sy = sy + p[1]; sz = sz + p[2];
+    // Split a[0, len) the way FindSplitAxisAndThresh does (kdtree.cpp:96-123; mean and variance as math_utils.h:35-47: float32 sums
+    // in index order, one IEEE operation at a time — the three coordinates ride in one SSE register, lane by lane the scalar code).
+    // `sum_in` (optional): Σ of the points, already accumulated by the parent's partition — a child's points are appended in their
+    // final order there, so its sum costs no pass of its own. Leaves the children's sums in sum_l / sum_r the same way (the side a
+    // point does not go to adds +0.0f, which changes no float32 sum: a sum that starts at +0 is never −0).
+    // Returns false for the degenerate case (every point on one side).
+    bool split(Rec* a, Rec* tmp, size_t len, const __m128* sum_in, int& axis, float& th, size_t& n_left, __m128& sum_l, __m128& sum_r) const {
+        const __m128 xyz_mask = _mm_castsi128_ps(_mm_set_epi32(0, -1, -1, -1));
+        __m128 s;
+        if (sum_in) {
+            s = *sum_in;
+        } else {
+            s = _mm_setzero_ps();
+            for (size_t i = 0; i < len; ++i) s = _mm_add_ps(s, _mm_and_ps(_mm_load_ps(&a[i].x), xyz_mask));
         }
-        const float flen = (float)len;
-        const float mx = sx / flen, my = sy / flen, mz = sz / flen;
-        float vx = 0.f, vy = 0.f, vz = 0.f;
+        const __m128 m = _mm_div_ps(s, _mm_set1_ps((float)len));
+        __m128 v = _mm_setzero_ps();
         for (size_t i = 0; i < len; ++i) {
-            const float* p = pts + 3 * (size_t)idx[i];
-            const float dx = p[0] - mx, dy = p[1] - my, dz = p[2] - mz;
-            vx = vx + dx * dx; vy = vy + dy * dy; vz = vz + dz * dz;
+            const __m128 d = _mm_sub_ps(_mm_and_ps(_mm_load_ps(&a[i].x), xyz_mask), m);
+            v = _mm_add_ps(v, _mm_mul_ps(d, d));
         }
-        const float flen1 = (float)(len - 1);
-        vx = vx / flen1; vy = vy / flen1; vz = vz / flen1;
+        v = _mm_div_ps(v, _mm_set1_ps((float)(len - 1)));
+        alignas(16) float mv[4], vv[4];
+        _mm_store_ps(mv, m);
+        _mm_store_ps(vv, v);
         axis = 0;
-        float best = vx;
-        if (vy > best) { best = vy; axis = 1; }
-        if (vz > best) { best = vz; axis = 2; }
-        th = axis == 0 ? mx : (axis == 1 ? my : mz);
+        float best = vv[0];
+        if (vv[1] > best) { best = vv[1]; axis = 1; }
+        if (vv[2] > best) { best = vv[2]; axis = 2; }
+        th = mv[axis];
         size_t nl = 0, nr = 0;
-        for (size_t i = 0; i < len; ++i) {  // stable partition: `< th` left, else right
-            const int32_t id = idx[i];
-            if (pts[3 * (size_t)id + axis] < th) idx[nl++] = id;
-            else tmp[nr++] = id;
+        __m128 sl = _mm_setzero_ps(), sr = _mm_setzero_ps();
+        for (size_t i = 0; i < len; ++i) {  // stable partition: `< th` left, else right; both targets are written, one counter moves
+            const Rec r = a[i];
+            const __m128 p = _mm_and_ps(_mm_load_ps(&a[i].x), xyz_mask);
+            const float c = axis == 0 ? r.x : (axis == 1 ? r.y : r.z);
+            const bool left = c < th;
+            const __m128 lm = _mm_castsi128_ps(_mm_set1_epi32(left ? -1 : 0));
+            sl = _mm_add_ps(sl, _mm_and_ps(p, lm));
+            sr = _mm_add_ps(sr, _mm_andnot_ps(lm, p));
+            a[nl] = r;      // nl <= i: the record at i has been read
+            tmp[nr] = r;
+            nl += left;
+            nr += !left;
         }
-        std::memcpy(idx + nl, tmp, nr * sizeof(int32_t));
+        if (nr <= 8) { for (size_t i = 0; i < nr; ++i) a[nl + i] = tmp[i]; }
+        else std::memcpy(a + nl, tmp, nr * sizeof(Rec));
         n_left = nl;
+        sum_l = sl;
+        sum_r = sr;
         return !(nl == 0 || nr == 0);
     }
 
-    void emit_leaf(std::vector<uint64_t>& out, int32_t id, Local& loc) {
-        const float* p = pts + 3 * (size_t)id;
+    static void emit_leaf(uint64_t* out, size_t& n_out, const Rec& r, Local& loc) {
         uint32_t xb, yb, zb;
-        std::memcpy(&xb, p, 4); std::memcpy(&yb, p + 1, 4); std::memcpy(&zb, p + 2, 4);
-        out.push_back((uint64_t)xb | ((uint64_t)((3u << 30) | (uint32_t)id) << 32));
-        out.push_back((uint64_t)yb | ((uint64_t)zb << 32));
+        std::memcpy(&xb, &r.x, 4); std::memcpy(&yb, &r.y, 4); std::memcpy(&zb, &r.z, 4);
+        out[n_out++] = (uint64_t)xb | ((uint64_t)((3u << 30) | (uint32_t)r.id) << 32);
+        out[n_out++] = (uint64_t)yb | ((uint64_t)zb << 32);
         loc.leaves++;
     }
 
@@ -92,27 +116,31 @@ struct Builder {
         while (level > d && !depth.compare_exchange_weak(d, level, std::memory_order_relaxed)) {}
     }
 
-    // Recursive build of one sub-tree into `out` (slot indices relative to out's start).
-    void build(int32_t* idx, int32_t* tmp, size_t len, int level, std::vector<uint64_t>& out, Local& loc) {
+    // Recursive build of one sub-tree: slots go to out[n_out…] (room for 3·len − 1), child indices are positions in `out`; the slot
+    // position of every leaf goes to leaf_out[n_leaf…] when leaf_out is given (the caller then passes the WHOLE tree's arrays and
+    // the sub-tree's first slot / leaf in n_out / n_leaf).
+    void build(Rec* a, Rec* tmp, size_t len, const __m128* sum_in, int level, uint64_t* out, size_t& n_out, uint32_t* leaf_out, size_t& n_leaf, Local& loc) {
         if (level > loc.depth) loc.depth = level;
-        if (len == 1) { emit_leaf(out, idx[0], loc); return; }
-        const int32_t first = idx[0];  // points[0] before the partition reorders nothing: stable ⇒ idx[0] stays first of its side
+        if (len == 1) { if (leaf_out) leaf_out[n_leaf++] = (uint32_t)n_out; emit_leaf(out, n_out, a[0], loc); return; }
+        const Rec first = a[0];  // points[0]: the leaf of the degenerate case (kdtree.cpp:66-70)
         int axis; float th; size_t nl;
-        if (!split(idx, tmp, len, axis, th, nl)) { emit_leaf(out, first, loc); return; }
-        const size_t pos = out.size();
-        out.push_back(0);
-        build(idx, tmp, nl, level + 1, out, loc);
-        const size_t right = out.size();
+        __m128 sl, sr;
+        if (!split(a, tmp, len, sum_in, axis, th, nl, sl, sr)) { if (leaf_out) leaf_out[n_leaf++] = (uint32_t)n_out; emit_leaf(out, n_out, first, loc); return; }
+        const size_t pos = n_out++;
+        build(a, tmp, nl, &sl, level + 1, out, n_out, leaf_out, n_leaf, loc);
+        const size_t right = n_out;
         uint32_t tb; std::memcpy(&tb, &th, 4);
         out[pos] = (uint64_t)tb | ((uint64_t)(((uint32_t)axis << 30) | (uint32_t)right) << 32);
-        build(idx + nl, tmp + nl, len - nl, level + 1, out, loc);
+        build(a + nl, tmp + nl, len - nl, &sr, level + 1, out, n_out, leaf_out, n_leaf, loc);
     }
 };
 
 struct Piece {  // a node of the level-parallel top of the tree, or a deferred sub-tree task
     bool is_task = false;
     bool is_leaf = false;
-    int32_t leaf_id = 0;
+    Rec leaf_rec{};
+    __m128 sum = _mm_setzero_ps();  // Σ of the range's points, left by the parent's partition (the root sums its own)
+    bool has_sum = false;
     int axis = 0;
     float th = 0.f;
     int left = -1, right = -1;  // piece indices
@@ -229,18 +257,46 @@ inline bool slot_floats_bounded(const uint64_t* s, size_t n) {
 
 }  // namespace
 
+// Scratch of a build — the point records and their partition buffer — kept between builds: a keyframe front-end re-ingests a
+// ≈35 k-point local map every few scans, and two fresh 0.5 MB vectors per build are two mmap/munmap pairs and ≈300 page faults
+// (a fifth of such a build). A small free list (several contexts may build at once); capacity only grows.
+struct BuildScratch { std::vector<Rec> a, tmp; };
+class ScratchCache {
+public:
+    static std::unique_ptr<BuildScratch> acquire() {
+        std::lock_guard<std::mutex> lk(mu());
+        auto& f = free_list();
+        if (f.empty()) return std::make_unique<BuildScratch>();
+        std::unique_ptr<BuildScratch> s = std::move(f.back());
+        f.pop_back();
+        return s;
+    }
+    static void release(std::unique_ptr<BuildScratch> s) {
+        std::lock_guard<std::mutex> lk(mu());
+        auto& f = free_list();
+        if (f.size() < 4 && s->a.size() <= (size_t)4 << 20) f.push_back(std::move(s));  // keep at most four, none larger than 64 MB a vector (a 10 M-point map's goes back)
+    }
+private:
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::vector<std::unique_ptr<BuildScratch>>& free_list() { static std::vector<std::unique_ptr<BuildScratch>> f; return f; }
+};
+
 bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::string& err) {
-    out = PackedKdTree();
+    out.slots.clear(); out.leaf_slots.clear();  // a PackedKdTree that is reused keeps its capacity (same reason as BuildScratch)
+    out.num_leaves = out.num_nodes = out.num_points = 0; out.depth = 0; out.bounded = true;
     if (n == 0) { err = "empty target cloud"; return false; }
     // 3n-1 slots of 8 bytes must stay below 4 GiB: the search kernel addresses the tree through a 32-bit buffer offset
     if (n >= (1ull << 29) / 3) { err = "target cloud too large (the packed tree must stay below 4 GiB)"; return false; }
     Builder b;
-    b.pts = xyz;
-    std::vector<int32_t> idx(n), tmp(n);
-    for (size_t i = 0; i < n; ++i) idx[i] = (int32_t)i;
+    struct ScratchHold { std::unique_ptr<BuildScratch> s = ScratchCache::acquire(); ~ScratchHold() { ScratchCache::release(std::move(s)); } } hold;
+    std::vector<Rec>& idx = hold.s->a;   // the points with their indices, reordered node by node
+    std::vector<Rec>& tmp = hold.s->tmp;  // partition buffer of the same size
+    if (idx.size() < n) { idx.resize(n); tmp.resize(n); }
+    for (size_t i = 0; i < n; ++i) idx[i] = Rec{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], (int32_t)i};
 
     Pool& pool = Pool::get();
-    const unsigned nt = (unsigned)std::min<size_t>(pool.size(), std::max<size_t>(1, n / 4096));  // threads worth waking for this map
+    static const size_t grain = [] { const char* e = std::getenv("LOCGPU_BUILD_GRAIN"); const long v = e ? std::atol(e) : 0; return v >= 256 ? (size_t)v : (size_t)2048; }();
+    const unsigned nt = (unsigned)std::min<size_t>(pool.size(), std::max<size_t>(1, n / grain));  // threads worth waking for this map
     const size_t task_len = std::max<size_t>(n / (4 * (size_t)nt), 2048);
 
     // Top of the tree, level by level: the nodes of one level are independent, so they are split in parallel (each node still
@@ -260,45 +316,38 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
         pool.run(split_now.size(), nt, [&](size_t k) {
             Piece& p = pieces[split_now[k]];
             b.note_depth(p.level);
-            const int32_t first = idx[p.off];
+            const Rec first = idx[p.off];
             int axis; float th; size_t nl;
-            if (!b.split(idx.data() + p.off, tmp.data() + p.off, p.len, axis, th, nl)) {
-                p.is_leaf = true; p.leaf_id = first;
+            __m128 sl, sr;
+            if (!b.split(idx.data() + p.off, tmp.data() + p.off, p.len, p.has_sum ? &p.sum : nullptr, axis, th, nl, sl, sr)) {
+                p.is_leaf = true; p.leaf_rec = first;
                 return;
             }
             p.axis = axis; p.th = th;
             p.left = (int)(base + 2 * k); p.right = p.left + 1;
             Piece& l = pieces[p.left];
             Piece& r = pieces[p.right];
-            l.off = p.off; l.len = nl; l.level = p.level + 1;
-            r.off = p.off + nl; r.len = p.len - nl; r.level = p.level + 1;
+            l.off = p.off; l.len = nl; l.level = p.level + 1; l.sum = sl; l.has_sum = true;
+            r.off = p.off + nl; r.len = p.len - nl; r.level = p.level + 1; r.sum = sr; r.has_sum = true;
         });
         frontier.clear();
         for (int pi : split_now)
             if (!pieces[pi].is_leaf) { frontier.push_back(pieces[pi].left); frontier.push_back(pieces[pi].right); }
     }
 
-    // The tasks, largest first.
+    // The tasks, largest first. A sub-tree of m distinct points is m leaves (two slots each) and m − 1 nodes: 3m − 1 slots. Only a
+    // degenerate split (every point of a node on one side — duplicates, kdtree.cpp:66-70) makes it smaller, so positions are laid out
+    // for the full size first and every task writes its sub-tree straight into the final arrays; if one of them comes out
+    // smaller the tasks are run again — from their ranges' original order — into buffers of their own and assembled (the path
+    // every build took before).
     std::sort(tasks.begin(), tasks.end(), [&](int a, int c) { return pieces[a].len > pieces[c].len; });
-    pool.run(tasks.size(), nt, [&](size_t t) {
-        Piece& p = pieces[tasks[t]];
-        p.slots.reserve(3 * p.len);
-        Local loc;
-        b.build(idx.data() + p.off, tmp.data() + p.off, p.len, p.level, p.slots, loc);
-        b.merge(loc);
-        p.n_slots = p.slots.size();
-        p.n_leaves = (size_t)loc.leaves;
-        p.bounded = slot_floats_bounded(p.slots.data(), p.slots.size());
-    });
-
-    // Sizes bottom-up (children have larger indices than their parent), then positions in preorder.
-    for (size_t i = pieces.size(); i-- > 0;) {
-        Piece& p = pieces[i];
-        if (p.is_task) continue;
-        if (p.is_leaf) { p.n_slots = 2; p.n_leaves = 1; }
-        else if (p.left >= 0) { p.n_slots = 1 + pieces[p.left].n_slots + pieces[p.right].n_slots; p.n_leaves = pieces[p.left].n_leaves + pieces[p.right].n_leaves; }
-    }
-    {
+    auto lay_out = [&] {  // sizes bottom-up (children have larger indices than their parent), then positions in preorder
+        for (size_t i = pieces.size(); i-- > 0;) {
+            Piece& p = pieces[i];
+            if (p.is_task) continue;
+            if (p.is_leaf) { p.n_slots = 2; p.n_leaves = 1; }
+            else if (p.left >= 0) { p.n_slots = 1 + pieces[p.left].n_slots + pieces[p.right].n_slots; p.n_leaves = pieces[p.left].n_leaves + pieces[p.right].n_leaves; }
+        }
         std::vector<int> stack{0};
         pieces[0].pos = 0; pieces[0].leaf_pos = 0;
         while (!stack.empty()) {
@@ -312,11 +361,62 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
             stack.push_back(p.right);
             stack.push_back(p.left);
         }
+    };
+    for (int ti : tasks) { pieces[ti].n_slots = 3 * pieces[ti].len - 1; pieces[ti].n_leaves = pieces[ti].len; }
+    lay_out();
+    out.slots.resize(pieces[0].n_slots);
+    out.leaf_slots.resize(pieces[0].n_leaves);
+    std::atomic<bool> direct_ok{true};
+    pool.run(tasks.size(), nt, [&](size_t t) {
+        Piece& p = pieces[tasks[t]];
+        Local loc;
+        size_t n_out = p.pos, n_leaf = p.leaf_pos;
+        b.build(idx.data() + p.off, tmp.data() + p.off, p.len, p.has_sum ? &p.sum : nullptr, p.level, out.slots.data(), n_out, out.leaf_slots.data(), n_leaf, loc);
+        if (n_out - p.pos != p.n_slots) { direct_ok.store(false); return; }  // a degenerate split inside: the layout was too generous
+        b.merge(loc);
+        p.bounded = slot_floats_bounded(out.slots.data() + p.pos, p.n_slots);
+    });
+    const bool direct = direct_ok.load();
+    if (!direct) {
+        b.leaves.store(0);
+        pool.run(tasks.size(), nt, [&](size_t t) {
+            Piece& p = pieces[tasks[t]];
+            p.slots.resize(3 * p.len);
+            // back to the order the first pass found: every node's range is in increasing point index (the root's is, and a stable
+            // partition keeps it), and the variance sums — which pick the axis — must run over it in exactly that order
+            std::sort(idx.begin() + p.off, idx.begin() + p.off + p.len, [](const Rec& x, const Rec& y) { return x.id < y.id; });
+            Local loc;
+            size_t n_out = 0, n_leaf = 0;
+            b.build(idx.data() + p.off, tmp.data() + p.off, p.len, p.has_sum ? &p.sum : nullptr, p.level, p.slots.data(), n_out, nullptr, n_leaf, loc);
+            p.slots.resize(n_out);
+            b.merge(loc);
+            p.n_slots = p.slots.size();
+            p.n_leaves = (size_t)loc.leaves;
+            p.bounded = slot_floats_bounded(p.slots.data(), p.slots.size());
+        });
+        lay_out();
     }
     const size_t total = pieces[0].n_slots;
     out.slots.resize(total);
     out.leaf_slots.resize(pieces[0].n_leaves);
     std::atomic<bool> bounded{true};
+    if (direct) {  // only the top of the tree is left to write: single slots, a few dozen of them
+        for (Piece& p : pieces) {
+            if (p.is_task) { if (!p.bounded) bounded.store(false); continue; }
+            if (p.is_leaf) {
+                Local loc;
+                size_t at = p.pos;
+                Builder::emit_leaf(out.slots.data(), at, p.leaf_rec, loc);
+                b.merge(loc);
+                out.leaf_slots[p.leaf_pos] = (uint32_t)p.pos;
+                if (!slot_floats_bounded(out.slots.data() + p.pos, 2)) bounded.store(false);
+            } else if (p.left >= 0) {
+                uint32_t tb; std::memcpy(&tb, &p.th, 4);
+                out.slots[p.pos] = (uint64_t)tb | ((uint64_t)(((uint32_t)p.axis << 30) | (uint32_t)pieces[p.right].pos) << 32);
+                if (!(std::fabs(p.th) < 1e18f)) bounded.store(false);
+            }
+        }
+    } else
     // Assemble: task outputs are copied (right-child indices rebased by the task's position) in parallel; top nodes are single slots.
     pool.run(pieces.size(), nt, [&](size_t i) {
         Piece& p = pieces[i];
@@ -339,14 +439,15 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
             if (!p.bounded) bounded.store(false);
             std::vector<uint64_t>().swap(p.slots);
         } else if (p.is_leaf) {
-            std::vector<uint64_t> two;
+            uint64_t two[2];
             Local loc;
-            b.emit_leaf(two, p.leaf_id, loc);
+            size_t n_two = 0;
+            Builder::emit_leaf(two, n_two, p.leaf_rec, loc);
             b.merge(loc);
             out.slots[p.pos] = two[0];
             out.slots[p.pos + 1] = two[1];
             out.leaf_slots[p.leaf_pos] = (uint32_t)p.pos;
-            if (!slot_floats_bounded(two.data(), 2)) bounded.store(false);
+            if (!slot_floats_bounded(two, 2)) bounded.store(false);
         } else if (p.left >= 0) {
             uint32_t tb; std::memcpy(&tb, &p.th, 4);
             out.slots[p.pos] = (uint64_t)tb | ((uint64_t)(((uint32_t)p.axis << 30) | (uint32_t)pieces[p.right].pos) << 32);

@@ -72,6 +72,16 @@ constexpr int kFirstChunk = 8, kNextChunk = 4;
 // about what two idle iterations do (3 dispatches of ≈4.6 µs each), and nine iterations — the common case beyond eight — then pay
 // 35 + 15 µs instead of 35 + 45 (tools/single_scan_trace.py).
 inline int next_chunk(const locgpu_batch* b) { return b->n_total == 1 ? 2 : kNextChunk; }
+// ... and sizes its FIRST chunk by the alignment it ran before: a front-end that matches every scan from a good prediction
+// (Lio::AddCloud: 4-5 iterations per scan) used to pay three or four idle iterations, ≈15 µs each, in every call — a sixth of the
+// match stage of the streaming loop (tools/stream_trace.py). One more than last time, between 3 and kFirstChunk; chunking never
+// changes a result (the same kernels run on the same data in the same order), only where the host looks at the flags.
+// LOCGPU_ADAPTIVE_CHUNK=0 switches it off (A/B).
+inline int first_chunk_len(const locgpu_batch* b) {
+    static const bool adaptive = [] { const char* e = getenv("LOCGPU_ADAPTIVE_CHUNK"); return !e || atoi(e) != 0; }();
+    if (!adaptive || b->n_total != 1 || b->sharded || b->last_iterations < 0) return kFirstChunk;
+    return std::min(kFirstChunk, std::max(3, b->last_iterations + 1));
+}
 }  // namespace
 
 namespace locgpu {
@@ -138,6 +148,7 @@ static void free_batch(locgpu_batch* b) {
 }
 
 static int target_join(locgpu_ctx* ctx, bool install = true);  // finishes a pending locgpu_icp_set_target_cloud_async (defined with it, below)
+static void free_target_scratch(locgpu_ctx* ctx);  // the ingest buffers the context keeps between SetInputTarget calls (defined with PendingTarget, below)
 
 extern "C" {
 
@@ -214,6 +225,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)target_join(ctx, false);
+    free_target_scratch(ctx);
     for (hipStream_t st : ctx->slot_stream) if (st) (void)hipStreamSynchronize(st);
     if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
     free_batch(ctx->single);
@@ -239,11 +251,46 @@ void locgpu_destroy(locgpu_ctx* ctx) {
 const char* locgpu_last_error(const locgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 // --------------------------------------------------------------------------------------------- target
+// One target ingest's host side: the deep copy of the points, the packed tree, and — for the asynchronous entry points — the
+// worker thread that builds it. The context keeps ONE of these between ingests (target_scratch): a keyframe front-end re-ingests
+// its ≈35 k-point local map every few scans, and the vectors' capacity (≈1.4 MB: fresh mmaps and page faults per ingest) is
+// worth keeping.
+namespace locgpu {
+struct PendingTarget {
+    std::thread worker;
+    std::vector<float> xyz;
+    PackedKdTree tree;
+    std::string err;
+    bool ok = false;
+};
+}  // namespace locgpu
+
+static locgpu::PendingTarget* take_target_scratch(locgpu_ctx* ctx) {
+    locgpu::PendingTarget* p = ctx->target_scratch;
+    ctx->target_scratch = nullptr;
+    if (!p) p = new locgpu::PendingTarget();
+    p->err.clear();
+    p->ok = false;
+    return p;
+}
+
+static void free_target_scratch(locgpu_ctx* ctx) {
+    delete ctx->target_scratch;  // never holds a running worker (keep_target_scratch joins first)
+    ctx->target_scratch = nullptr;
+}
+
+static void keep_target_scratch(locgpu_ctx* ctx, locgpu::PendingTarget* p) {
+    if (p->worker.joinable()) p->worker.join();
+    // a 10 M-point map's buffers (≈360 MB) go back to the allocator; a local map's stay
+    if (ctx->target_scratch || p->xyz.capacity() > (size_t)3 << 21) delete p;
+    else ctx->target_scratch = p;
+}
+
 // The reference's tree for `pts`, built on the host (kdtree_build.cpp).
-static int build_host_tree(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, PackedKdTree& t) {
+static int build_host_tree(locgpu_ctx* ctx, const void* pts, size_t n, size_t stride_bytes, std::vector<float>& xyz, PackedKdTree& t) {
     if (!pts || n == 0 || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: empty cloud or stride < 12");
     // deep copy (icp_registration.cpp:16 + kdtree.cpp:267 copy too): pack xyz
-    std::vector<float> xyz(3 * n);
+    xyz.resize(3 * n);
     const char* base = (const char*)pts;
     for (size_t i = 0; i < n; ++i) std::memcpy(&xyz[3 * i], base + i * stride_bytes, 12);
     std::string err;
@@ -293,15 +340,6 @@ static hipError_t write_sentinel_leaf(locgpu_ctx* ctx) {
 // filter the next scan — so the build may run on a worker thread. Only the BUILD does: the worker touches its own copy of the points,
 // its own PackedKdTree and the process-wide build pool, nothing of HIP and nothing of the context; every HIP call of the ingest
 // (buffers, H2D, sentinel) is made by the caller's thread in target_join(), which every entry point that reads the target calls first.
-namespace locgpu {
-struct PendingTarget {
-    std::thread worker;
-    std::vector<float> xyz;
-    PackedKdTree tree;
-    std::string err;
-    bool ok = false;
-};
-}  // namespace locgpu
 
 static int install_built_tree(locgpu_ctx* ctx, const PackedKdTree& t) {
     const long long meta[6] = {(long long)t.slots.size(), (long long)t.num_leaves, (long long)t.num_nodes, (long long)t.num_points, t.depth, t.bounded ? 1 : 0};
@@ -328,7 +366,7 @@ static int target_join(locgpu_ctx* ctx, bool install) {
         else if (hipSetDevice(ctx->device) != hipSuccess) rc = LOCGPU_ERR_NO_DEVICE;
         else rc = install_built_tree(ctx, p->tree);
     }
-    delete p;
+    keep_target_scratch(ctx, p);
     return rc;
 }
 
@@ -344,12 +382,14 @@ int locgpu_icp_set_target(locgpu_ctx* ctx, const void* pts, size_t n, size_t str
         fprintf(stderr, "[locgpu ingest] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
     };
-    PackedKdTree t;
-    int rc = build_host_tree(ctx, pts, n, stride_bytes, t);
-    if (rc != LOCGPU_OK) return rc;
+    locgpu::PendingTarget* p = take_target_scratch(ctx);
+    int rc = build_host_tree(ctx, pts, n, stride_bytes, p->xyz, p->tree);
     lap("host build");
-    rc = install_built_tree(ctx, t);
-    lap("device buffers + H2D");
+    if (rc == LOCGPU_OK) {
+        rc = install_built_tree(ctx, p->tree);
+        lap("device buffers + H2D");
+    }
+    keep_target_scratch(ctx, p);
     return rc;
 }
 
@@ -358,7 +398,7 @@ int locgpu_icp_set_target_async(locgpu_ctx* ctx, const void* pts, size_t n, size
     if (!ctx) return LOCGPU_ERR_INVALID;
     if (!pts || n == 0 || stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "icp_set_target: empty cloud or stride < 12");
     (void)target_join(ctx, false);  // an earlier pending ingest is superseded
-    auto* p = new locgpu::PendingTarget();
+    locgpu::PendingTarget* p = take_target_scratch(ctx);
     p->xyz.resize(3 * n);  // the deep copy of SetInputTarget (icp_registration.cpp:16)
     const char* base = (const char*)pts;
     for (size_t i = 0; i < n; ++i) std::memcpy(&p->xyz[3 * i], base + i * stride_bytes, 12);
@@ -378,10 +418,11 @@ int locgpu_icp_set_target_bcast(locgpu_ctx* ctx, const void* pts, size_t n, size
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     hipStream_t s = ctx->stream;
     PackedKdTree t;
+    std::vector<float> xyz;
     long long meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [6] = the root's status
     int rc = LOCGPU_OK;
     if (ctx->comm_rank == root) {
-        rc = build_host_tree(ctx, pts, n, stride_bytes, t);
+        rc = build_host_tree(ctx, pts, n, stride_bytes, xyz, t);
         if (rc == LOCGPU_OK) { meta[0] = (long long)t.slots.size(); meta[1] = (long long)t.num_leaves; meta[2] = (long long)t.num_nodes; meta[3] = (long long)t.num_points; meta[4] = t.depth; meta[5] = t.bounded ? 1 : 0; }
         meta[6] = rc;
     }
@@ -963,7 +1004,7 @@ static int enqueue_chunk(locgpu_ctx* ctx, locgpu_batch* b, bool first_chunk) {
             it.n_active = na;
         }
     }
-    const int todo = std::min(first_chunk ? kFirstChunk : next_chunk(b), P.prm.max_iteration - P.launched);
+    const int todo = std::min(first_chunk ? first_chunk_len(b) : next_chunk(b), P.prm.max_iteration - P.launched);
     for (int c = 0; c < todo; ++c)
         if (!it.launch(1)) return LOCGPU_ERR_NO_DEVICE;
     P.ev_used = it.ev_used;
@@ -1020,6 +1061,7 @@ static int align_finish(locgpu_ctx* ctx, locgpu_batch* b, double* out_poses, loc
         if (rc != LOCGPU_OK) return rc;
     }
     write_results(b, P.init_poses.data(), out_poses, stats);
+    if (b->n_total == 1 && P.prm.max_iteration > 0) b->last_iterations = b->h_state[0].iterations;
     return LOCGPU_OK;
 }
 
@@ -1547,7 +1589,7 @@ int locgpu_icp_set_target_cloud_async(locgpu_ctx* ctx, const locgpu_cloud* targe
     if (!hip_ok(ctx, cloud_stage(ctx, target->n, &stage), "pinned staging")) return LOCGPU_ERR_OOM;
     LOCGPU_HIP(ctx, hipMemcpyAsync(stage, target->d, target->n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     LOCGPU_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    auto* p = new locgpu::PendingTarget();
+    locgpu::PendingTarget* p = take_target_scratch(ctx);
     p->xyz.resize(3 * target->n);  // the deep copy of SetInputTarget (icp_registration.cpp:16): the staging block is free again after it
     for (size_t i = 0; i < target->n; ++i) std::memcpy(&p->xyz[3 * i], &stage[i], 12);
     const size_t n = target->n;

@@ -244,12 +244,15 @@ def cpp_stream_section(n_scans, kf_every, num_kfs, leaf, passes=5, workdir="/tmp
     for mode, name in ((0, "sequential"), (1, "two_stage_pipeline")):
         f_out = os.path.join(workdir, "locgpu_stream_out_%d.bin" % mode)
         r = subprocess.run([exe, f_scans, f_poses, str(n_scans), str(scans.shape[1]), str(kf_every), str(num_kfs), str(leaf), str(mode), str(passes), f_out],
-                           capture_output=True, text=True, timeout=600)
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, STREAM_PIPELINE_TIMES="1"))
         if r.returncode != 0:
             raise RuntimeError("stream_pipeline mode %d failed: %s" % (mode, r.stderr[-500:]))
         j = json.loads(r.stdout.strip().splitlines()[-1])
         rates = sorted(j["scans_per_s_all_passes"])
         out[name] = dict(scans_per_s=rates[len(rates) // 2], scans_per_s_all_passes=j["scans_per_s_all_passes"])
+        stage = [ln for ln in r.stderr.splitlines() if ln.startswith("per scan [ms]")]
+        if stage:
+            out[name]["last_pass_host_times"] = stage[-1]
         got[mode] = np.fromfile(f_out, dtype=np.float64).reshape(n_scans, 7)
     out["poses_identical"] = bool(np.array_equal(got[0], got[1]))
     out["reported"] = "median of %d passes after one untimed pass; scans / wall time of the whole loop, C++ caller (tests/cpp/stream_pipeline.cpp)" % passes
