@@ -21,7 +21,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <condition_variable>
 #include <functional>
@@ -281,22 +283,150 @@ private:
     static std::vector<std::unique_ptr<BuildScratch>>& free_list() { static std::vector<std::unique_ptr<BuildScratch>> f; return f; }
 };
 
+// The build every map without duplicate points takes. A sub-tree of m distinct points is m leaves (two slots each) and m − 1 nodes:
+// 3m − 1 slots, so in preorder a node at slot s with nl points on its left has its left child at s + 1 and its right child at
+// s + 3·nl — known the moment the node is split. Nothing has to wait for a level to finish or for sizes to come back: a thread
+// splits a node, writes its slot, hands the right child to a shared list and goes on with the left one; ranges of at most
+// task_len points are finished recursively, straight into the final arrays. The threads of the pool are woken ONCE per build
+// (behind the root's split, which nobody can help with) and look for work until none is outstanding — the level-by-level
+// scheme below paid a condition-variable round trip per level, a third of a 35 k-point build.
+// Returns false when a degenerate split (every point of a node on one side — duplicates, kdtree.cpp:66-70) made a sub-tree
+// smaller than that: the caller restores the records and takes the level-by-level path, which measures sizes before it places.
+struct WorkItem { size_t off, len, pos, leaf_pos; int level; __m128 sum; bool has_sum; };
+
+bool build_direct(Builder& b, Rec* a, Rec* tmp, size_t n, Pool& pool, unsigned nt, size_t task_len, PackedKdTree& out, bool& all_bounded) {
+    out.slots.resize(3 * n - 1);
+    out.leaf_slots.resize(n);
+    uint64_t* slots = out.slots.data();
+    uint32_t* leaves = out.leaf_slots.data();
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::vector<WorkItem> queue;
+    queue.reserve(1024);
+    long outstanding = 1;               // items in the list or being worked on; guarded by qmu
+    std::atomic<long> listed{1};        // queue.size(), readable without the lock
+    std::atomic<bool> finished{false};  // outstanding reached 0
+    std::atomic<bool> ok{true}, bounded{true};
+    queue.push_back(WorkItem{0, n, 0, 0, 1, _mm_setzero_ps(), false});
+    auto take = [&](WorkItem& w) {  // under qmu: the largest range first — it has the longest way to go
+        if (queue.empty()) return false;
+        size_t best = 0;
+        for (size_t i = 1; i < queue.size(); ++i)
+            if (queue[i].len > queue[best].len) best = i;
+        w = queue[best];
+        queue[best] = queue.back();
+        queue.pop_back();
+        listed.store((long)queue.size(), std::memory_order_relaxed);
+        return true;
+    };
+    pool.run(nt, nt, [&](size_t) {
+        Local loc;
+        for (;;) {
+            WorkItem w{};
+            bool got = false;
+            // An idle thread polls for a moment — work turns up every few µs while the top of the tree is being split, and a futex
+            // wake-up (tens of µs each, one after the other down the right spine) is what the level-by-level scheme lost its time
+            // to — and then SLEEPS: a helper spinning on a shared or over-subscribed core slows the thread that has the work.
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned it = 1;; ++it) {
+                if (listed.load(std::memory_order_acquire) > 0) {
+                    std::lock_guard<std::mutex> lk(qmu);
+                    got = take(w);
+                }
+                if (got || finished.load(std::memory_order_acquire) || !ok.load(std::memory_order_relaxed)) break;
+                _mm_pause();
+                if ((it & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
+            }
+            if (!got && !finished.load(std::memory_order_acquire) && ok.load(std::memory_order_relaxed)) {
+                std::unique_lock<std::mutex> lk(qmu);
+                qcv.wait(lk, [&] { return !queue.empty() || outstanding == 0 || !ok.load(std::memory_order_relaxed); });
+                if (ok.load(std::memory_order_relaxed)) got = take(w);
+            }
+            if (!got) break;
+            while (ok.load(std::memory_order_relaxed)) {  // down the left spine
+                if (w.len <= task_len) {
+                    size_t n_out = w.pos, n_leaf = w.leaf_pos;
+                    b.build(a + w.off, tmp + w.off, w.len, w.has_sum ? &w.sum : nullptr, w.level, slots, n_out, leaves, n_leaf, loc);
+                    if (n_out - w.pos != 3 * w.len - 1) ok.store(false);
+                    else if (!slot_floats_bounded(slots + w.pos, 3 * w.len - 1)) bounded.store(false);
+                    break;
+                }
+                if (w.level > loc.depth) loc.depth = w.level;
+                int axis; float th; size_t nl;
+                __m128 sl, sr;
+                if (!b.split(a + w.off, tmp + w.off, w.len, w.has_sum ? &w.sum : nullptr, axis, th, nl, sl, sr)) { ok.store(false); break; }
+                const size_t right_pos = w.pos + 3 * nl;
+                uint32_t tb; std::memcpy(&tb, &th, 4);
+                slots[w.pos] = (uint64_t)tb | ((uint64_t)(((uint32_t)axis << 30) | (uint32_t)right_pos) << 32);
+                if (!(std::fabs(th) < 1e18f)) bounded.store(false);
+                {
+                    std::lock_guard<std::mutex> lk(qmu);
+                    ++outstanding;
+                    queue.push_back(WorkItem{w.off + nl, w.len - nl, right_pos, w.leaf_pos + nl, w.level + 1, sr, true});
+                    listed.store((long)queue.size(), std::memory_order_release);
+                }
+                qcv.notify_one();
+                w = WorkItem{w.off, nl, w.pos + 1, w.leaf_pos, w.level + 1, sl, true};
+            }
+            bool last;
+            {
+                std::lock_guard<std::mutex> lk(qmu);
+                last = --outstanding == 0;
+                if (last) finished.store(true, std::memory_order_release);
+            }
+            if (last || !ok.load(std::memory_order_relaxed)) qcv.notify_all();
+        }
+        b.merge(loc);
+    });
+    all_bounded = bounded.load();
+    return ok.load();
+}
+
 bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::string& err) {
     out.slots.clear(); out.leaf_slots.clear();  // a PackedKdTree that is reused keeps its capacity (same reason as BuildScratch)
     out.num_leaves = out.num_nodes = out.num_points = 0; out.depth = 0; out.bounded = true;
     if (n == 0) { err = "empty target cloud"; return false; }
     // 3n-1 slots of 8 bytes must stay below 4 GiB: the search kernel addresses the tree through a 32-bit buffer offset
     if (n >= (1ull << 29) / 3) { err = "target cloud too large (the packed tree must stay below 4 GiB)"; return false; }
+    static const bool times = std::getenv("LOCGPU_BUILD_TIMES") != nullptr;  // diagnostic: phase times of every build on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    double t_phase[5] = {0, 0, 0, 0, 0};  // records, root split, further top levels, tasks, lay-out + top slots
+    auto lap = [&](int ph) {
+        if (!times) return;
+        const auto t = std::chrono::steady_clock::now();
+        t_phase[ph] += std::chrono::duration<double, std::micro>(t - t_prev).count();
+        t_prev = t;
+    };
     Builder b;
     struct ScratchHold { std::unique_ptr<BuildScratch> s = ScratchCache::acquire(); ~ScratchHold() { ScratchCache::release(std::move(s)); } } hold;
     std::vector<Rec>& idx = hold.s->a;   // the points with their indices, reordered node by node
     std::vector<Rec>& tmp = hold.s->tmp;  // partition buffer of the same size
     if (idx.size() < n) { idx.resize(n); tmp.resize(n); }
     for (size_t i = 0; i < n; ++i) idx[i] = Rec{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], (int32_t)i};
+    lap(0);
 
     Pool& pool = Pool::get();
     static const size_t grain = [] { const char* e = std::getenv("LOCGPU_BUILD_GRAIN"); const long v = e ? std::atol(e) : 0; return v >= 256 ? (size_t)v : (size_t)2048; }();
     const unsigned nt = (unsigned)std::min<size_t>(pool.size(), std::max<size_t>(1, n / grain));  // threads worth waking for this map
+    {
+        bool all_bounded = true;
+        static const size_t min_task = [] { const char* e = std::getenv("LOCGPU_BUILD_TASK"); const long v = e ? std::atol(e) : 0; return v >= 16 ? (size_t)v : (size_t)1024; }();
+        if (build_direct(b, idx.data(), tmp.data(), n, pool, nt, std::max<size_t>(n / (8 * (size_t)nt), min_task), out, all_bounded)) {
+            lap(3);
+            if (times) std::fprintf(stderr, "[locgpu build] %zu points, %u threads: records %.0f us | direct build %.0f us\n", n, nt, t_phase[0], t_phase[3]);
+            out.num_leaves = (size_t)b.leaves.load();
+            out.num_nodes = out.slots.size() - out.num_leaves;
+            out.depth = b.depth.load();
+            out.num_points = n;
+            out.bounded = all_bounded;
+            return true;
+        }
+        // duplicates: start again from the records' original order, sizes first
+        b.leaves.store(0);
+        b.depth.store(0);
+        for (size_t i = 0; i < n; ++i) idx[i] = Rec{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], (int32_t)i};
+        lap(0);
+    }
     const size_t task_len = std::max<size_t>(n / (4 * (size_t)nt), 2048);
 
     // Top of the tree, level by level: the nodes of one level are independent, so they are split in parallel (each node still
@@ -333,6 +463,7 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
         frontier.clear();
         for (int pi : split_now)
             if (!pieces[pi].is_leaf) { frontier.push_back(pieces[pi].left); frontier.push_back(pieces[pi].right); }
+        lap(split_now.size() == 1 && split_now[0] == 0 ? 1 : 2);
     }
 
     // The tasks, largest first. A sub-tree of m distinct points is m leaves (two slots each) and m − 1 nodes: 3m − 1 slots. Only a
@@ -377,6 +508,7 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
         p.bounded = slot_floats_bounded(out.slots.data() + p.pos, p.n_slots);
     });
     const bool direct = direct_ok.load();
+    lap(3);
     if (!direct) {
         b.leaves.store(0);
         pool.run(tasks.size(), nt, [&](size_t t) {
@@ -454,6 +586,10 @@ bool build_packed_kdtree(const float* xyz, size_t n, PackedKdTree& out, std::str
             if (!(std::fabs(p.th) < 1e18f)) bounded.store(false);
         }
     });
+    lap(4);
+    if (times)
+        std::fprintf(stderr, "[locgpu build] %zu points, %u threads, %zu tasks: records %.0f us | root split %.0f | further top levels %.0f | tasks %.0f | lay-out + top slots %.0f\n", n, nt,
+                     tasks.size(), t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4]);
     out.num_leaves = (size_t)b.leaves.load();
     out.num_nodes = total - out.num_leaves;  // internal (1 slot) + leaves (2 slots) ⇒ nodes = slots − leaves
     out.depth = b.depth.load();

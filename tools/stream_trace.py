@@ -61,9 +61,12 @@ def main():
     out = ["# tools/stream_trace.py --mode %d: %d scans, last pass %.1f us on the GPU clock (%.1f us per scan)" % (a.mode, a.scans, (t_last - t_first) / 1e3, (t_last - t_first) / 1e3 / a.scans)]
     if host:
         out.append("# host side, " + host[-1])
+    def short(kn):
+        return kn.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("locgpu::", "").replace("rocprim::ROCPRIM_400200_NS::detail::", "rocprim::")
+
     per, busy = {}, 0.0
     for q in rows:
-        name = q["Kernel_Name"].split("(")[0].replace("void ", "").replace("locgpu::", "")
+        name = short(q["Kernel_Name"])
         dur = (int(q["End_Timestamp"]) - int(q["Start_Timestamp"])) / 1e3
         k = name.split("<")[0]
         per[k] = (per.get(k, (0, 0.0))[0] + 1, per.get(k, (0, 0.0))[1] + dur)
@@ -76,7 +79,7 @@ def main():
         st = int(q["Start_Timestamp"])
         if st < mid or st > mid + a.window_us * 1e3:
             continue
-        name = q["Kernel_Name"].split("(")[0].replace("void ", "").replace("locgpu::", "")[:64]
+        name = short(q["Kernel_Name"])[:64]
         dur = (int(q["End_Timestamp"]) - st) / 1e3
         gap = 0.0 if prev_end is None else (st - prev_end) / 1e3
         prev_end = max(prev_end or 0, int(q["End_Timestamp"]))
