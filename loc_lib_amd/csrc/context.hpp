@@ -107,6 +107,8 @@ struct locgpu_batch {
     double* d_plane_cache = nullptr;             // [pitch][4]
     unsigned long long* d_same_mask = nullptr;   // [n_scans][ceil(max_n / 64)]
     bool cache_chain = false;                    // the previous iteration of the running alignment filled the cache
+    const float4* d_src_ext = nullptr;           // one-scan batches: the points stay where the caller's cloud holds them (no copy into d_src); nullptr = d_src
+    bool counters_clean = false;                 // the search stage's work-list counters are known to be zero (the last alignment ran to its end)
     int last_iterations = -1;                    // one-scan batches: iterations of the previous alignment run on this batch (-1: none yet) — sizes the next first chunk
     double* d_partials = nullptr;  // [n_scans][blocks_per_scan][kAccW]
     double* d_hb = nullptr;        // [n_scans][44]

@@ -72,6 +72,7 @@ constexpr int kFirstChunk = 8, kNextChunk = 4;
 // about what two idle iterations do (3 dispatches of ≈4.6 µs each), and nine iterations — the common case beyond eight — then pay
 // 35 + 15 µs instead of 35 + 45 (tools/single_scan_trace.py).
 inline int next_chunk(const locgpu_batch* b) { return b->n_total == 1 ? 2 : kNextChunk; }
+inline const float4* batch_src(const locgpu_batch* b) { return b->d_src_ext ? b->d_src_ext : b->d_src; }
 // ... and sizes its FIRST chunk by the alignment it ran before: a front-end that matches every scan from a good prediction
 // (Lio::AddCloud: 4-5 iterations per scan) used to pay three or four idle iterations, ≈15 µs each, in every call — a sixth of the
 // match stage of the streaming loop (tools/stream_trace.py). One more than last time, between 3 and kFirstChunk; chunking never
@@ -772,7 +773,7 @@ bool IterLauncher::launch(int do_update) {
     if (b->n_scans == 0) {
         mark(true);  // nothing local: this rank only takes part in the exchange below
     } else if (!ndt) {
-        SearchArgs sa{ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ctx->depth, b->d_src, b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, k, alpha_eff,
+        SearchArgs sa{ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ctx->depth, batch_src(b), b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, k, alpha_eff,
                       prm.method == LOCGPU_P2P ? 1 : 0, ctx->count_visits ? ctx->d_visits : nullptr, b->d_redo_list, b->d_redo_count,
                       b->d_redo_list2, b->d_redo_count + 1, ctx->d_search_stats};
         const bool grid_mode = alpha_eff < 0.f && ctx->tree_bounded;
@@ -814,7 +815,7 @@ bool IterLauncher::launch(int do_update) {
         if (sa.touched) launch_count_touched(sa.touched, (ctx->tree_slots + 2 + 31) / 32, sa.visit_totals, s);
         mark(true);
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
-        AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
+        AccumArgs aa{ctx->d_tree, batch_src(b), b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
         aa.active = active; aa.n_active = n_active;
         if (cached && plane_cache_mode() != 3) { aa.plane_cache = b->d_plane_cache; aa.same_mask = b->d_same_mask; aa.use_cache = plane_cache_mode() == 2 ? 0 : sa.have_previous; }
         b->cache_chain = cached;
@@ -823,10 +824,10 @@ bool IterLauncher::launch(int do_update) {
     } else {
         mark(true);  // NDT has no separate search kernel: search slot stays empty
         if (prm.method == 4)
-            launch_inc_accum(ctx->inc, ctx->ndt_opts.res_outlier_th, ctx->ndt_opts.nearby_type == 0 ? 1 : 7, b->d_src, b->d_counts, st_local,
+            launch_inc_accum(ctx->inc, ctx->ndt_opts.res_outlier_th, ctx->ndt_opts.nearby_type == 0 ? 1 : 7, batch_src(b), b->d_counts, st_local,
                              b->max_n, b->n_scans, b->d_partials, s);
         else
-            n_partial_blocks = launch_ndt_accum(ctx->ndt, b->d_src, b->d_counts, st_local, b->max_n, b->n_scans, b->d_partials, s);
+            n_partial_blocks = launch_ndt_accum(ctx->ndt, batch_src(b), b->d_counts, st_local, b->max_n, b->n_scans, b->d_partials, s);
     }
     mark();
     if (b->sharded) {
@@ -1032,7 +1033,8 @@ static int align_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_pose
     init_states(b, init_poses);
     // the search stage's work-list counters: zero once per alignment, whatever an earlier call that failed between a search and
     // its solve kernel left behind (the solve kernel re-zeroes them after every search)
-    if (!ndt) LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 4 * sizeof(unsigned int), b->stream));
+    if (!ndt && !b->counters_clean) LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 4 * sizeof(unsigned int), b->stream));
+    b->counters_clean = false;  // until this alignment has run to its end
     if (P.graph) { const int rc = ensure_graphs(ctx, b, prm, k, alpha_eff, ndt); if (rc != LOCGPU_OK) return rc; }
     if (prm.max_iteration > 0) { const int rc = enqueue_chunk(ctx, b, true); if (rc != LOCGPU_OK) return rc; }
     P.active = true;
@@ -1061,6 +1063,7 @@ static int align_finish(locgpu_ctx* ctx, locgpu_batch* b, double* out_poses, loc
         if (rc != LOCGPU_OK) return rc;
     }
     write_results(b, P.init_poses.data(), out_poses, stats);
+    b->counters_clean = !P.ndt && !ctx->count_visits && P.alpha_eff >= 0.f && !b->sharded;  // every search was followed by its solve kernel, which zeroes them (a one-scan front-end saves a fill launch per call)
     if (b->n_total == 1 && P.prm.max_iteration > 0) b->last_iterations = b->h_state[0].iterations;
     return LOCGPU_OK;
 }
@@ -1146,6 +1149,7 @@ static int single_batch(locgpu_ctx* ctx, const void* src, size_t n, size_t strid
     const int rc = single_reserve(ctx, n, &b);
     if (rc != LOCGPU_OK) return rc;
     pack_points((const char*)src, stride_bytes, n, b->h_src);
+    b->d_src_ext = nullptr;
     b->counts[0] = (int)n;
     LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_src, b->h_src, n * sizeof(float4), hipMemcpyHostToDevice, b->stream));
     LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_counts, b->counts.data(), sizeof(int), hipMemcpyHostToDevice, b->stream));
@@ -1159,7 +1163,10 @@ static int single_batch_dev(locgpu_ctx* ctx, const float4* d_src, size_t n, locg
     const int rc = single_reserve(ctx, n, &b);
     if (rc != LOCGPU_OK) return rc;
     b->counts[0] = (int)n;
-    LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_src, d_src, n * sizeof(float4), hipMemcpyDeviceToDevice, b->stream));
+    // The call that follows is synchronous and only reads the points: they stay where the cloud holds them (a D2D copy was one more
+    // dispatch in front of every match of the streaming loop). A captured graph has the batch's own buffer in its kernel arguments.
+    b->d_src_ext = ctx->use_graph ? nullptr : d_src;
+    if (!b->d_src_ext) LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_src, d_src, n * sizeof(float4), hipMemcpyDeviceToDevice, b->stream));
     LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_counts, b->counts.data(), sizeof(int), hipMemcpyHostToDevice, b->stream));
     *out = b;
     return LOCGPU_OK;
@@ -1222,6 +1229,7 @@ int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* poses, c
     { const int urc = batch_ready(ctx, b); if (urc != LOCGPU_OK) return urc; }
     if (b->pending.active) return fail(ctx, LOCGPU_ERR_INVALID, "icp_hb_batch: an alignment of this batch has been begun and not finished");
     init_states(b, poses);
+    b->counters_clean = false;
     LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 4 * sizeof(unsigned int), b->stream));
     LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, b->stream));
     IterLauncher it{ctx, b, prm, k, alpha_eff};
