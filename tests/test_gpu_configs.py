@@ -751,6 +751,56 @@ def test_later_chunks_launch_only_the_open_scans(tmp_path):
         assert np.array_equal(outs["list"][name + "_flight"][:len(it)], outs["list"][name])
 
 
+def test_one_scan_calls_do_not_depend_on_the_call_before(api, synth):
+    """Round 4: a one-scan alignment sizes its first chunk of iterations by the call before it (a streaming front-end converges in 4-5
+    iterations and used to pay for eight), reads a resident cloud's points in place, and skips the zeroing of the search stage's
+    work-list counters when the previous alignment ran to its end. None of that may show in a result: calls with far, exact and
+    near initial poses — 10+, 1-2 and a handful of iterations — in every order, through the resident-cloud entry point, the host
+    pointer entry point and a one-scan batch, with an H/B evaluation and an NDT call in between, give the poses, iteration counts
+    and dx norms of the same call made first on a fresh context, bit for bit."""
+    m = synth.make_local_map(300000, 5, half=40.0)
+    scan = synth.make_scan(5, crop_half=36.0)[::3].copy()
+    xyzi = np.concatenate([scan[:, :3], np.zeros((len(scan), 1), np.float32)], axis=1).astype(np.float32)
+    truth, init = synth.make_pose(5)
+    far = init.copy(); far[4:] += [0.6, -0.5, 0.1]
+    opts = api.icp_opts(method=api.P2PLANE)
+    inits = dict(far=far, exact=truth, near=init)
+
+    def fresh(name):
+        ctx = api.Context(0)
+        ctx.icp_set_target(m)
+        c = api.Cloud(ctx, xyzi)
+        r = ctx.icp_align_cloud(c, inits[name], opts)
+        c.close(); ctx.close()
+        return r
+
+    want = {k: fresh(k) for k in inits}
+    assert want["far"][1]["iterations"] > 8 and want["exact"][1]["iterations"] <= 3, (want["far"][1], want["exact"][1])
+
+    def same(got, name):
+        assert np.array_equal(got[0], want[name][0]), name
+        for key in ("iterations", "converged", "last_effective_num", "last_dx_norm"):
+            assert got[1][key] == want[name][1][key], (name, key)
+
+    ctx = api.Context(0)
+    ctx.icp_set_target(m)
+    ctx.ndt_set_target(m)
+    c = api.Cloud(ctx, xyzi)
+    b = ctx.batch([scan])
+    order = ["exact", "far", "near", "near", "far", "exact", "exact", "near", "far", "far"]
+    for i, name in enumerate(order):
+        same(ctx.icp_align_cloud(c, inits[name], opts), name)
+        if i % 3 == 1:
+            p, st = ctx.icp_align(scan, inits[name], opts)            # host pointer entry: the same reusable one-scan batch, its own buffer
+            same((p, st), name)
+        if i % 3 == 2:
+            ctx.icp_hb_batch(b, inits[name][None], opts)              # leaves through the solve kernel without an update
+            ctx.ndt_align_batch(b, inits[name][None])
+        pb, stb = ctx.icp_align_batch(b, inits[name][None], opts)
+        same((pb[0], stb[0]), name)
+    b.close(); c.close(); ctx.close()
+
+
 def test_secular_plane_fit_agrees_with_the_four_column_fit(tmp_path):
     """Round 4: the P2Plane fit kernel finds FitPlane's 4-vector (math_utils.h:112-136) from the 3×3 eigen-decomposition of the centred
     neighbours plus the secular equation of the homogeneous column (device_math.hpp plane_null_vector_secular; LOCGPU_PLANE_FIT=1, the
