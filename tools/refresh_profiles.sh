@@ -17,6 +17,11 @@ timeout 600 python tests/perf/pipeline_microbench.py 2>/dev/null | grep '^{' > $
 timeout 1500 python3 tests/perf/baseline_table.py --out $O/baseline_table.json > $O/baseline_table.md 2>/dev/null
 timeout 300 python3 tools/iter_trace.py --out $O/iteration_trace.txt > /dev/null 2>&1
 timeout 300 python3 tools/single_scan_trace.py --out $O/single_scan_trace.txt > /dev/null 2>&1
+timeout 300 python3 tools/stream_trace.py --mode 0 --window-us 1500 --out $O/stream_trace_sequential.txt > /dev/null 2>&1
+timeout 300 python3 tools/stream_trace.py --mode 1 --window-us 1500 --out $O/stream_trace_two_stage.txt > /dev/null 2>&1
+(timeout 120 ./tools/ubench/tree_build_bench 35133 300; LOCGPU_BUILD_TIMES=1 timeout 60 ./tools/ubench/tree_build_bench 35133 3 2>&1 | tail -4; LOCGPU_BUILD_THREADS=1 timeout 120 ./tools/ubench/tree_build_bench 35133 100; timeout 200 ./tools/ubench/tree_build_bench 10000000 3) > $O/tree_build.txt 2>&1
+timeout 120 ./tools/ubench/plane_fit_accuracy > $O/plane_fit_accuracy.txt 2>&1
+for f in 0 1; do LOCGPU_PLANE_FIT=$f timeout 200 python bench.py --steps 20 --warmup 5 --pipeline 1 --resident --no-cpu-baseline 2>/dev/null | grep '^{' > $O/bench_plane_fit$f.json; done
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --traffic none > /dev/null 2>&1
 cp $O/prof/*/bench_kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null || cp $O/prof/bench_kernel_stats.csv $O/bench_kernel_stats.csv; rm -rf $O/prof
