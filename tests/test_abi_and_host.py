@@ -120,6 +120,48 @@ def test_packed_tree_equals_oracle_tree(api, locref, synth, case):
     np.testing.assert_array_equal(p, p2)
 
 
+def test_packed_tree_equals_oracle_tree_randomised(api, locref):
+    """Round 4 rewrote the host build (contiguous point records, SSE lanes, a child's sum taken in its parent's partition pass, no level
+    barriers: positions are laid out for 3m − 1 slots per m-point sub-tree, duplicates fall back to the level-by-level path). Forty
+    seeded clouds — 1 … 60 000 points; uniform, planar, clustered, on a lattice (ties on every axis), a few to most of the points
+    duplicated, all points equal, one coordinate constant, huge and tiny magnitudes — must give the oracle's tree: axes, point order,
+    counts, depth, and split thresholds BIT for bit."""
+    rng = np.random.RandomState(20260)
+    sizes = [1, 2, 3, 4, 5, 7, 16, 33, 100, 511, 1024, 2049, 5000, 20000, 60000]
+    kinds = ["uniform", "planar", "clusters", "lattice", "dups_few", "dups_most", "all_equal", "const_axis", "huge", "tiny"]
+    for case in range(40):
+        n = sizes[case % len(sizes)]
+        kind = kinds[(case * 7 + case // len(sizes)) % len(kinds)]
+        pts = (rng.rand(n, 3) * 50 - 25).astype(np.float32)
+        if kind == "planar":
+            pts[:, 2] = (0.02 * rng.randn(n)).astype(np.float32)
+        elif kind == "clusters":
+            c = (rng.rand(max(1, n // 200), 3) * 80).astype(np.float32)
+            pts = (c[rng.randint(0, len(c), n)] + 0.05 * rng.randn(n, 3)).astype(np.float32)
+        elif kind == "lattice":
+            pts = rng.randint(0, 6, size=(n, 3)).astype(np.float32)
+        elif kind == "dups_few" and n > 3:
+            pts[n // 3: n // 3 + max(2, n // 20)] = pts[n // 3]
+        elif kind == "dups_most" and n > 3:
+            pts = pts[rng.randint(0, max(2, n // 50), n)]
+        elif kind == "all_equal":
+            pts[:] = pts[0]
+        elif kind == "const_axis":
+            pts[:, rng.randint(0, 3)] = np.float32(3.25)
+        elif kind == "huge":
+            pts *= np.float32(1e15)
+        elif kind == "tiny":
+            pts *= np.float32(1e-20)
+        slots, info = _packed_tree(api, pts)
+        tree = locref.KdTree(pts)
+        assert tuple(int(v) for v in info) == (tree.num_leaves, tree.num_nodes, tree.depth), (case, kind, n)
+        a, t, p = tree.dump()
+        a2, t2, p2, _ = _preorder(slots)
+        assert np.array_equal(a, a2), (case, kind, n)
+        assert np.array_equal(t.view(np.uint32), t2.view(np.uint32)), (case, kind, n)
+        assert np.array_equal(p, p2), (case, kind, n)
+
+
 def test_packed_tree_child_links_reproduce_knn(api, locref):
     """Walk the packed slots (left = slot+1, right = stored index) with the reference's DFS in pure Python (small case)."""
     rng = np.random.RandomState(8)
