@@ -117,6 +117,12 @@ static int ensure_grid(locgpu_ctx* ctx) {
     return LOCGPU_OK;
 }
 
+// Zero-fill of device memory that is COMPLETE when the call returns (see alloc_batch: a plain hipMemset is not, and is not ordered
+// with the context's non-blocking streams either).
+static bool fill_now(locgpu_ctx* ctx, void* p, size_t bytes, const char* what) {
+    return hip_ok(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream), what) && hip_ok(ctx, hipStreamSynchronize(ctx->stream), what);
+}
+
 static void free_batch(locgpu_batch* b) {
     if (!b) return;
     upload_free_batch(b);
@@ -577,8 +583,12 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_total * 44 * sizeof(double)), "hipHostMalloc hb") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipHostMalloc active") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipMalloc active") &&
-              hip_ok(ctx, hipMemset(b->d_counts, 0, std::max(n_scans, 1) * sizeof(int)), "hipMemset counts") &&
-              hip_ok(ctx, hipMemset(b->d_redo_count, 0, 4 * sizeof(unsigned int)), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
+              // hipMemset runs on the NULL stream and returns before it has run; the context's streams are non-blocking, i.e. NOT ordered
+              // behind it — the first upload of the scan counts could be overtaken by this very fill (the first alignment of a fresh
+              // batch then saw a scan of zero points and ran its 20 iterations on nothing; once in ≈1000 first calls, found by
+              // tools/fuzz_align.py --cases 120 in round 4). fill_now: on the context's stream, and waited for.
+              fill_now(ctx, b->d_counts, std::max(n_scans, 1) * sizeof(int), "hipMemset counts") &&
+              fill_now(ctx, b->d_redo_count, 4 * sizeof(unsigned int), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
     // Spill records of the search kernel's stragglers (launch.hpp SpillBuf; opt-in with LOCGPU_WALK_STOP): batches of at least 16384
     // waves of queries; every wave owns room for the lanes it may hand over: 16 + 16 + 40 + 8 x 24 rows = 264 B per record — 0.97 GB
     // for 256 full scans at 8 lanes — plus one counter per wave
@@ -1370,7 +1380,7 @@ int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset) {
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_search_stats) {
         LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_search_stats, kSearchStatSlots * sizeof(unsigned long long)));
-        LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, kSearchStatSlots * sizeof(unsigned long long)));
+        if (!fill_now(ctx, ctx->d_search_stats, kSearchStatSlots * sizeof(unsigned long long), "hipMemset search stats")) return LOCGPU_ERR_NO_DEVICE;
     }
     for (hipStream_t st : ctx->slot_stream) LOCGPU_HIP(ctx, hipStreamSynchronize(st));
     unsigned long long h[kSearchStatSlots];
@@ -1383,7 +1393,7 @@ int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset) {
         fprintf(stderr, "[locgpu stamp] %llu queries in %llu waves: %.2f rounds per lane, %.2f per wave; lane efficiency %.3f\n", h[0], h[12], (double)h[4] / (double)h[0],
                 (double)h[9] / (double)h[12], (double)h[4] / (double)std::max<unsigned long long>(h[13], 1ull));
     if (getenv("LOCGPU_WALK_DEBUG")) fprintf(stderr, "[locgpu walk] searched %llu exact-in-wave+redo %llu overflow %llu tie-evict %llu replays %llu slow %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
-    if (reset) LOCGPU_HIP(ctx, hipMemset(ctx->d_search_stats, 0, sizeof(h)));
+    if (reset && !fill_now(ctx, ctx->d_search_stats, sizeof(h), "hipMemset search stats")) return LOCGPU_ERR_NO_DEVICE;
     return LOCGPU_OK;
 }
 
@@ -1392,7 +1402,7 @@ int locgpu_visit_count_enable(locgpu_ctx* ctx, int on) {
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     if (on && !ctx->d_visits) {
         LOCGPU_HIP(ctx, hipMalloc((void**)&ctx->d_visits, 4 * sizeof(unsigned long long)));
-        LOCGPU_HIP(ctx, hipMemset(ctx->d_visits, 0, 4 * sizeof(unsigned long long)));
+        if (!fill_now(ctx, ctx->d_visits, 4 * sizeof(unsigned long long), "hipMemset visits")) return LOCGPU_ERR_NO_DEVICE;
     }
     ctx->count_visits = on != 0;
     return LOCGPU_OK;
@@ -1407,7 +1417,7 @@ int locgpu_visit_count_read(locgpu_ctx* ctx, uint64_t out[4], int reset) {
     unsigned long long h[4];
     LOCGPU_HIP(ctx, hipMemcpy(h, ctx->d_visits, sizeof(h), hipMemcpyDeviceToHost));
     out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
-    if (reset) LOCGPU_HIP(ctx, hipMemset(ctx->d_visits, 0, sizeof(h)));
+    if (reset && !fill_now(ctx, ctx->d_visits, sizeof(h), "hipMemset visits")) return LOCGPU_ERR_NO_DEVICE;
     return LOCGPU_OK;
 }
 

@@ -66,6 +66,27 @@ def test_product_never_imports_the_oracle():
     assert not bad, bad
 
 
+def test_no_null_stream_fills_in_the_library():
+    """Round 4, found by `tools/fuzz_align.py --cases 120` (about one first call in a thousand): the batch allocation zero-filled the scan
+    counts with hipMemset — NULL stream, not complete when it returns — while the context's streams are non-blocking, i.e. not ordered
+    behind it: the fill could land BEHIND the first upload of the counts, and the first alignment of a fresh one-scan batch then ran its
+    20 iterations on a scan of zero points and handed the initial pose back (the same call repeated was right). The race cannot be forced
+    from outside (a busy NULL stream holds the allocation's own hipMalloc calls back), so the rule is pinned in the sources: device fills
+    go through `fill_now` / hipMemsetAsync on a stream of the context, kernels are never launched on the default stream."""
+    bad = []
+    csrc = os.path.join(ROOT, "loc_lib_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".hpp", ".cpp")):
+            continue
+        for ln, line in enumerate(open(os.path.join(csrc, fn), errors="ignore"), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bhipMemset\s*\(", code) or re.search(r"\bhipMemsetD\d+\s*\(", code) or "<<<" in code:
+                bad.append("%s:%d: %s" % (fn, ln, line.strip()[:120]))
+            if re.search(r"hipLaunchKernelGGL\([^;]*,\s*0,\s*(0|nullptr|NULL)\s*,", code):
+                bad.append("%s:%d: default-stream launch: %s" % (fn, ln, line.strip()[:120]))
+    assert not bad, bad
+
+
 # ---------------------------------------------------------------------------------------------- host logic: tree ingest
 def _packed_tree(api, xyz):
     L = api.lib()

@@ -63,6 +63,15 @@ def main():
             if st["iterations"] != want["iters"]:
                 it_bad += 1
                 print("ITERATIONS differ: case %d method %d gpu %d oracle %d (pose delta %.2e m)" % (case, method, st["iterations"], want["iters"], dt), flush=True)
+                if method >= 0:  # what is wrong: the tree on the device, the call, or the context?
+                    q = np.ascontiguousarray(scan[:, :3], dtype=np.float32)
+                    kd = locref.KdTree(m)
+                    n_bad = int((ctx.knn(q, k=5, approximate=True) != kd.knn(q, k=5, approximate=True)).any(axis=1).sum())
+                    again, st2 = ctx.icp_align(scan, init, api.icp_opts(method=method))
+                    ok_o, Ho, Bo, eff_o = ref.hb(scan, init)
+                    hb = ctx.icp_hb(scan, init, api.icp_opts(method=method))
+                    print("   device tree vs oracle tree: %d of %d 5-NN lists of the raw scan differ; the same call again: %d iterations; H/B at the initial pose: effective_num %d vs %d, |dH| %.2e of |H|"
+                          % (n_bad, len(q), st2["iterations"], hb[3], eff_o, float(np.abs(hb[1] - Ho).max() / max(np.abs(Ho).max(), 1e-300))), flush=True)
         del ctx
     print("cases %d x 4 methods: worst pose delta %.2e m / %.2e rad, iteration-count mismatches %d" % (a.cases, worst_t, worst_r, it_bad))
     return 0
