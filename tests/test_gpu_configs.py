@@ -751,6 +751,22 @@ def test_later_chunks_launch_only_the_open_scans(tmp_path):
         assert np.array_equal(outs["list"][name + "_flight"][:len(it)], outs["list"][name])
 
 
+def test_two_matchers_on_one_gpu_concurrently():
+    """Two threads of one process, each with its own context, map and scans, running SetInputTarget, single-scan and batch alignments
+    and direct NDT at the same time (what two robots' matchers sharing one GPU would do): the process-wide pieces — the host build's
+    thread pool and scratch cache, the library's statics, the HIP runtime's streams — are shared. Every pose and iteration count must be
+    the one the same calls give when run alone, bit for bit (tests/gpu_two_matchers_case.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_two_matchers_case.py"), "10"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["differing"] == 0, out
+
+
 def test_one_scan_calls_do_not_depend_on_the_call_before(api, synth):
     """Round 4: a one-scan alignment sizes its first chunk of iterations by the call before it (a streaming front-end converges in 4-5
     iterations and used to pay for eight), reads a resident cloud's points in place, and skips the zeroing of the search stage's
