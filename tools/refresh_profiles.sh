@@ -34,5 +34,6 @@ timeout 500 python tools/fuzz_search.py --cases 300 --seed 4 > $O/fuzz_search.lo
 timeout 300 python tools/fuzz_ndt.py --cases 300 --seed 4 > $O/fuzz_ndt.log 2>&1
 timeout 600 python tools/fuzz_align.py --cases 120 > $O/fuzz_align.log 2>&1
 timeout 200 python tools/fuzz_hb.py > $O/fuzz_hb.log 2>&1
-tail -2 $O/ndt_determinism.log $O/fuzz_search.log $O/fuzz_ndt.log $O/fuzz_align.log $O/fuzz_hb.log
+timeout 400 python tools/fuzz_batch.py --cases 80 --seed 6 > $O/fuzz_batch.log 2>&1
+tail -2 $O/ndt_determinism.log $O/fuzz_search.log $O/fuzz_ndt.log $O/fuzz_align.log $O/fuzz_hb.log $O/fuzz_batch.log
 ls -la $O
