@@ -45,7 +45,8 @@ def test_fuzz_ndt_short():
     """Hard again: every mismatch fails, there is no retry path. Round 3 saw ONE incremental case go wrong once
     in ≈1 700; round 4 rebuilt the incremental target ingest on the device with every buffer written before it is read and sequential
     (order-defined) per-voxel sums, and tools/ndt_determinism.py holds 5 000 clean repetitions of the sequence that case ran in
-    (profiles/experiments.md)."""
+    (profiles/experiments.md). (The one-off itself has the signature of the NULL-stream fill race found at the end of round 4 — a first call on a
+    fresh context that saw a scan of zero points; test_no_null_stream_fills_in_the_library.)"""
     assert "mismatches 0" in _run("fuzz_ndt.py", "--cases", "30")
 
 
@@ -55,6 +56,14 @@ def test_ndt_determinism_short():
     repetition's bit for bit, at capacities that take the host-replay path, the device path with evictions and the plain device path."""
     out = _run("ndt_determinism.py", "--reps", "90")
     assert "mismatches 0" in out and "MISMATCH" not in out, out[-3000:]
+
+
+def test_fuzz_batch_short():
+    """tools/fuzz_batch.py, 12 cases (≈250 scan alignments): random batch compositions — 1 to 40 scans of one point to a full scan,
+    ragged, copies of each other, far / exact / near initial poses — around the launch-shape thresholds of the library; every scan
+    against the oracle's single-scan alignment (degenerate scans, on which the oracle itself is unstable, are counted apart)."""
+    out = _run("fuzz_batch.py", "--cases", "12", "--seed", "6")
+    assert "mismatches 0;" in out and "MISMATCH" not in out, out[-3000:]
 
 
 def test_fuzz_align_short():
