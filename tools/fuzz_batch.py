@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised batch-composition probe (run ON the GPU box): batches of 1-40 scans of random sizes (one point to a full scan, ragged,
 some copies of each other, some far / exact / near initial poses so that scans leave the loop at different iterations), against local maps
-of random size — every scan's pose and iteration count against the oracle's single-scan alignment, P2Plane and P2Line. The batch sizes
+of random size — every scan's pose and iteration count against the oracle's single-scan alignment: P2Plane, P2Line and (every other case)
+direct NDT; a third of the cases under hipGraph replay, a third as two batches in flight together. The batch sizes
 straddle the launch-shape thresholds of the library (thin-wave / full-wave search kernel at 2048 waves, points per thread of the fit
 kernel at 2048 / 4096 / 8192 blocks, open-scan lists from the second chunk on).
 
@@ -67,12 +68,36 @@ def main():
         inits = np.stack(inits)
         ctx = api.Context(0)
         ctx.icp_set_target(m)
-        for method in (api.P2PLANE, api.P2LINE):
-            ref = locref.Icp(method=method)
-            ref.set_target(m)
-            b = ctx.batch(scans)
-            poses, st = ctx.icp_align_batch(b, inits, api.icp_opts(method=method))
-            b.close()
+        how = case % 3  # 0: blocking call; 1: the same under hipGraph replay; 2: the scans as TWO batches begun together, then finished
+        for method in (api.P2PLANE, api.P2LINE, -1):
+            if method >= 0:
+                ref = locref.Icp(method=method)
+                ref.set_target(m)
+            else:
+                if case % 2:
+                    continue
+                ref = locref.Ndt()
+                ref.set_target(m)
+                ctx.ndt_set_target(m)
+            ctx.graph_enable(how == 1)
+            if how == 2 and n_scans >= 2:
+                h = n_scans // 2
+                b1, b2 = ctx.batch(scans[:h]), ctx.batch(scans[h:])
+                if method >= 0:
+                    ctx.icp_align_batch_begin(b1, inits[:h], api.icp_opts(method=method))
+                    ctx.icp_align_batch_begin(b2, inits[h:], api.icp_opts(method=method))
+                else:
+                    ctx.ndt_align_batch_begin(b1, inits[:h])
+                    ctx.ndt_align_batch_begin(b2, inits[h:])
+                p1, s1 = ctx.align_batch_end(b1)
+                p2, s2 = ctx.align_batch_end(b2)
+                poses, st = np.concatenate([p1, p2]), list(s1) + list(s2)
+                b1.close(); b2.close()
+            else:
+                b = ctx.batch(scans)
+                poses, st = ctx.icp_align_batch(b, inits, api.icp_opts(method=method)) if method >= 0 else ctx.ndt_align_batch(b, inits)
+                b.close()
+            ctx.graph_enable(False)
             for j in range(n_scans):
                 want = ref.align(scans[j], inits[j])
                 dt, dr = pose_delta(poses[j], want["pose"])
@@ -81,11 +106,12 @@ def main():
                 if st[j]["iterations"] != want["iters"] or dt > tol or dr > tol:
                     # A few dozen points of one scan ring are collinear: the normal equations are singular to working precision, the
                     # det(H) != 0 test and the step are accidents of the summation order — for the CPU as for the GPU.
-                    ok_o, Ho, Bo, eff_o = ref.hb(scans[j], inits[j])
-                    sv = np.linalg.svd(Ho, compute_uv=False)
-                    if sv[0] == 0.0 or sv[-1] <= 1e-10 * sv[0]:
-                        singular += 1
-                        continue
+                    if method >= 0:
+                        ok_o, Ho, Bo, eff_o = ref.hb(scans[j], inits[j])
+                        sv = np.linalg.svd(Ho, compute_uv=False)
+                        if sv[0] == 0.0 or sv[-1] <= 1e-10 * sv[0]:
+                            singular += 1
+                            continue
                     # ... or become so on the way: then the CPU restatement itself ends somewhere else when its initial pose is moved by 1e-9
                     nudged = inits[j].copy()
                     nudged[4:] += 1e-9
