@@ -17,7 +17,7 @@
 //   crop / NaN     16 in + 1 flag + 16·kept out
 #include "cloud_filters.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include "device_prims.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -314,8 +314,8 @@ hipError_t ensure_scratch(locgpu_ctx* ctx, size_t n) {
     LOCGPU_TRY(hipMalloc((void**)&S->head, cap * sizeof(uint32_t)));
     LOCGPU_TRY(hipMalloc((void**)&S->rank, cap * sizeof(uint32_t)));
     size_t b1 = 0, b2 = 0;
-    LOCGPU_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, S->keys[0], S->keys[1], S->vals[0], S->vals[1], (int)cap, 0, 32, ctx->stream));
-    LOCGPU_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, S->head, S->rank, (int)cap, ctx->stream));
+    LOCGPU_TRY(prim::sort_pairs(nullptr, b1, S->keys[0], S->keys[1], S->vals[0], S->vals[1], (int)cap, 0, 32, ctx->stream));
+    LOCGPU_TRY(prim::exclusive_sum(nullptr, b2, S->head, S->rank, (int)cap, ctx->stream));
     S->temp_bytes = std::max(b1, b2) + 256;
     LOCGPU_TRY(hipMalloc(&S->temp, S->temp_bytes));
     S->cap = cap;
@@ -470,10 +470,10 @@ hipError_t voxel_filter_dev(locgpu_ctx* ctx, const locgpu_cloud* in, float leaf,
     }
     hipLaunchKernelGGL(voxel_key_kernel, dim3(blocks_for(n)), dim3(kFB), 0, s, in->d, n, dense, S->d_params, S->keys[0], S->vals[0]);
     size_t tb = S->temp_bytes;
-    LOCGPU_TRY(hipcub::DeviceRadixSort::SortPairs(S->temp, tb, S->keys[0], S->keys[1], S->vals[0], S->vals[1], (int)n, 0, end_bit, s));
+    LOCGPU_TRY(prim::sort_pairs(S->temp, tb, S->keys[0], S->keys[1], S->vals[0], S->vals[1], (int)n, 0, end_bit, s));
     hipLaunchKernelGGL(voxel_head_kernel, dim3(blocks_for(n)), dim3(kFB), 0, s, S->keys[1], n, S->d_params, dense, S->head);
     tb = S->temp_bytes;
-    LOCGPU_TRY(hipcub::DeviceScan::ExclusiveSum(S->temp, tb, S->head, S->rank, (int)n, s));
+    LOCGPU_TRY(prim::exclusive_sum(S->temp, tb, S->head, S->rank, (int)n, s));
     uint32_t* start = S->keys[0];  // free again after the sort; capacity ≥ n + 1 (ensure_scratch above)
     hipLaunchKernelGGL(voxel_starts_kernel, dim3(blocks_for(n)), dim3(kFB), 0, s, S->keys[1], S->head, S->rank, n, dense, start, S->d_params);
     LOCGPU_TRY(hipGetLastError());
@@ -509,7 +509,7 @@ static hipError_t compact(locgpu_ctx* ctx, const locgpu_cloud* in, Pred pred, lo
     uint32_t *tile_count = S->head, *tile_offset = S->rank;
     hipLaunchKernelGGL((compact_count_kernel<Pred>), dim3(n_tiles), dim3(kFB), 0, s, in->d, n, pred, tile_count);
     size_t tb = S->temp_bytes;
-    LOCGPU_TRY(hipcub::DeviceScan::ExclusiveSum(S->temp, tb, tile_count, tile_offset, (int)n_tiles, s));
+    LOCGPU_TRY(prim::exclusive_sum(S->temp, tb, tile_count, tile_offset, (int)n_tiles, s));
     hipLaunchKernelGGL((compact_scatter_kernel<Pred>), dim3(n_tiles), dim3(kFB), 0, s, in->d, n, pred, tile_offset, tile_count, n_tiles, S->d_tmp, S->d_params);
     LOCGPU_TRY(hipGetLastError());
     LOCGPU_TRY(read_params(ctx));

@@ -80,8 +80,6 @@ struct locgpu_ctx {
     unsigned long long* d_search_stats = nullptr;  // [2]: queries searched / queries redone by the exact kernel
 };
 
-constexpr size_t kSpillRecordBytes = 16 + 16 + 5 * 8 + 24 * 8;  // hdr, query, result set, up to 24 stack rows (launch.hpp SpillBuf)
-
 struct locgpu_batch {
     locgpu_ctx* ctx = nullptr;
     int slot = 0;
@@ -98,15 +96,6 @@ struct locgpu_batch {
     int* d_counts = nullptr;
     locgpu::PoseState* d_state = nullptr;
     uint32_t* d_nn = nullptr;      // [5][pitch]
-    // spill records of the search kernel's stragglers (launch.hpp SpillBuf; large batches only)
-    void* d_spill = nullptr;
-    unsigned int spill_cap = 0;
-    size_t spill_waves = 0;
-    // plane cache of the P2Plane fit kernel (batches large enough for the 64-lane search kernel; launch.hpp): per point the plane
-    // 4-vector fitted for the list it had then, per 64 queries the "same list as last iteration" bits of the search kernel
-    double* d_plane_cache = nullptr;             // [pitch][4]
-    unsigned long long* d_same_mask = nullptr;   // [n_scans][ceil(max_n / 64)]
-    bool cache_chain = false;                    // the previous iteration of the running alignment filled the cache
     const float4* d_src_ext = nullptr;           // one-scan batches: the points stay where the caller's cloud holds them (no copy into d_src); nullptr = d_src
     bool counters_clean = false;                 // the search stage's work-list counters are known to be zero (the last alignment ran to its end)
     int last_iterations = -1;                    // one-scan batches: iterations of the previous alignment run on this batch (-1: none yet) — sizes the next first chunk

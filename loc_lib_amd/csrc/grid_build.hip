@@ -14,7 +14,7 @@
 //   its record (65 prefix sums of the cells' counts) → open-addressing hash table tile → record.
 #include "grid_kernels.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include "device_prims.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -205,15 +205,15 @@ hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, 
     GB_TRY(tmp.alloc(&d_k64, n * sizeof(unsigned long long)));
     GB_TRY(tmp.alloc(&d_k64s, n * sizeof(unsigned long long)));
     size_t sort_bytes = 0;
-    GB_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, d_k64, d_k64s, (int)n, 0, 64, s));
+    GB_TRY(prim::sort_keys(nullptr, sort_bytes, d_k64, d_k64s, (int)n, 0, 64, s));
     {
         size_t b2 = 0;
         uint32_t* z = nullptr;
-        GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b2, z, z, z, z, (int)n, 0, 32, s));
+        GB_TRY(prim::sort_pairs(nullptr, b2, z, z, z, z, (int)n, 0, 32, s));
         sort_bytes = std::max(sort_bytes, b2);
-        GB_TRY(hipcub::DeviceRunLengthEncode::Encode(nullptr, b2, z, z, z, z, (int)n, s));
+        GB_TRY(prim::run_length_encode(nullptr, b2, z, z, z, z, (int)n, s));
         sort_bytes = std::max(sort_bytes, b2);
-        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, z, z, (int)n, s));
+        GB_TRY(prim::exclusive_sum(nullptr, b2, z, z, (int)n, s));
         sort_bytes = std::max(sort_bytes, b2);
     }
     void* d_sort_tmp = nullptr;
@@ -223,7 +223,7 @@ hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, 
     for (double c = ext / 8192.0; c < ext; c *= 1.3) {
         hipLaunchKernelGGL(probe_key_kernel, dim3(blocks_for(n)), dim3(kGB), 0, s, d_leaves, n, lo[0], lo[1], lo[2], (float)(1.0 / c), d_k64);
         size_t tb = sort_bytes;
-        GB_TRY(hipcub::DeviceRadixSort::SortKeys(d_sort_tmp, tb, d_k64, d_k64s, (int)n, 0, 63, s));
+        GB_TRY(prim::sort_keys(d_sort_tmp, tb, d_k64, d_k64s, (int)n, 0, 63, s));
         GB_TRY(hipMemsetAsync(d_flag + 1, 0, sizeof(unsigned int), s));
         hipLaunchKernelGGL(count_distinct_kernel, dim3(blocks_for(n)), dim3(kGB), 0, s, d_k64s, n, d_flag + 1);
         unsigned int occ = 0;
@@ -266,16 +266,16 @@ hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, 
     hipLaunchKernelGGL(cell_key_kernel, dim3(blocks_for(n)), dim3(kGB), 0, s, d_leaves, n, lo[0], lo[1], lo[2], inv, dims[0], dims[1], dims[2], tdims[0],
                        tdims[1], d_key, d_idx);
     size_t tb = sort_bytes;
-    GB_TRY(hipcub::DeviceRadixSort::SortPairs(d_sort_tmp, tb, d_key, d_key_s, d_idx, d_idx_s, (int)n, 0, 32, s));  // stable: tree order inside a cell
+    GB_TRY(prim::sort_pairs(d_sort_tmp, tb, d_key, d_key_s, d_idx, d_idx_s, (int)n, 0, 32, s));  // stable: tree order inside a cell
     GB_TRY(hipMalloc((void**)&buf.pts, n * sizeof(float4)));
     hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks_for(n)), dim3(kGB), 0, s, d_leaves, d_idx_s, d_key_s, n, buf.pts, d_tile_of);
     tb = sort_bytes;
-    GB_TRY(hipcub::DeviceRunLengthEncode::Encode(d_sort_tmp, tb, d_tile_of, d_utile, d_cnt, d_nocc, (int)n, s));
+    GB_TRY(prim::run_length_encode(d_sort_tmp, tb, d_tile_of, d_utile, d_cnt, d_nocc, (int)n, s));
     uint32_t n_tocc = 0;
     GB_TRY(hipMemcpyAsync(&n_tocc, d_nocc, 4, hipMemcpyDeviceToHost, s));
     GB_TRY(hipStreamSynchronize(s));
     tb = sort_bytes;
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_sort_tmp, tb, d_cnt, d_start, (int)n_tocc, s));
+    GB_TRY(prim::exclusive_sum(d_sort_tmp, tb, d_cnt, d_start, (int)n_tocc, s));
     uint32_t cap = 1024;
     while (cap < 2u * n_tocc) cap <<= 1;
     GB_TRY(hipMalloc((void**)&buf.tile_hash, (size_t)cap * sizeof(uint2)));
@@ -291,7 +291,7 @@ hipError_t grid_build_device(const uint2* d_tree, const uint32_t* d_leaf_slots, 
     // ---- per-iteration binning scratch: one counter per occupied tile
     GB_TRY(hipMalloc((void**)&buf.tile_count, ((size_t)n_tocc + 2) * sizeof(uint32_t)));
     size_t scan_bytes = 0;
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, buf.tile_count, buf.tile_count, (int)(n_tocc + 1), s));
+    GB_TRY(prim::exclusive_sum(nullptr, scan_bytes, buf.tile_count, buf.tile_count, (int)(n_tocc + 1), s));
     GB_TRY(hipMalloc(&buf.scan_temp, scan_bytes ? scan_bytes : 1));
     GB_TRY(hipGetLastError());
     GB_TRY(hipStreamSynchronize(s));

@@ -24,11 +24,43 @@
 #include "grid_kernels.hpp"
 #include "icp_kernels.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include "device_prims.hpp"
 
 #include <cstdlib>
 
 namespace locgpu {
+
+// Result set of the grid search: ascending sorted array with insertion; a tie raises the flag that sends the query to the exact
+// tree traversal (whose libstdc++ heap decides the order among equal distances).
+template <int K>
+struct SortedSet {  // ascending: d[0] ≤ … ≤ d[K-1]; empty slots hold +inf / kInvalidSlot
+    float d[K];
+    uint32_t id[K];
+    int n;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int j = 0; j < K; ++j) { d[j] = __builtin_inff(); id[j] = kInvalidSlot; }
+        n = 0;
+    }
+    __device__ __forceinline__ float top() const { return d[K - 1]; }
+    // returns true when the insertion tied with a resident distance (⇒ heap layout would matter)
+    __device__ __forceinline__ bool insert(float x, uint32_t w) {
+        bool tie = false;
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) tie |= (x == d[j]);
+        d[K - 1] = x;
+        id[K - 1] = w;
+#pragma unroll
+        for (int j = K - 1; j > 0; --j) {
+            const bool sw = d[j] < d[j - 1];
+            const float lo = sw ? d[j] : d[j - 1], hi = sw ? d[j - 1] : d[j];
+            const uint32_t ilo = sw ? id[j] : id[j - 1], ihi = sw ? id[j - 1] : id[j];
+            d[j - 1] = lo; d[j] = hi; id[j - 1] = ilo; id[j] = ihi;
+        }
+        n = n < K ? n + 1 : K;
+        return tie;
+    }
+};
 
 struct GridDev {
     const uint2* tile_hash;
@@ -462,7 +494,7 @@ static bool search_grid_k(const GridView& grid, const GridDev& g, const SearchAr
     hipLaunchKernelGGL((grid_bin_count_kernel<K>), blocks, dim3(kBlock), 0, s, g, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.skip_nonfinite, sc.qkey,
                        grid.tile_count, a.redo_list2, a.redo_count2, a.search_stats);
     size_t tb = grid.scan_temp_bytes;
-    if (hipcub::DeviceScan::ExclusiveSum(grid.scan_temp, tb, grid.tile_count, grid.tile_count, (int)(grid.n_tocc + 1), s) != hipSuccess) return false;
+    if (prim::exclusive_sum(grid.scan_temp, tb, grid.tile_count, grid.tile_count, (int)(grid.n_tocc + 1), s) != hipSuccess) return false;
     hipLaunchKernelGGL(grid_bin_scatter_kernel, blocks, dim3(kBlock), 0, s, a.counts, a.st, a.max_n, sc.qkey, grid.tile_count, sc.sorted);
     // after the scatter tile_count[t] = end of tile t's queries; the last entry (never incremented) still holds the total
     const size_t total_q = (size_t)a.max_n * a.n_scans;

@@ -9,17 +9,6 @@ namespace locgpu {
 
 struct GnParams;
 
-// Spill records of the search kernel's stragglers (icp_kernels.hip, "straggler hand-over"): `cap` entries; wave g of a launch owns
-// the entries [g·stop_at, (g + 1)·stop_at) and n[g] says how many of them it filled.
-struct SpillBuf {
-    uint4* hdr = nullptr;       // {query index, next slot, avail | slow << 16, c3n}
-    float4* q = nullptr;        // the query
-    uint2* set = nullptr;       // [5][cap] {d_j, id_j}
-    uint2* stack = nullptr;     // [rows][cap] the stack rows below avail
-    unsigned int* n = nullptr;  // [waves] stragglers of each wave
-    unsigned int cap = 0;
-};
-
 struct SearchArgs {
     const uint2* tree;
     size_t tree_bytes;
@@ -43,12 +32,6 @@ struct SearchArgs {
     // iterations hold a handful of scans: 460 k empty workgroups cost ≈96 µs per launch). nullptr = every scan.
     const int* active = nullptr;
     int n_active = 0;
-    // Plane cache (P2Plane batches, DESIGN.md §3 "K2"): the 64-lane walk kernel writes, per wave, the lanes whose five neighbour
-    // indices equal the previous iteration's (one 64-bit word per 64 queries, [n_scans][ceil(max_n/64)]); `have_previous` = the
-    // lists in nn are the previous iteration's of this very alignment (else every bit is 0). nullptr = not wanted.
-    unsigned long long* same_mask = nullptr;
-    int have_previous = 0;
-    SpillBuf spill;  // straggler hand-over of the 64-lane walk kernel; hdr == nullptr = none
     // instrumented pass only: bitmap over the tree's 8-byte slots (one bit each, zeroed by the caller, counted and cleared again
     // by launch_count_touched) — which slots this search launch reads at all
     uint32_t* touched = nullptr;
@@ -66,22 +49,12 @@ struct AccumArgs {
     double* partials;   // [n_scans][blocks_per_scan][kAccW]
     const int* active = nullptr;  // see SearchArgs
     int n_active = 0;
-    // Plane cache: the plane 4-vector of every point as fitted for the list it had then ([pitch] × 4 doubles; all zero = no plane),
-    // and the search stage's "same five indices as last time" bits. use_cache = the bits are valid for this launch.
-    double* plane_cache = nullptr;
-    const unsigned long long* same_mask = nullptr;
-    int use_cache = 0;
 };
 
 bool launch_icp_search(const SearchArgs& a, hipStream_t s);
-// true iff launch_icp_search(a) runs the kernel that fills a.same_mask (the plane cache of the fit kernel is usable behind it)
-bool icp_search_writes_same_mask(const SearchArgs& a);
-int walk_stop_lanes();         // LOCGPU_WALK_STOP: lanes a wave hands over to the continuation kernel; 0 (default) = no hand-over
-size_t walk_stop_min_waves();  // search launches of at least this many waves hand their stragglers over (LOCGPU_WALK_STOP_MIN_WAVES)
-int plane_cache_mode();  // LOCGPU_PLANE_CACHE: 0 off, 1 on (default), 2 / 3 timing experiments (icp_kernels.hip)
 // exact tree traversal over a.redo_list only (the list is filled by a preceding fast / grid kernel)
 bool launch_icp_search_redo(const SearchArgs& a, hipStream_t s);
-// fast tree traversal (a.alpha_eff) over the queries in `list`, then the exact redo kernel for what it could not finish
+// the walk traversal with every level stored (a.alpha_eff) over the queries in `list`, then the exact redo kernel for its ties
 bool launch_icp_search_list(const SearchArgs& a, const uint32_t* list, const unsigned int* n_list, hipStream_t s);
 bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, int k, float alpha_eff, int32_t* out, uint32_t* visits,
                       hipStream_t s);

@@ -14,7 +14,7 @@
 //
 // Mapping: one 256-thread workgroup per (sector, ring): bitonic sort of the sector's (curvature, id) pairs in LDS, the
 // inherently sequential pick loop on one lane (≤ 21 picks), ordered compaction of the surface points by ballot/popcount.
-#include <hipcub/hipcub.hpp>
+#include "device_prims.hpp"
 
 #include <cstring>
 #include <string>
@@ -277,7 +277,7 @@ hipError_t ensure(locgpu_ctx* ctx, size_t n, int num_scan) {
         LOCGPU_TRY(hipMalloc((void**)&S->surf_slot, cap * sizeof(float4)));
         LOCGPU_TRY(hipMalloc((void**)&S->curv, cap * sizeof(double)));
         size_t tb = 0;
-        LOCGPU_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, S->keys[0], S->keys[1], S->vals[0], S->vals[1], (int)cap, 0, 8, ctx->stream));
+        LOCGPU_TRY(prim::sort_pairs(nullptr, tb, S->keys[0], S->keys[1], S->vals[0], S->vals[1], (int)cap, 0, 8, ctx->stream));
         S->temp_bytes = tb + 256;
         LOCGPU_TRY(hipMalloc(&S->temp, S->temp_bytes));
         S->cap = cap;
@@ -308,7 +308,7 @@ hipError_t loam_extract_dev(locgpu_ctx* ctx, const locgpu_cloud* in, const unsig
     LOCGPU_TRY(hipMemsetAsync(S->d_params, 0, sizeof(LoamParams), s));
     hipLaunchKernelGGL(ring_key_kernel, dim3(nb), dim3(kLB), 0, s, S->d_ring, n, S->keys[0], S->vals[0]);
     size_t tb = S->temp_bytes;
-    LOCGPU_TRY(hipcub::DeviceRadixSort::SortPairs(S->temp, tb, S->keys[0], S->keys[1], S->vals[0], S->vals[1], (int)n, 0, 8, s));  // stable: input order per ring
+    LOCGPU_TRY(prim::sort_pairs(S->temp, tb, S->keys[0], S->keys[1], S->vals[0], S->vals[1], (int)n, 0, 8, s));  // stable: input order per ring
     hipLaunchKernelGGL(ring_start_kernel, dim3((num_scan + 1 + 63) / 64), dim3(64), 0, s, S->keys[1], (uint32_t)n, num_scan, S->ring_start);
     hipLaunchKernelGGL(ring_gather_kernel, dim3(nb), dim3(kLB), 0, s, in->d, S->vals[1], n, S->ring_pts);
     hipLaunchKernelGGL(curvature_kernel, dim3(nb, num_scan), dim3(kLB), 0, s, S->ring_pts, S->ring_start, num_scan, S->curv);

@@ -77,10 +77,8 @@ inline const float4* batch_src(const locgpu_batch* b) { return b->d_src_ext ? b-
 // (Lio::AddCloud: 4-5 iterations per scan) used to pay three or four idle iterations, ≈15 µs each, in every call — a sixth of the
 // match stage of the streaming loop (tools/stream_trace.py). One more than last time, between 3 and kFirstChunk; chunking never
 // changes a result (the same kernels run on the same data in the same order), only where the host looks at the flags.
-// LOCGPU_ADAPTIVE_CHUNK=0 switches it off (A/B).
 inline int first_chunk_len(const locgpu_batch* b) {
-    static const bool adaptive = [] { const char* e = getenv("LOCGPU_ADAPTIVE_CHUNK"); return !e || atoi(e) != 0; }();
-    if (!adaptive || b->n_total != 1 || b->sharded || b->last_iterations < 0) return kFirstChunk;
+    if (b->n_total != 1 || b->sharded || b->last_iterations < 0) return kFirstChunk;
     return std::min(kFirstChunk, std::max(3, b->last_iterations + 1));
 }
 }  // namespace
@@ -133,9 +131,6 @@ static void free_batch(locgpu_batch* b) {
     if (b->d_counts) (void)hipFree(b->d_counts);
     if (b->d_state) (void)hipFree(b->d_state);
     if (b->d_nn) (void)hipFree(b->d_nn);
-    if (b->d_spill) (void)hipFree(b->d_spill);
-    if (b->d_plane_cache) (void)hipFree(b->d_plane_cache);
-    if (b->d_same_mask) (void)hipFree(b->d_same_mask);
     if (b->d_partials) (void)hipFree(b->d_partials);
     if (b->d_hb) (void)hipFree(b->d_hb);
     if (b->d_acc) (void)hipFree(b->d_acc);
@@ -578,7 +573,7 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               hip_ok(ctx, hipMalloc((void**)&b->d_hb, (size_t)n_total * 44 * sizeof(double)), "hipMalloc hb") &&
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_list, (getenv("LOCGPU_STAMP") ? 2 : 1) * std::max<size_t>(b->pitch, 1) * sizeof(uint32_t)), "hipMalloc redo") &&  // diagnostic build: + per-query trip counts
               hip_ok(ctx, hipMalloc((void**)&b->d_redo_list2, std::max<size_t>(b->pitch, 1) * sizeof(uint32_t)), "hipMalloc redo2") &&  // deep pass / grid search: second work list
-              hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, 4 * sizeof(unsigned int)), "hipMalloc redo") &&  // [0] redo list, [1] deep list, [2] spill records, [3] spare
+              hip_ok(ctx, hipMalloc((void**)&b->d_redo_count, 4 * sizeof(unsigned int)), "hipMalloc redo") &&  // [0] redo list, [1] deep list, [2..3] spare
               hip_ok(ctx, hipHostMalloc((void**)&b->h_state, n_total * sizeof(PoseState)), "hipHostMalloc state") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_hb, (size_t)n_total * 44 * sizeof(double)), "hipHostMalloc hb") &&
               hip_ok(ctx, hipHostMalloc((void**)&b->h_active, (size_t)std::max(n_scans, 1) * sizeof(int)), "hipHostMalloc active") &&
@@ -589,23 +584,6 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
               // tools/fuzz_align.py --cases 120 in round 4). fill_now: on the context's stream, and waited for.
               fill_now(ctx, b->d_counts, std::max(n_scans, 1) * sizeof(int), "hipMemset counts") &&
               fill_now(ctx, b->d_redo_count, 4 * sizeof(unsigned int), "hipMemset redo");  // kept zero between searches by gn_solve_kernel
-    // Spill records of the search kernel's stragglers (launch.hpp SpillBuf; opt-in with LOCGPU_WALK_STOP): batches of at least 16384
-    // waves of queries; every wave owns room for the lanes it may hand over: 16 + 16 + 40 + 8 x 24 rows = 264 B per record — 0.97 GB
-    // for 256 full scans at 8 lanes — plus one counter per wave
-    if (ok && walk_stop_lanes() > 0 && (size_t)((max_n + 63) / 64) * (size_t)n_scans >= walk_stop_min_waves()) {
-        const size_t waves = (size_t)((max_n + 63) / 64) * (size_t)n_scans;
-        const size_t cap = waves * (size_t)walk_stop_lanes();
-        if (cap < 0x7FFFFFFFull) {
-            b->spill_cap = (unsigned int)cap;
-            b->spill_waves = waves;
-            ok = hip_ok(ctx, hipMalloc(&b->d_spill, cap * kSpillRecordBytes + waves * sizeof(unsigned int)), "hipMalloc spill records");
-        }
-    }
-    // plane cache of the P2Plane fit kernel (opt-in, LOCGPU_PLANE_CACHE=1): only for batches that can ever run the 64-lane search kernel
-    // (more than 2048 waves of queries); 32 B per point — 0.94 GB for 256 full scans
-    if (ok && plane_cache_mode() != 0 && (size_t)((max_n + 63) / 64) * (size_t)n_scans > 2048)
-        ok = hip_ok(ctx, hipMalloc((void**)&b->d_plane_cache, b->pitch * 4 * sizeof(double)), "hipMalloc plane cache") &&
-             hip_ok(ctx, hipMalloc((void**)&b->d_same_mask, (size_t)n_scans * ((max_n + 63) / 64) * sizeof(unsigned long long)), "hipMalloc same-list mask");
     if (!ok) { free_batch(b); return LOCGPU_ERR_OOM; }
     *out = b;
     return LOCGPU_OK;
@@ -757,7 +735,6 @@ struct IterLauncher {
     bool replicated_on_comm_stream = false;  // the chunk's read-back must wait for the communication stream as well
     const int* active = nullptr;  // later chunks: the local scans still open (SearchArgs::active); nullptr = all
     int n_active = 0;
-    int iter = 0;            // index of the next iteration within its alignment (0 = the first: no previous neighbour lists)
     bool launch(int do_update);
     void collect_profile();
 };
@@ -792,16 +769,6 @@ bool IterLauncher::launch(int do_update) {
         if (grid_mode && !b->d_grid_qkey) { fail(ctx, LOCGPU_ERR_INVALID, "grid search: work list missing (ensure_grid_lists was not called)"); return false; }
         sa.redo_list2 = b->d_redo_list2;
         sa.active = active; sa.n_active = n_active;
-        if (b->d_spill) {
-            char* base = (char*)b->d_spill;
-            const size_t cap = b->spill_cap;
-            sa.spill.hdr = (uint4*)base;
-            sa.spill.q = (float4*)(base + cap * 16);
-            sa.spill.set = (uint2*)(base + cap * 32);
-            sa.spill.stack = (uint2*)(base + cap * 72);
-            sa.spill.n = (unsigned int*)(base + cap * kSpillRecordBytes);
-            sa.spill.cap = b->spill_cap;
-        }
         if (sa.visit_totals && !capturing) {  // instrumented pass: which tree slots does this launch read at all? (bench.py: compulsory bytes)
             const size_t words = (ctx->tree_slots + 2 + 31) / 32;
             if (words > ctx->touched_words) {
@@ -812,13 +779,6 @@ bool IterLauncher::launch(int do_update) {
             }
             sa.touched = ctx->touched_words ? ctx->d_touched : nullptr;
         }
-        // plane cache (launch.hpp): wanted for P2Plane on batches that own one; usable when this launch runs the 64-lane walk kernel,
-        // trustworthy when the previous iteration of this alignment ran it as well
-        const bool want_cache = prm.method == LOCGPU_P2PLANE && b->d_plane_cache && !grid_mode && do_update;
-        sa.same_mask = want_cache ? b->d_same_mask : nullptr;
-        sa.have_previous = (want_cache && iter > 0 && b->cache_chain) ? 1 : 0;
-        const bool cached = want_cache && icp_search_writes_same_mask(sa);
-        if (!cached) { sa.same_mask = nullptr; sa.have_previous = 0; }
         const GridSearchScratch gsc{b->d_grid_qkey, b->d_grid_sorted};
         const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, gsc, s) : launch_icp_search(sa, s);
         if (!ok_search) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
@@ -827,9 +787,6 @@ bool IterLauncher::launch(int do_update) {
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
         AccumArgs aa{ctx->d_tree, batch_src(b), b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
         aa.active = active; aa.n_active = n_active;
-        if (cached && plane_cache_mode() != 3) { aa.plane_cache = b->d_plane_cache; aa.same_mask = b->d_same_mask; aa.use_cache = plane_cache_mode() == 2 ? 0 : sa.have_previous; }
-        b->cache_chain = cached;
-        iter++;
         n_partial_blocks = launch_icp_accum(prm.method, aa, s);
     } else {
         mark(true);  // NDT has no separate search kernel: search slot stays empty
@@ -953,8 +910,6 @@ static int capture_chunk(locgpu_ctx* ctx, locgpu_batch* b, const GnParams& prm, 
     IterLauncher it{ctx, b, prm, k, alpha_eff};
     it.ndt = ndt;
     it.capturing = true;
-    it.iter = with_h2d ? 0 : kFirstChunk;  // the first graph starts an alignment, the second continues one
-    if (!with_h2d) b->cache_chain = b->d_plane_cache != nullptr && prm.method == LOCGPU_P2PLANE;  // captured behind the first graph's iterations (same launches, same kernels)
     for (int i = 0; ok && i < iters; ++i) ok = it.launch(1);
     ok = ok && hip_ok(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_total * sizeof(PoseState), hipMemcpyDeviceToHost, s), "capture D2H");
     const hipError_t e = hipStreamEndCapture(s, &graph);
@@ -999,9 +954,7 @@ static int enqueue_chunk(locgpu_ctx* ctx, locgpu_batch* b, bool first_chunk) {
     IterLauncher it{ctx, b, P.prm, P.k, P.alpha_eff};
     it.ndt = P.ndt;
     it.ev_used = P.ev_used;
-    it.iter = P.launched;
-    static const bool use_active = [] { const char* e = getenv("LOCGPU_ACTIVE_LIST"); return !e || atoi(e) != 0; }();  // 0: every chunk launches every scan (A/B)
-    if (!first_chunk && !P.ndt && b->n_scans > 1 && use_active) {
+    if (!first_chunk && !P.ndt && b->n_scans > 1) {
         // The host has just read every scan's flags (align_finish): launch the search and accumulate kernels of this chunk over the
         // local scans still open only. A 256-scan step's second and third chunk hold ≈60 and ≈5 scans; the rest used to be 1800
         // early-exit workgroups per scan and kernel (≈96 µs per search launch for nothing). Results are the same bits: a scan's
@@ -1038,7 +991,6 @@ static int align_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_pose
     P.graph = ctx->use_graph && !ctx->count_visits && !b->sharded && prm.max_iteration > 0;
     P.launched = 0;
     P.ev_used = 0;
-    b->cache_chain = false;
     P.init_poses.assign(init_poses, init_poses + 7 * (size_t)b->n_total);
     init_states(b, init_poses);
     // the search stage's work-list counters: zero once per alignment, whatever an earlier call that failed between a search and
@@ -1392,7 +1344,6 @@ int locgpu_search_stats_read(locgpu_ctx* ctx, uint64_t out[4], int reset) {
     if (stamp && h[12])
         fprintf(stderr, "[locgpu stamp] %llu queries in %llu waves: %.2f rounds per lane, %.2f per wave; lane efficiency %.3f\n", h[0], h[12], (double)h[4] / (double)h[0],
                 (double)h[9] / (double)h[12], (double)h[4] / (double)std::max<unsigned long long>(h[13], 1ull));
-    if (getenv("LOCGPU_WALK_DEBUG")) fprintf(stderr, "[locgpu walk] searched %llu exact-in-wave+redo %llu overflow %llu tie-evict %llu replays %llu slow %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
     if (reset && !fill_now(ctx, ctx->d_search_stats, sizeof(h), "hipMemset search stats")) return LOCGPU_ERR_NO_DEVICE;
     return LOCGPU_OK;
 }

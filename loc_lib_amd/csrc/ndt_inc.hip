@@ -31,7 +31,7 @@
 // align: AlignIncNdt differs from the direct variant: sums ARE info-weighted (H += Jᵀ·info·J, err += −Jᵀ·info·e, :345-346),
 // effective_num counts accepted (point, voxel) pairs (:343), too few ⇒ `return false` with result = current pose (:349-353), and
 // there is no det(H) test.
-#include <hipcub/hipcub.hpp>
+#include "device_prims.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -365,7 +365,7 @@ struct IncNdtState {
     unsigned long long *d_ev_stamp = nullptr, *d_ev_stamp_sorted = nullptr;
     int *d_ev_slot = nullptr, *d_ev_slot_sorted = nullptr;
     size_t ev_cap = 0;
-    void* d_temp = nullptr;  // hipcub
+    void* d_temp = nullptr;  // scratch of the device-wide primitives
     size_t temp_bytes = 0;
     int *d_ctr = nullptr, *h_ctr = nullptr;  // kIncCtrs counters, device + pinned
 };
@@ -436,8 +436,8 @@ static hipError_t ensure_points(IncNdtState& st, size_t n, hipStream_t s) {
         INC_TRY(regrow(st.d_psorted, 0, cap, false, s)); INC_TRY(regrow(st.d_keep, 0, cap, false, s));
         st.pt_cap = cap;
         size_t b1 = 0, b2 = 0;
-        INC_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, st.d_pkey, st.d_skey, st.d_pidx, st.d_sidx, (int)cap, 0, 64, s));
-        INC_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, st.d_head, st.d_uid, (int)cap, s));
+        INC_TRY(prim::sort_pairs(nullptr, b1, st.d_pkey, st.d_skey, st.d_pidx, st.d_sidx, (int)cap, 0, 64, s));
+        INC_TRY(prim::exclusive_sum(nullptr, b2, st.d_head, st.d_uid, (int)cap, s));
         INC_TRY(ensure_temp(st, std::max(b1, b2)));
     }
     return hipSuccess;
@@ -450,7 +450,7 @@ static hipError_t ensure_evict(IncNdtState& st, size_t n_live, hipStream_t s) {
         INC_TRY(regrow(st.d_ev_slot, 0, cap, false, s)); INC_TRY(regrow(st.d_ev_slot_sorted, 0, cap, false, s));
         st.ev_cap = cap;
         size_t b = 0;
-        INC_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b, st.d_ev_stamp, st.d_ev_stamp_sorted, st.d_ev_slot, st.d_ev_slot_sorted, (int)cap, 0, 64, s));
+        INC_TRY(prim::sort_pairs(nullptr, b, st.d_ev_stamp, st.d_ev_stamp_sorted, st.d_ev_slot, st.d_ev_slot_sorted, (int)cap, 0, 64, s));
         INC_TRY(ensure_temp(st, b));
     }
     return hipSuccess;
@@ -482,10 +482,10 @@ static hipError_t sort_and_look_up(IncNdtState& st, const float4* d_pts, size_t 
     INC_TRY(hipMemsetAsync(st.d_ctr, 0, kIncCtrs * sizeof(int), s));
     hipLaunchKernelGGL(inc_key_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, d_pts, n, st.inv_voxel, masked ? st.d_keep : nullptr, st.d_pkey, st.d_pidx, st.d_ctr);
     size_t tb = st.temp_bytes;
-    INC_TRY(hipcub::DeviceRadixSort::SortPairs(st.d_temp, tb, st.d_pkey, st.d_skey, st.d_pidx, st.d_sidx, (int)n, 0, 64, s));  // stable: a voxel's points keep their input order
+    INC_TRY(prim::sort_pairs(st.d_temp, tb, st.d_pkey, st.d_skey, st.d_pidx, st.d_sidx, (int)n, 0, 64, s));  // stable: a voxel's points keep their input order
     hipLaunchKernelGGL(inc_head_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, st.d_skey, n, st.d_head);
     tb = st.temp_bytes;
-    INC_TRY(hipcub::DeviceScan::ExclusiveSum(st.d_temp, tb, st.d_head, st.d_uid, (int)n, s));
+    INC_TRY(prim::exclusive_sum(st.d_temp, tb, st.d_head, st.d_uid, (int)n, s));
     hipLaunchKernelGGL(inc_runs_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, st.d_skey, st.d_sidx, st.d_head, st.d_uid, n, d_pts, st.d_ukey, st.d_ustart, st.d_psorted, st.d_ctr);
     hipLaunchKernelGGL(inc_lookup_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, st.d_ukey, st.d_ctr, st.d_keys, st.d_vid, st.table_cap - 1, st.d_uslot, st.d_unew, st.d_ctr);
     INC_TRY(hipGetLastError());
@@ -595,12 +595,12 @@ hipError_t inc_ndt_ingest(IncNdtState& st, const float4* host_pts, const float4*
         INC_TRY(ensure_evict(st, (size_t)st.n_live, s));
         hipLaunchKernelGGL(inc_collect_kernel, dim3(grid_for((size_t)st.n_slots)), dim3(kBlock), 0, s, st.d_slot_key, st.d_slot_stamp, st.n_slots, st.d_ev_stamp, st.d_ev_slot, st.d_ctr);
         size_t tb = st.temp_bytes;
-        INC_TRY(hipcub::DeviceRadixSort::SortPairs(st.d_temp, tb, st.d_ev_stamp, st.d_ev_stamp_sorted, st.d_ev_slot, st.d_ev_slot_sorted, st.n_live, 0, 64, s));
+        INC_TRY(prim::sort_pairs(st.d_temp, tb, st.d_ev_stamp, st.d_ev_stamp_sorted, st.d_ev_slot, st.d_ev_slot_sorted, st.n_live, 0, 64, s));
         hipLaunchKernelGGL(inc_evict_kernel, dim3(grid_for((size_t)n_evict)), dim3(kBlock), 0, s, st.d_ev_slot_sorted, n_evict, st.n_free, st.d_slot_key, st.d_free);
     }
     if (m_new > 0) {
         size_t tb = st.temp_bytes;
-        INC_TRY(hipcub::DeviceScan::ExclusiveSum(st.d_temp, tb, st.d_unew, st.d_urank, m, s));
+        INC_TRY(prim::exclusive_sum(st.d_temp, tb, st.d_unew, st.d_urank, m, s));
         hipLaunchKernelGGL(inc_assign_kernel, dim3(grid_for((size_t)m)), dim3(kBlock), 0, s, st.d_ukey, st.d_unew, st.d_urank, st.d_ustart, st.d_sidx, m, st.d_free,
                            n_free_after_evict, st.n_slots, epoch_hi, st.d_slot_key, st.d_slot_stamp, st.d_uslot);
     }

@@ -573,27 +573,6 @@ def test_search_parity_at_other_stack_depths(rows):
 
 
 # ----------------------------------------------------------------------------------------------- straggler hand-over
-@pytest.mark.parametrize("stop,rows", [("8", "15"), ("24", "12")])
-def test_search_parity_with_the_straggler_handover(stop, rows):
-    """Round 4 (opt-in, LOCGPU_WALK_STOP: built on the evidence of the per-query round counts, measured a net loss on the bench workload and
-    therefore off by default — profiles/experiments.md; these tests keep the measurement repeatable): a wave of the 64-lane search kernel stops once at most LOCGPU_WALK_STOP of its lanes still have work and hands those
-    queries — registers and the live rows of their LDS stacks — to a continuation kernel that packs 64 of them to a wave. Same
-    traversal, so the index-list / H,B / alignment parity tests must pass unchanged; LOCGPU_WALK_STOP_MIN_WAVES=2049 switches the
-    hand-over on for every launch of the batch kernel (otherwise only launches of 16384 waves or more use it), 24 lanes makes a
-    third of the queries travel, 12 stack rows add the deep pass and the overflow rule on top."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LOCGPU_WALK_STOP=stop, LOCGPU_WALK_STOP_MIN_WAVES="2049", LOCGPU_FAST_STACK=rows)
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_configs.py"),
-                          "-q", "-m", "gpu", "-x", "-k", "hot_search or bench_config_parity or later_chunks or (align and not sharded and not ndt and not handover)"],
-                         env=env, capture_output=True, text=True, timeout=1200, cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
-    assert " passed" in out.stdout
-
-
-# ----------------------------------------------------------------------------------------------- measurement hooks
 def test_profile_modes_and_marshalled_scans():
     """locgpu_profile_enable: 1 times all three stages, 2 only the search stage (what bench.py uses inside its timed region); a
     pre-marshalled scan list uploads the same bytes as the list itself."""
@@ -726,31 +705,6 @@ def test_hot_search_kernel_lists_when_a_candidate_descent_outgrows_the_stack(see
         ctx.close()
 
 
-def test_later_chunks_launch_only_the_open_scans(tmp_path):
-    """After the first eight iterations the host knows which scans are still open; the following chunks launch the search and
-    accumulate kernels over those only (a device list of their indices) instead of whole grids of early exits. Same bits either way:
-    a ragged nine-scan batch whose scans need from 1 to more than 8 iterations, all three ICP methods, blocking and two in flight,
-    with the list (default) and without (LOCGPU_ACTIVE_LIST=0)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = {}
-    for tag, val in (("list", "1"), ("all", "0")):
-        f = str(tmp_path / (tag + ".npz"))
-        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_active_list_case.py"), f], env=dict(os.environ, LOCGPU_ACTIVE_LIST=val),
-                           capture_output=True, text=True, timeout=600, cwd=root)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        outs[tag] = np.load(f)
-    for name in ("plane", "line", "point"):
-        it = outs["list"][name + "_it"]
-        assert it.min() <= 8 < it.max(), (name, it)   # some scans closed in the first chunk, some did not: the list was shorter than the batch
-        assert np.array_equal(it, outs["all"][name + "_it"])
-        assert np.array_equal(outs["list"][name], outs["all"][name])
-        assert np.array_equal(outs["list"][name + "_flight"], outs["all"][name + "_flight"])
-        assert np.array_equal(outs["list"][name + "_flight"][:len(it)], outs["list"][name])
-
-
 def test_nothing_leaks_over_create_use_destroy_cycles():
     """Everything the C ABI hands out — contexts, targets (ICP, NDT, asynchronous), batches, a captured graph, clouds, a submap — created,
     used and destroyed 80 times after a warm-up: the device memory comes back to the byte-ish (hipMemGetInfo) and the process's resident
@@ -847,8 +801,8 @@ def test_secular_plane_fit_agrees_with_the_four_column_fit(tmp_path):
     outs = {}
     for tag, val in (("secular", "1"), ("jacobi4", "0")):
         f = str(tmp_path / (tag + ".npz"))
-        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_plane_cache_case.py"), f],
-                           env=dict(os.environ, LOCGPU_PLANE_FIT=val, LOCGPU_PLANE_CACHE="0"), capture_output=True, text=True, timeout=600, cwd=root)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_plane_fit_case.py"), f],
+                           env=dict(os.environ, LOCGPU_PLANE_FIT=val), capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[tag] = np.load(f)
     a, b = outs["secular"], outs["jacobi4"]
@@ -861,35 +815,6 @@ def test_secular_plane_fit_agrees_with_the_four_column_fit(tmp_path):
     assert np.array_equal(hb_a[:, 42:44], hb_b[:, 42:44])  # effective_num, ok
 
 
-def test_plane_cache_gives_the_uncached_kernels_bits(tmp_path):
-    """Round 4 (opt-in, LOCGPU_PLANE_CACHE=1: built for VERDICT r3 item 5, measured slower than the plain kernels on the bench workload and
-    therefore not the default — the parity claim below is what keeps the measurement honest).
-    On batches large enough for the 64-lane search kernel the P2Plane fit kernel keeps every point's plane 4-vector and refits
-    only the points whose five neighbour indices changed since the previous iteration (the search kernel leaves one bit per query).
-    A cached vector is what the same code computed from the same five leaves, so poses, iteration counts and H/B must equal the
-    uncached kernel's (LOCGPU_PLANE_CACHE=0) bit for bit — blocking, two in flight, under hipGraph replay, on repeated alignments of
-    one batch and with another method run on the batch in between."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = {}
-    for tag, val in (("cache", "1"), ("plain", "0")):
-        f = str(tmp_path / (tag + ".npz"))
-        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_plane_cache_case.py"), f], env=dict(os.environ, LOCGPU_PLANE_CACHE=val),
-                           capture_output=True, text=True, timeout=600, cwd=root)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        outs[tag] = np.load(f)
-    c, p = outs["cache"], outs["plain"]
-    assert c["it"].min() <= 3 and c["it"].max() > 8, c["it"]  # scans that stop at once and scans that outlive the first chunk
-    for name in ("pose", "it", "pose_again", "hb", "flight", "graph", "graph_again", "line", "pose_after_line"):
-        assert np.array_equal(c[name], p[name]), name
-    for name in ("pose_again", "graph", "graph_again", "pose_after_line"):
-        assert np.array_equal(c[name], c["pose"]), name
-    assert np.array_equal(c["flight"][:len(c["pose"])], c["pose"])
-
-
-# ----------------------------------------------------------------------------------------------- two alignments in flight
 def test_align_begin_end_two_batches_in_flight(gpu_ctx, api, small_world):
     """locgpu_*_align_batch_begin / locgpu_align_batch_end: two batches (different scans, ragged counts) begun back to back and ended
     in order give bit for bit the poses, iteration counts and stats of the blocking calls — ICP and direct NDT — also when the

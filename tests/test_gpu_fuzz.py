@@ -27,12 +27,6 @@ def test_fuzz_search_short(rows):
     assert "mismatching runs 0" in out, out[-2000:]
 
 
-def test_fuzz_search_short_with_the_straggler_handover():
-    """The same 45 cases with every batch-kernel launch handing its last 12 lanes per wave to the continuation kernel."""
-    out = _run("fuzz_search.py", "--cases", "45", "--seed", "101", env={"LOCGPU_WALK_STOP": "12", "LOCGPU_WALK_STOP_MIN_WAVES": "2049"})
-    assert "mismatching runs 0" in out, out[-2000:]
-
-
 def test_fuzz_filters_short():
     assert "mismatches 0" in _run("fuzz_filters.py", "--cases", "400", "--seed", "7")
 
