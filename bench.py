@@ -129,11 +129,11 @@ PMC_PASSES = [  # one rocprofv3 --pmc run each, nothing but --pmc (MI355X_MICROA
 ]
 
 
-def measure_counters_live(passthrough_args, budget_s=300.0):
+def measure_counters_live(passthrough_args, budget_s=300.0, steps=2, pipeline=1, extra=4):
     """Per-kernel hardware counters of this very workload, measured NOW: child runs of this script (2 timed + 4 profiled steps, one
     alignment in flight) under `rocprofv3 --pmc <group>` — separate passes, no tracing, the program directly after `--`, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes. Children are ordinary subprocesses (never an exec of this process).
-    Returns ({kernel base name: {counter: mean per launch, "launches": n}}, note)."""
+    Returns ({kernel base name: {counter: total over the child run, "launches": n}, "_steps": steps the child ran}, note)."""
     import collections
     import csv
     import glob
@@ -142,7 +142,7 @@ def measure_counters_live(passthrough_args, budget_s=300.0):
     import tempfile
     if not shutil.which("rocprofv3"):
         return {}, "rocprofv3 not on PATH"
-    child = ["python3", os.path.abspath(__file__)] + list(passthrough_args) + ["--steps", "2", "--warmup", "0", "--pipeline", "1", "--no-cpu-baseline", "--traffic", "none"]
+    child = [os.path.realpath(sys.executable), os.path.abspath(__file__)] + list(passthrough_args) + ["--steps", str(steps), "--warmup", "0", "--pipeline", str(pipeline), "--extra-steps", str(extra), "--no-cpu-baseline", "--traffic", "none"]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     t_start = time.time()
     notes = []
@@ -165,17 +165,18 @@ def measure_counters_live(passthrough_args, budget_s=300.0):
             shutil.rmtree(outdir, ignore_errors=True)
     out = {}
     for k, cs in agg.items():
-        out[k] = {c: sum(v) / len(v) for c, v in cs.items()}
+        out[k] = {c: sum(v) for c, v in cs.items()}  # TOTALS over the child run: the caller divides by the steps the child ran
         out[k]["launches"] = max(len(v) for v in cs.values())
-    return out, "live: rocprofv3 --pmc passes %s, 2 + 4 steps each%s" % (" | ".join(" ".join(c) for c in PMC_PASSES), ("; " + "; ".join(notes)) if notes else "")
+    out["_steps"] = steps + extra  # steps of the workload every hot kernel ran in the child (the fit kernels one more: the instrumented pass)
+    return out, "live: rocprofv3 --pmc passes %s, %d timed + the profiled steps each%s" % (" | ".join(" ".join(c) for c in PMC_PASSES), steps, ("; " + "; ".join(notes)) if notes else "")
 
 
-def measure_lane_efficiency_live(passthrough_args, budget_s=120.0):
+def measure_lane_efficiency_live(passthrough_args, budget_s=120.0, steps=1, pipeline=1, resident=True):
     """Lane efficiency of the search kernel's main loop on this workload, measured NOW by one child run of this script on the
     library's diagnostic build (LOCGPU_STAMP=1: the same kernel counting, per lane, the rounds the lane needed and the rounds its
     wave ran; its timing is meaningless and not used). Returns (useful / paid | None, note)."""
     import subprocess
-    child = ["python3", os.path.abspath(__file__)] + list(passthrough_args) + ["--steps", "1", "--warmup", "0", "--pipeline", "1", "--no-cpu-baseline", "--traffic", "none", "--resident"]
+    child = [os.path.realpath(sys.executable), os.path.abspath(__file__)] + list(passthrough_args) + ["--steps", str(steps), "--warmup", "0", "--pipeline", str(pipeline), "--no-cpu-baseline", "--traffic", "none"] + (["--resident"] if resident and "--resident" not in passthrough_args else [])
     try:
         out = subprocess.run(child, capture_output=True, text=True, timeout=budget_s, env=dict(os.environ, LOCGPU_STAMP="1"), cwd=ROOT)
         for ln in out.stdout.splitlines():
@@ -278,6 +279,11 @@ def main():
                          "overlap there): they come from --extra-steps further steps of the same workload run one at a time behind it")
     ap.add_argument("--extra-steps", type=int, default=4, help="untimed steps behind the timed region, one alignment at a time with HIP events around every stage")
     ap.add_argument("--total-scans", type=int, default=256)
+    ap.add_argument("--pool-slots", type=int, default=-1,
+                    help="run the steps through the library's open-scan pool (locgpu_pool: one launch sequence per iteration over the open scans of "
+                         "all steps begun) with this many scan slots; 0 = plain batches, three alignments in flight; -1 (default) = 256 slots "
+                         "whenever a rank's step holds fewer than 256 scans, plain batches otherwise")
+    ap.add_argument("--pool-chunk", type=int, default=0, help="pool: iterations between two looks at the flags (0 = the library's default)")
     ap.add_argument("--traffic", choices=["live", "profiles", "none"], default="live",
                     help="roofline counters: live = rocprofv3 --pmc child runs + one diagnostic-build child run now (1 GPU only), profiles = newest committed traffic collection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -344,14 +350,6 @@ def main():
     B_local = len(scans)
     pts_per_scan = len(scans[0])
 
-    def new_batch():
-        return ctx.batch(scans, first=lo, n_total=n_total) if strong else ctx.batch(scans)
-
-    depth = args.pipeline if args.pipeline else 3
-    # resident: `depth` batches hold the same scans; streaming: one more, so that the copy for step g+1 never lands in a batch
-    # that an alignment in flight (steps g, g-1) is reading
-    bufs = [new_batch() for _ in range(depth if args.resident else depth + 1)]
-    scans_c = api.MarshalledScans(scans)  # the (pointer, count) arrays a C caller of locgpu_batch_upload_async already holds
     method = dict(p2plane=api.P2PLANE, p2line=api.P2LINE, p2p=api.P2P, ndt=-1)[args.method]
     opts = api.icp_opts(method=max(method, 0))  # every other field = reference default
     if args.search == "grid":
@@ -362,6 +360,24 @@ def main():
         t0 = time.time()
         ctx.ndt_set_target(map_xyz)           # NdtOptions defaults: voxel 1.0, NEARBY6, DIRECT_NDT
         t_ingest = time.time() - t0
+
+    def new_batch():
+        return ctx.batch(scans, first=lo, n_total=n_total) if strong else ctx.batch(scans)
+
+    # The open-scan pool (locgpu_pool, scan_pool.hip): by default whenever a rank's step is small — 32 scans per rank of configs[3] on
+    # eight GPUs — with room for about 256 scans of this rank: the steps begun share one launch sequence per Gauss–Newton iteration.
+    pool_slots = args.pool_slots
+    if pool_slots < 0:
+        pool_slots = n_total * (-(-256 // max(B_local, 1))) if (0 < B_local < 256 and args.search != "grid" and not args.resident) else 0
+    use_pool = pool_slots > 0
+    if use_pool and (args.search == "grid" or args.resident or pool_slots < n_total):
+        raise SystemExit("bench.py: --pool-slots needs room for one step (%d scans) and excludes --search grid and --resident" % n_total)
+    depth = args.pipeline if args.pipeline else (max(1, pool_slots // n_total) if use_pool else 3)
+    # plain batches — resident: `depth` batches hold the same scans; streaming: one more, so that the copy for step g+1 never lands
+    # in a batch that an alignment in flight (steps g, g-1) is reading. Pool: one plain batch for the instrumented pass.
+    bufs = [new_batch() for _ in range(1 if use_pool else (depth if args.resident else depth + 1))]
+    scans_c = api.MarshalledScans(scans) if scans else []  # the (pointer, count) arrays a C caller of locgpu_batch_upload_async already holds
+    pool = api.Pool(ctx, slots=pool_slots, max_points=max(pts_per_scan, 1), scans_per_job=n_total, chunk=args.pool_chunk, opts=opts, ndt=(method < 0)) if use_pool else None
 
     def align_batch(b):
         return ctx.ndt_align_batch(b, inits) if method < 0 else ctx.icp_align_batch(b, inits, opts)
@@ -390,13 +406,14 @@ def main():
         return b
 
     def run_steps(n):
-        """Exactly n steps, begun and ended in here; at most `depth` alignments in flight."""
+        """Exactly n steps, begun and ended in here; at most `depth` alignments in flight. Pool: a step = one job — its scans are
+        submitted (the copy into free slots starts at once and runs beside the pool's iterations) and collected by ticket."""
         inflight, begun, res = [], 0, None
         while begun < n or inflight:
             while begun < n and len(inflight) < depth:
-                inflight.append(begin_step())
+                inflight.append(pool.submit(scans_c, inits, first=lo, n_total=n_total) if use_pool else begin_step())
                 begun += 1
-            res = ctx.align_batch_end(inflight.pop(0))
+            res = pool.wait(inflight.pop(0)) if use_pool else ctx.align_batch_end(inflight.pop(0))
         return res
 
     def barrier():
@@ -410,7 +427,7 @@ def main():
     vc = ctx.visit_count_read(reset=True)
     ctx.visit_count_enable(False)
 
-    if not args.resident:  # the copy for the first step (every later one is started by the step before it)
+    if not args.resident and not use_pool:  # the copy for the first step (every later one is started by the step before it)
         bufs[g_step[0] % len(bufs)].upload_async(scans_c)
     run_steps(args.warmup)
 
@@ -430,14 +447,18 @@ def main():
         b.upload_wait()
     # ---- kernel durations: `extra` further steps of the same workload, ONE alignment at a time (launches of different batches
     # overlap in the timed region), HIP events on the library's stream around every stage of every iteration
-    n_extra = max(1, args.extra_steps)
+    n_extra = max(1, args.extra_steps, 2 * depth if use_pool else 0)  # pool: at least two pools' worth, so that the launches profiled are steady-state ones
     ctx.profile_read(reset=True)
     ctx.profile_enable(1)
-    for _ in range(n_extra):
-        align_batch(bufs[0])
+    if use_pool:
+        run_steps(n_extra)
+    else:
+        for _ in range(n_extra):
+            align_batch(bufs[0])
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
-    stage_src = "HIP events around every stage of %d further steps of the same workload, one alignment at a time, right behind the timed region" % n_extra
+    stage_src = ("HIP events around every stage of %d further steps of the same workload through the pool (%d steps in flight), right behind the timed region" % (n_extra, depth)) if use_pool else \
+        "HIP events around every stage of %d further steps of the same workload, one alignment at a time, right behind the timed region" % n_extra
 
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -478,15 +499,22 @@ def main():
         counters, counters_note, lane_eff, lane_note = {}, "not collected", None, "not collected"
         if args.traffic == "live" and world == 1 and dist is None:
             passthrough = ["--scans-per-gpu", str(args.scans_per_gpu), "--map-points", str(args.map_points), "--method", args.method,
-                           "--search", args.search, "--scaling", args.scaling, "--total-scans", str(args.total_scans)] + (["--resident"] if args.resident else [])
-            counters, counters_note = measure_counters_live(passthrough)
+                           "--search", args.search, "--scaling", args.scaling, "--total-scans", str(args.total_scans), "--pool-slots", str(pool_slots),
+                           "--pool-chunk", str(args.pool_chunk)] + (["--resident"] if args.resident else [])
+            counters, counters_note = measure_counters_live(passthrough, steps=(2 * depth if use_pool else 2), pipeline=(0 if use_pool else 1), extra=n_extra)
             if method >= 0 and args.search != "grid":
-                lane_eff, lane_note = measure_lane_efficiency_live(passthrough)
+                lane_eff, lane_note = measure_lane_efficiency_live(passthrough, steps=(depth if use_pool else 1), pipeline=(0 if use_pool else 1), resident=not use_pool)
 
         def stage_counter(kernels, name):
-            """Sum over the stage's kernels of the counter's mean per launch (every kernel of a stage is launched once per iteration)."""
-            vals = [counters[kk][name] for kk in counters for want in kernels if kk.startswith(want) and name in counters[kk]]
-            return sum(vals) if vals else None
+            """The counter summed over the stage's kernels, PER LAUNCH of the stage as this process ran it: the child's total ÷ the steps
+            the child ran (the same scans and iterations: the same work per step however the launches cut it) ÷ this process's launches
+            per step. The fit kernels ran once more in the child (its instrumented pass uses them too)."""
+            vals = [counters[kk][name] for kk in counters if kk != "_steps" for want in kernels if kk.startswith(want) and name in counters[kk]]
+            if not vals or not counters.get("_steps"):
+                return None
+            child_steps = counters["_steps"] + (1 if kernels is accum_kernels else 0)
+            lps = (prof["accum_n"] if kernels is accum_kernels else prof["search_n"]) / n_extra
+            return sum(vals) / child_steps / max(lps, 1e-9)
 
         def hbm_bytes(kernels):
             f, w = stage_counter(kernels, "FETCH_SIZE"), stage_counter(kernels, "WRITE_SIZE")
@@ -506,28 +534,39 @@ def main():
             t2 = load_traffic(kname, args.scans_per_gpu, args.map_points, args.method)
             if t2 is not None:
                 traffic, traffic_note = t2, "copied from the newest committed profiles/*traffic*.json of this workload (" + counters_note + ")"
-        achieved = (kbytes / 1e9) / (kt / 1e3) if kt > 0 else 0.0
+        nominal_gbs = (kbytes / 1e9) / (kt / 1e3) if kt > 0 else 0.0
         valu_n, valu_frac = issue_frac(kset, ["SQ_INSTS_VALU"], kavg)
-        roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                        frac_note="nominal: SURVEY 8(d)'s algorithmic bytes (one 16-byte load per node visit) over launch time; most of those loads are "
-                                  "served by L1/L2, so this is an effective rate, not HBM traffic, and may pass 1 — hbm_frac is the measured HBM share, "
-                                  "issue.valu_issue_frac the bound that binds",
+        ISSUE_PEAK = SIMDS * CLOCK_HZ / 4.0 / 1e9  # G wave64 VALU instructions per second the chip can issue at the nominal clock
+        is_search = kset is search_kernels
+        # The bound that binds. Both hot kernels are bound by vector-instruction issue, not by HBM (the tree traversal is a
+        # cache-resident pointer chase: ~91 % of its node loads hit L1; its HBM traffic is a few per cent of the roofline), so
+        # `frac` is the VALU issue fraction — never above 1 by construction. The byte model of SURVEY 8(d) is kept beside it as
+        # nominal_bytes_frac (an EFFECTIVE rate: it prices every node visit as HBM bytes and can pass 1); hbm_frac is what the PMC
+        # counters say actually left HBM.
+        roofline = dict(bound="valu_issue", kernel=kname,
+                        achieved=(round(valu_n / (kavg / 1e3) / 1e9, 2) if valu_n and kavg > 0 else None), peak=round(ISSUE_PEAK, 1), unit="G wave64-VALU-inst/s",
+                        frac=(round(valu_frac, 4) if valu_frac else None),
+                        clock_note="peak = 1024 SIMDs x 2.4 GHz (nominal) / 4 cycles per wave64 VALU instruction; under this load the chip holds about 1.95 GHz "
+                                   "(profiles/r04_pmc_kernels.md), i.e. frac / 0.81 of what it can issue at the clock it runs at",
+                        traffic=traffic,
                         hbm_frac=(round(traffic / (kavg / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and kavg > 0 else None),
-                        traffic_source=traffic_note,
+                        hbm_peak_gbs=HBM_PEAK_GBS, traffic_source=traffic_note,
+                        nominal_bytes_frac=round(nominal_gbs / HBM_PEAK_GBS, 5), nominal_bytes_gbs=round(nominal_gbs, 2),
+                        nominal_bytes_note="SURVEY 8(d)'s algorithmic bytes (one 16-byte load per tree node visited + source + index lists) over launch time and 8 TB/s: an "
+                                           "effective rate — those loads are served by L1/L2 — not HBM traffic; it may pass 1. north_star's >= 50 %-of-HBM target is "
+                                           "NOT met in HBM's own terms (see hbm_frac): the traversal does not need the bytes",
                         algorithmic_bytes_per_launch=int(kbytes / max(launches_per_step, 1)), avg_launch_ms=round(kavg, 5),
                         launches_per_step=launches_per_step,
+                        valu_insts_per_launch=(int(valu_n) if valu_n else None),
                         nodes_per_query=round(vc["nodes"] / max(q, 1), 2), leaves_per_query=round(vc["leaves"] / max(q, 1), 2))
-        if method >= 0 and args.search != "grid":
+        if method >= 0 and args.search != "grid" and is_search:
             # what the stage cannot avoid moving: every query's source point and index list once, and every tree slot any query of the
             # launch reads, once (counted by the instrumented pass, per launch)
             roofline["compulsory_bytes"] = int((q * (16 + 4 * k) + vc["distinct_slots"] * 8) / max(launches_per_step, 1))
-            roofline["issue"] = dict(bound="valu_issue", valu_insts_per_launch=(int(valu_n) if valu_n else None),
-                                     valu_issue_frac=(round(valu_frac, 4) if valu_frac else None),
-                                     peak="1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
-                                     lane_efficiency=(round(lane_eff, 4) if lane_eff else None), lane_efficiency_source=lane_note,
-                                     note="the kernel is bound by vector-instruction issue: valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (SIMDs x launch time) at the nominal "
-                                          "clock; lane_efficiency = main-loop rounds the lanes need / rounds their waves run (a wave runs until its slowest lane is done)")
+            roofline["lane_efficiency"] = round(lane_eff, 4) if lane_eff else None
+            roofline["lane_efficiency_source"] = lane_note
+            roofline["note"] = ("valu_issue frac = SQ_INSTS_VALU x 4 cycles / (SIMDs x launch time) at the nominal clock; lane_efficiency = main-loop rounds the "
+                                "lanes need / rounds their waves run (a wave runs until its slowest lane is done)")
         # which BASELINE.json configuration the arguments amount to
         if strong:
             cfg_name = "BASELINE configs[3] (%d scans in all, sharded over %d GPU(s), RCCL all-reduce)" % (n_total, world)
@@ -538,15 +577,17 @@ def main():
         else:
             cfg_name = "%d-pt map (not a BASELINE configuration)" % args.map_points
         mode = "scans resident in HBM before the timed region (secondary number)" if args.resident else \
-               "includes scan H2D: every step aligns a batch copied host->HBM for it (pinned double buffer, copy stream, overlapped with the previous step)"
+               ("includes scan H2D: every step's scans are copied host->HBM into free pool slots (pinned staging, copy stream, beside the pool's iterations)" if use_pool else
+                "includes scan H2D: every step aligns a batch copied host->HBM for it (pinned double buffer, copy stream, overlapped with the previous step)")
         shard = ("strong scaling: %d scans in all sharded over %d rank(s), per-iteration RCCL all-reduce of the per-scan normal equations" % (n_total, world)) if strong \
             else "scans sharded by rank, no collective"
         line = dict(metric="scans/sec (64x1800-pt scan vs 10M-pt map) + ICP iter ms", value=round(value, 3), unit="scans/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 4),
                     higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f64", search_dtype="f32", data="synthetic",
                     config=dict(workload="%s: %d scans/GPU x %d pts (64x1800, cityblock-v1) vs one %d-pt map, "
-                                         "%s, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), %s; %s; %d alignment(s) in flight"
-                                         % (cfg_name, B_local, pts_per_scan, args.map_points, "direct NDT (voxel 1.0, NEARBY6)" if method < 0 else args.method.upper() + " ICP", shard, mode, depth),
+                                         "%s, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), %s; %s; %s"
+                                         % (cfg_name, B_local, pts_per_scan, args.map_points, "direct NDT (voxel 1.0, NEARBY6)" if method < 0 else args.method.upper() + " ICP", shard, mode,
+                                            ("open-scan pool of %d slots, %d steps in flight" % (pool_slots, depth)) if use_pool else "%d alignment(s) in flight" % depth),
                                 scans_per_gpu=B_local, map_points=args.map_points, scan_h2d_in_timed_region=not args.resident, pipeline_depth=depth,
                                 search_mode=dict(tree="tree_faithful_ann", tree_exact="tree_faithful_exact", grid="grid_exact")[args.search], tree_depth=tinfo["depth"],
                                 tree_bytes=tinfo["bytes"]),
@@ -559,6 +600,8 @@ def main():
                     median_translation_error_to_truth_m=round(err_t, 4),
                     setup_s=dict(map_gen=round(t_map, 2), tree_ingest=round(t_ingest, 2)),
                     roofline=roofline)
+        if use_pool:
+            line["pool"] = dict(slots=pool_slots, steps_in_flight=depth, chunk=(args.pool_chunk or 4), **{k: v for k, v in pool.info().items() if k in ("iterations", "scan_iterations")})
         line["scans_per_rank"] = B_local
         line["rccl_ranks"] = (ctx.comm_info()[1] if use_comm else (world if dist is not None else 1))  # ranks RCCL joined: the library's communicator (strong), torch's process group (weak)
         line["rccl_use"] = ("per-iteration all-reduce + tree broadcast inside liblocgpu.so (locgpu_comm_info)" if use_comm else
@@ -573,14 +616,15 @@ def main():
             k2_avg = prof["accum_ms"]
             f64_n, f64_frac = issue_frac(accum_kernels, ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"], k2_avg)
             v_n, v_frac = issue_frac(accum_kernels, ["SQ_INSTS_VALU"], k2_avg)
-            line["roofline_k2"] = dict(bound="hbm", kernel=accum_kernels[0], achieved=round(a_gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                                       frac=round(a_gbs / HBM_PEAK_GBS, 5), ms_per_step=round(t_accum, 4), avg_launch_ms=round(k2_avg, 5), traffic=k2_traffic,
+            line["roofline_k2"] = dict(bound="valu_issue (two thirds of it FP64)", kernel=accum_kernels[0],
+                                       achieved=(round(v_n / (k2_avg / 1e3) / 1e9, 2) if v_n and k2_avg > 0 else None), peak=round(SIMDS * CLOCK_HZ / 4.0 / 1e9, 1),
+                                       unit="G wave64-VALU-inst/s", frac=(round(v_frac, 4) if v_frac else None),
+                                       fp64_issue_frac=(round(f64_frac, 4) if f64_frac else None),
+                                       fp64_insts_per_launch=(int(f64_n) if f64_n else None), valu_insts_per_launch=(int(v_n) if v_n else None),
+                                       ms_per_step=round(t_accum, 4), avg_launch_ms=round(k2_avg, 5), traffic=k2_traffic,
                                        hbm_frac=(round(k2_traffic / (k2_avg / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if k2_traffic and k2_avg > 0 else None),
-                                       issue=dict(bound="valu_issue", fp64_insts_per_launch=(int(f64_n) if f64_n else None),
-                                                  fp64_issue_frac=(round(f64_frac, 4) if f64_frac else None),
-                                                  valu_insts_per_launch=(int(v_n) if v_n else None), valu_issue_frac=(round(v_frac, 4) if v_frac else None),
-                                                  note="bound by vector-instruction issue: valu_issue_frac is at the nominal 2.4 GHz (the chip holds about 1.95 GHz under this load); about two thirds of the instructions are the plane fit"),
-                                       note=stage_src)
+                                       nominal_bytes_frac=round(a_gbs / HBM_PEAK_GBS, 5),
+                                       note="frac at the nominal 2.4 GHz (the chip holds about 1.95 GHz under this load); about two thirds of the instructions are the plane fit; " + stage_src)
         if world == 1 and not args.no_cpu_baseline and args.search == "tree":
             cb, cpu_poses = cpu_baseline(map_xyz, scans, inits, args.cpu_seconds, args.method)
             n = len(cpu_poses)
@@ -590,6 +634,8 @@ def main():
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
 
+    if pool is not None:
+        pool.close()
     for b in bufs:
         b.close()
     ctx.close()

@@ -39,6 +39,8 @@ ABI_SYMBOLS = [
     "locgpu_bfnn_set_target", "locgpu_bfnn_knn",
     "locgpu_icp_align_batch_begin", "locgpu_ndt_align_batch_begin", "locgpu_align_batch_end",
     "locgpu_comm_unique_id", "locgpu_comm_init", "locgpu_comm_info", "locgpu_batch_create_sharded", "locgpu_icp_set_target_bcast",
+    "locgpu_pool_opts_default", "locgpu_pool_create", "locgpu_pool_destroy", "locgpu_pool_submit", "locgpu_pool_wait", "locgpu_pool_info",
+    "locgpu_pool_profile_read",
 ]
 COMM_ID_BYTES = 128
 NO_INTENSITY = ctypes.c_size_t(-1).value
@@ -60,6 +62,11 @@ class NdtOpts(ctypes.Structure):
     _fields_ = [("max_iteration", ctypes.c_int32), ("voxel_size", ctypes.c_double), ("min_effective_pts", ctypes.c_int32),
                 ("min_pts_in_voxel", ctypes.c_int32), ("eps", ctypes.c_double), ("res_outlier_th", ctypes.c_double),
                 ("nearby_type", ctypes.c_int32), ("method", ctypes.c_int32), ("capacity", ctypes.c_int64)]
+
+
+class PoolOpts(ctypes.Structure):
+    _fields_ = [("slots", ctypes.c_int32), ("scans_per_job", ctypes.c_int32), ("chunk", ctypes.c_int32), ("matcher", ctypes.c_int32),
+                ("max_points", ctypes.c_uint64), ("icp", IcpOpts)]
 
 
 class AlignStats(ctypes.Structure):
@@ -129,6 +136,9 @@ def lib():
             "locgpu_batch_create_sharded": (i32, [vp, vp, vp, sz, i32, i32, i32, vp]),
             "locgpu_icp_set_target_bcast": (i32, [vp, vp, sz, sz, i32]),
             "locgpu_bfnn_set_target": (i32, [vp, vp, sz, sz]), "locgpu_bfnn_knn": (i32, [vp, vp, sz, i32, vp]),
+            "locgpu_pool_opts_default": (None, [vp]), "locgpu_pool_create": (i32, [vp, vp, vp]), "locgpu_pool_destroy": (None, [vp]),
+            "locgpu_pool_submit": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, vp]), "locgpu_pool_wait": (i32, [vp, ctypes.c_int64, vp, vp]),
+            "locgpu_pool_info": (i32, [vp, vp]), "locgpu_pool_profile_read": (i32, [vp, vp, i32]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -654,6 +664,66 @@ class Batch:
             lib().locgpu_batch_destroy(self._h)
         self._h = None
         self._keep = None
+
+    def __del__(self):
+        self.close()
+
+
+class Pool:
+    """The open-scan pool (locgpu_pool): jobs of scans submitted at any time, iterated together, collected by ticket."""
+
+    def __init__(self, ctx, slots, max_points, scans_per_job=0, chunk=0, opts=None, ndt=False):
+        self.ctx = ctx
+        self._h = ctypes.c_void_p()
+        self._keep = {}
+        o = PoolOpts()
+        lib().locgpu_pool_opts_default(ctypes.byref(o))
+        o.slots, o.scans_per_job, o.chunk, o.matcher, o.max_points = int(slots), int(scans_per_job), int(chunk), (1 if ndt else 0), int(max_points)
+        if opts is not None:
+            o.icp = opts
+        ctx._check(lib().locgpu_pool_create(ctx._h, ctypes.byref(o), ctypes.byref(self._h)))
+
+    def submit(self, scans, init_poses, first=0, n_total=None):
+        """scans: the scans this rank holds of the job (a list or MarshalledScans; may be empty on a rank of a sharded job);
+        init_poses: [n_total, 7]. Returns the ticket."""
+        n_total = len(scans) if n_total is None else int(n_total)
+        ip = _pose(init_poses).reshape(n_total, 7)
+        t = ctypes.c_int64(0)
+        if len(scans):
+            sc, ptrs, cnts, stride = Batch._marshal(scans)
+        else:
+            sc, ptrs, cnts, stride = [], None, None, 16
+        rc = lib().locgpu_pool_submit(self._h, ptrs, cnts, stride, len(sc), int(first), n_total, ip.ctypes.data, ctypes.byref(t))
+        self.ctx._check(rc)
+        self._keep = {t.value: (sc, ptrs, cnts, n_total)}  # the clouds of a submit stay alive until the next call on the pool
+        self._n = getattr(self, "_n", {})
+        self._n[t.value] = n_total
+        return t.value
+
+    def wait(self, ticket):
+        n = self._n.pop(ticket, None)
+        if n is None:
+            raise LocGpuError(-1, "pool.wait: unknown ticket (a ticket is good once)")
+        out = np.zeros((n, 7))
+        st = (AlignStats * n)()
+        self.ctx._check(lib().locgpu_pool_wait(self._h, ctypes.c_int64(ticket), out.ctypes.data, st))
+        return out, [_stats_dict(s) for s in st]
+
+    def info(self):
+        out = (ctypes.c_int64 * 6)()
+        self.ctx._check(lib().locgpu_pool_info(self._h, out))
+        return dict(slots=out[0], free=out[1], jobs=out[2], iterations=out[3], scan_iterations=out[4], open=out[5])
+
+    def profile_read(self, reset=True):
+        out = (ctypes.c_double * 2)()
+        self.ctx._check(lib().locgpu_pool_profile_read(self._h, out, 1 if reset else 0))
+        return dict(chunk_ms=out[0], chunks=int(out[1]))
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib().locgpu_pool_destroy(self._h)
+        self._h = None
+        self._keep = {}
 
     def __del__(self):
         self.close()

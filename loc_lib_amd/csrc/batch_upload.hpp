@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -31,7 +32,10 @@ struct Uploader {  // per context
     std::vector<char> slot_busy;   // the slot's event has been recorded: its last copy may still be reading it (kept across uploads)
     std::thread worker;
     bool worker_active = false;
+    std::atomic<bool> worker_done{false};  // the worker has enqueued its last copy (it still has to be joined)
     locgpu_batch* current = nullptr;  // batch of the running upload
+    struct BatchUploadState* current_st = nullptr;  // where its event and status live: the batch's own state, or a pool job's
+    std::vector<int> dst;             // scan i of the upload goes to scan slot dst[i] of the batch (empty: slot i, and the counts are copied too)
     int rc = 0;
     std::string err;
     // arguments of the running upload (the caller keeps the clouds alive until upload_join)
@@ -54,6 +58,12 @@ void pack_points(const char* base, size_t stride, size_t n, float4* dst);
 
 // Starts packing + copying `srcs` into b's source array. Returns a locgpu_status; on LOCGPU_OK the work continues on a worker thread.
 int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts, size_t stride_bytes);
+// The same for `n` scans that go to the scan slots dst[0..n) of b (a scan pool's storage, scan_pool.hip): only the points move —
+// the pool hands the counts to the device itself — and the event behind the last copy is st->done (one per pool job).
+int upload_start_slots(locgpu_batch* b, BatchUploadState* st, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n, const int* dst);
+// Is the upload whose state is `st` the one the context's worker was started for and not joined yet? *packing (optional): the
+// worker is still reading the host clouds.
+bool upload_running_for(locgpu_ctx* ctx, const BatchUploadState* st, bool* packing = nullptr);
 // Waits until the context's worker has read every host cloud and enqueued every copy (of whatever batch it was working for);
 // returns that upload's status. The copies themselves may still be in flight: upload_order_after() makes a stream wait for them.
 int upload_join(locgpu_ctx* ctx);

@@ -142,8 +142,15 @@ namespace locgpu {
 int fail(locgpu_ctx* ctx, int code, const std::string& msg);
 bool hip_ok(locgpu_ctx* ctx, hipError_t e, const char* what);
 
-// ndt_api.hip
+// locgpu_api.hip
 void ndt_free(locgpu_ctx* ctx);
+// Device buffers + pinned result staging for n_scans scans of at most max_n points each; no points yet. n_total >= 0: a sharded batch.
+int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch** out, int first = 0, int n_total = -1);
+void free_batch(locgpu_batch* b);
+// Validate the matcher's options against the context's target; fill the Gauss–Newton parameters of an alignment.
+int check_icp(locgpu_ctx* ctx, const locgpu_icp_opts* o, GnParams& prm, int& k, float& alpha_eff);
+int check_ndt(locgpu_ctx* ctx, GnParams& prm);
+bool comm_all_reduce_f64(locgpu_ctx* ctx, double* buf, size_t count, hipStream_t s);
 
 }  // namespace locgpu
 

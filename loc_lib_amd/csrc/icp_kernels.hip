@@ -607,14 +607,16 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ row
 // K3: one 256-thread block per scan. Sums the block partials in a fixed order, then thread 0 runs the
 // reference's checks and update (icp_registration.cpp:204-211 + 362-375; ndt_registration.cpp:435-459).
 // hb_out (optional): per scan 44 doubles = H (36, row-major), B (6), effective_num, ok.
+// scans (optional): the scans to solve — block i takes scan scans[i] (a scan pool solves its open slots only, scan_pool.hip).
 __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restrict__ partials, int blocks_per_scan, PoseState* __restrict__ st,
-                                                          GnParams prm, int do_update, double* __restrict__ hb_out, unsigned int* __restrict__ list_counts) {
+                                                          GnParams prm, int do_update, double* __restrict__ hb_out, unsigned int* __restrict__ list_counts,
+                                                          const int* __restrict__ scans) {
     __shared__ double s_sum[kBlock / kAccW][kAccW];
     __shared__ double s_lu[36 + 6];
-    const int scan = blockIdx.x;
-    // The search stage's work-list counters (fast kernel → redo kernel) are consumed by now: zero them for the next iteration's
+    const int scan = scans ? scans[blockIdx.x] : (int)blockIdx.x;
+    // The search stage's work-list counters (walk kernel → deep pass → redo kernel) are consumed by now: zero them for the next iteration's
     // search instead of paying two fill launches per iteration (a single-scan alignment is launch-latency bound).
-    if (list_counts && scan == 0 && threadIdx.x < 4) list_counts[threadIdx.x] = 0u;
+    if (list_counts && blockIdx.x == 0 && threadIdx.x < 4) list_counts[threadIdx.x] = 0u;
     if (st[scan].done) return;
     const double col_total = reduce_partials(partials + (size_t)scan * blocks_per_scan * kAccW, blocks_per_scan, true, s_sum);
     if (threadIdx.x < kAccW) s_sum[0][threadIdx.x] = col_total;
@@ -674,12 +676,13 @@ __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restri
 }
 
 // First half of gn_solve_kernel for sharded batches (see launch.hpp): one block per GLOBAL scan.
+// owned (optional, scan pools): owned[g] != 0 where this rank holds the points of slot g; then first = 0 and n_local = all slots.
 __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* __restrict__ partials, int blocks_per_scan, const PoseState* __restrict__ st_all,
-                                                              int first, int n_local, double* __restrict__ acc) {
+                                                              int first, int n_local, double* __restrict__ acc, const unsigned char* __restrict__ owned) {
     __shared__ double s_sum[kBlock / kAccW][kAccW];
     const int g = blockIdx.x;
     const int scan = g - first;
-    const bool mine = scan >= 0 && scan < n_local && !st_all[g].done;  // a finished scan's partials are stale: contribute zeros (nobody reads them)
+    const bool mine = scan >= 0 && scan < n_local && !st_all[g].done && (!owned || owned[g]);  // a finished scan's partials are stale: contribute zeros (nobody reads them)
     const double t = reduce_partials(partials + (size_t)(mine ? scan : 0) * blocks_per_scan * kAccW, blocks_per_scan, mine, s_sum);
     if (threadIdx.x < kAccW) acc[(size_t)g * kAccW + threadIdx.x] = threadIdx.x < 28 ? t : 0.0;
 }
@@ -910,14 +913,18 @@ bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, i
     return false;
 }
 
+// Points per thread of the accumulate kernels for a batch of n_scans scans of at most max_n points: amortise the block reduction
+// when the batch already fills the chip; 1 for small launches (latency). The plane kernel's reduction is cheap (LDS rows, see
+// there): 4 is as good as 8 and leaves a finer tail; the line and point kernels still pay a 28-value wave reduction per block.
+int icp_accum_split(int method, int max_n, int n_scans) {
+    const long total_blocks = (long)((max_n + kBlock - 1) / kBlock) * n_scans;
+    return total_blocks >= 8192 ? (method == 2 ? 4 : 8) : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1));
+}
+
 int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
     const int blocks = (a.max_n + kBlock - 1) / kBlock;
-    // points per thread: amortise the block reduction when the batch already fills the chip; 1 for small launches (latency).
-    // The plane kernel's reduction is cheap (LDS rows, see there): 4 is as good as 8 and leaves a finer tail; the line and point
-    // kernels still pay a 28-value wave reduction per block.
-    const long total_blocks = (long)blocks * a.n_scans;  // ALL scans of the batch, open or not: the split — hence the order of the sums — must not depend on a.active
-    int pts = (total_blocks >= 8192 ? (method == 2 ? 4 : 8) : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1)));
-    if (pts > 8) pts = 8;
+    int pts = icp_accum_split(method, a.max_n, a.n_scans);  // ALL scans of the batch, open or not: the split — hence the order of the sums — must not depend on a.active
+    if (a.split_scans > 0) pts = icp_accum_split(method, a.max_n, a.split_scans);
     const dim3 grid((blocks + pts - 1) / pts, a.active ? a.n_active : a.n_scans);
     if (method == 2) {
         if (plane_fit_mode() == 1)
@@ -932,13 +939,13 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
 }
 
 void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
-                     unsigned int* list_counts, hipStream_t s) {
-    hipLaunchKernelGGL(gn_solve_kernel, dim3(n_scans), dim3(kBlock), 0, s, partials, blocks_per_scan, st, prm, do_update, hb_out, list_counts);
+                     unsigned int* list_counts, hipStream_t s, const int* scans) {
+    hipLaunchKernelGGL(gn_solve_kernel, dim3(n_scans), dim3(kBlock), 0, s, partials, blocks_per_scan, st, prm, do_update, hb_out, list_counts, scans);
 }
 
 void launch_sum_partials(const double* partials, int blocks_per_scan, const PoseState* st_all, int first, int n_local, int n_total, double* acc,
-                         hipStream_t s) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(n_total), dim3(kBlock), 0, s, partials, blocks_per_scan, st_all, first, n_local, acc);
+                         hipStream_t s, const unsigned char* owned) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(n_total), dim3(kBlock), 0, s, partials, blocks_per_scan, st_all, first, n_local, acc, owned);
 }
 
 void launch_count_touched(uint32_t* touched, size_t n_words, unsigned long long* totals, hipStream_t s) {

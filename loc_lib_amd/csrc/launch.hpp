@@ -49,6 +49,9 @@ struct AccumArgs {
     double* partials;   // [n_scans][blocks_per_scan][kAccW]
     const int* active = nullptr;  // see SearchArgs
     int n_active = 0;
+    // > 0: split the sums as a plain batch of this many scans would (a scan pool of many slots serving jobs of that size), so that
+    // a pooled scan's partial sums — hence its pose — are the plain batch's bit for bit. 0: by n_scans.
+    int split_scans = 0;
 };
 
 bool launch_icp_search(const SearchArgs& a, hipStream_t s);
@@ -61,13 +64,16 @@ bool launch_knn_query(const uint2* tree, int depth, const float* q, size_t nq, i
 // returns the number of partial blocks per scan the kernel wrote (what gn_solve must sum)
 int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s);
 // list_counts (optional): the two search work-list counters, zeroed for the next iteration
+// scans (optional): n_scans indices — block i solves scan scans[i] instead of scan i
 void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
-                     unsigned int* list_counts, hipStream_t s);
+                     unsigned int* list_counts, hipStream_t s, const int* scans = nullptr);
+int icp_accum_split(int method, int max_n, int n_scans);  // points per thread of the accumulate kernels (the split of the partial sums)
 // Sharded batches: acc[g][0..28) = sum of the block partials of global scan g when this rank holds it (local index g - first),
 // zeros otherwise — in exactly the order gn_solve_kernel sums them, so that all-reduce(acc) followed by gn_solve on acc
 // (blocks_per_scan = 1) gives bit for bit the single-GPU result.
+// owned (optional, scan pools): per global scan, whether this rank holds its points (then first = 0, n_local = n_total)
 void launch_sum_partials(const double* partials, int blocks_per_scan, const PoseState* st_all, int first, int n_local, int n_total, double* acc,
-                         hipStream_t s);
+                         hipStream_t s, const unsigned char* owned = nullptr);
 void launch_transform_cloud(const float4* src, size_t n, const float* m12, float4* dst, hipStream_t s);
 // Code-object self-test (once per process): no walk kernel owns static LDS, so every traversal stack starts at LDS address 0 —
 // the precondition of search_walk.hpp's out-of-range rows (tests/test_gpu_lds_semantics.py pins the hardware side).

@@ -62,6 +62,14 @@ Rccl& rccl() {
 }
 }  // namespace
 
+// Sum of `count` doubles over the context's communicator, in place, on stream `s` (scan_pool.hip's exchange step).
+bool locgpu::comm_all_reduce_f64(locgpu_ctx* ctx, double* buf, size_t count, hipStream_t s) {
+    const ncclResult_t nr = rccl().AllReduce(buf, buf, count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, s);
+    if (nr == ncclSuccess) return true;
+    fail(ctx, LOCGPU_ERR_NO_DEVICE, std::string("ncclAllReduce: ") + rccl().GetErrorString(nr));
+    return false;
+}
+
 namespace {
 std::string g_create_err;
 // GN iterations enqueued between two host reads of the convergence flags. Kernels of a finished scan return at once (device-side
@@ -121,7 +129,7 @@ static bool fill_now(locgpu_ctx* ctx, void* p, size_t bytes, const char* what) {
     return hip_ok(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream), what) && hip_ok(ctx, hipStreamSynchronize(ctx->stream), what);
 }
 
-static void free_batch(locgpu_batch* b) {
+void locgpu::free_batch(locgpu_batch* b) {
     if (!b) return;
     upload_free_batch(b);
     for (hipEvent_t ev : b->events) (void)hipEventDestroy(ev);
@@ -537,8 +545,10 @@ int locgpu_knn(locgpu_ctx* ctx, const float* queries, size_t nq, int k, int appr
 }
 
 // --------------------------------------------------------------------------------------------- batches
+}  // extern "C"
+
 // Device buffers + pinned result staging for n_scans scans of at most max_n points each; no points yet.
-static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch** out, int first = 0, int n_total = -1) {
+int locgpu::alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch** out, int first, int n_total) {
     if (!ctx || !out) return LOCGPU_ERR_INVALID;
     *out = nullptr;
     const bool sharded = n_total >= 0;
@@ -588,6 +598,8 @@ static int alloc_batch(locgpu_ctx* ctx, int n_scans, size_t max_n, locgpu_batch*
     *out = b;
     return LOCGPU_OK;
 }
+
+extern "C" {
 
 // Batch with the given scans resident when the call returns (deep copy of the sources, icp_registration.cpp:259).
 static int make_batch(locgpu_ctx* ctx, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_scans, locgpu_batch** out,
@@ -1022,7 +1034,12 @@ static int align_finish(locgpu_ctx* ctx, locgpu_batch* b, double* out_poses, loc
             if (!b->h_state[i].done) { all_done = false; break; }
         if (all_done || P.launched >= P.prm.max_iteration) break;
         const int rc = enqueue_chunk(ctx, b, false);
-        if (rc != LOCGPU_OK) return rc;
+        if (rc != LOCGPU_OK) {
+            // whatever of the chunk was enqueued must not run on under the batch's next upload (which relies on an ended alignment
+            // leaving its stream idle, batch_upload.hip)
+            (void)hipStreamSynchronize(b->stream);
+            return rc;
+        }
     }
     write_results(b, P.init_poses.data(), out_poses, stats);
     b->counters_clean = !P.ndt && !ctx->count_visits && P.alpha_eff >= 0.f && !b->sharded;  // every search was followed by its solve kernel, which zeroes them (a one-scan front-end saves a fill launch per call)
@@ -1056,7 +1073,7 @@ static void write_results(locgpu_batch* b, const double* init_poses, double* out
     }
 }
 
-static int check_icp(locgpu_ctx* ctx, const locgpu_icp_opts* o, GnParams& prm, int& k, float& alpha_eff) {
+int check_icp(locgpu_ctx* ctx, const locgpu_icp_opts* o, GnParams& prm, int& k, float& alpha_eff) {
     if (!ctx) return LOCGPU_ERR_INVALID;
     if (!o) return fail(ctx, LOCGPU_ERR_INVALID, "icp: opts is NULL");
     { const int jrc = target_join(ctx); if (jrc != LOCGPU_OK) return jrc; }  // an asynchronous SetInputTarget ends here at the latest
@@ -1409,7 +1426,7 @@ void ndt_free(locgpu_ctx* ctx) {
     if (ctx->ndt) { ndt_table_free(*ctx->ndt); delete ctx->ndt; ctx->ndt = nullptr; }
     if (ctx->inc) { inc_ndt_destroy(ctx->inc); ctx->inc = nullptr; }
 }
-static int check_ndt(locgpu_ctx* ctx, GnParams& prm) {
+int check_ndt(locgpu_ctx* ctx, GnParams& prm) {
     if (!ctx) return LOCGPU_ERR_INVALID;
     const bool inc = ctx->ndt_opts.method == 2;
     if ((inc && !ctx->inc) || (!inc && !ctx->ndt)) return fail(ctx, LOCGPU_ERR_NO_TARGET, "ndt: SetInputTarget has not been called");

@@ -227,9 +227,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                                                            const double* __restrict__ mu, const double* __restrict__ info, size_t cap_mask,
                                                            double inv_voxel, double res_th, int n_nearby, const float4* __restrict__ src,
                                                            const int* __restrict__ counts, const PoseState* __restrict__ st, int max_n,
-                                                           double* __restrict__ partials) {
+                                                           double* __restrict__ partials, const int* __restrict__ active) {
 #pragma clang fp contract(fast)
-    const int scan = blockIdx.y;
+    const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     double acc[28];
@@ -612,10 +612,10 @@ hipError_t inc_ndt_ingest(IncNdtState& st, const float4* host_pts, const float4*
 }
 
 void launch_inc_accum(const IncNdtState* st, double res_th, int n_nearby, const float4* src, const int* counts, const PoseState* ps, int max_n,
-                      int n_scans, double* partials, hipStream_t s) {
-    dim3 grid((max_n + kBlock - 1) / kBlock, n_scans);
+                      int n_scans, double* partials, hipStream_t s, const int* active, int n_active) {
+    dim3 grid((max_n + kBlock - 1) / kBlock, active ? n_active : n_scans);
     hipLaunchKernelGGL(inc_accum_kernel, grid, dim3(kBlock), 0, s, st->d_keys, st->d_vid, st->d_mu, st->d_info, st->table_cap - 1, st->inv_voxel, res_th,
-                       n_nearby, src, counts, ps, max_n, partials);
+                       n_nearby, src, counts, ps, max_n, partials, active);
 }
 
 size_t inc_ndt_dump(const IncNdtState* st, int32_t* keys, double* mu, double* info, size_t cap) {

@@ -44,7 +44,9 @@ hipError_t ndt_build(NdtTable& t, const float4* d_pts, size_t n, double voxel_si
 void ndt_table_free(NdtTable& t);
 
 // K5: per-point 7-voxel probe + χ² gate + un-weighted JᵀJ / Jᵀe sums (AlignNdt inner loop, ndt cpp:399-433).
+// active / n_active (optional): the scans to launch (SearchArgs::active); split_scans > 0: split the partial sums as a plain batch of
+// that many scans would (AccumArgs::split_scans).
 int launch_ndt_accum(const NdtTable* t, const float4* src, const int* counts, const PoseState* st, int max_n, int n_scans, double* partials,
-                      hipStream_t s);
+                     hipStream_t s, const int* active = nullptr, int n_active = 0, int split_scans = 0);
 
 }  // namespace locgpu

@@ -92,6 +92,20 @@ def rank_main(rank, uid, m, scans, inits, want, log):
         a.close()
         b.close()
         log.append((rank, "two in flight"))
+        # the open-scan pool, sharded: five jobs of five scans through twelve slots (jobs wait for slots; the slot bookkeeping must
+        # come out the same on both ranks), each split differently over the ranks, one exchange per pooled iteration
+        for kind in ("plane", "ndt"):
+            pool = api.Pool(ctx, slots=12, max_points=10000, scans_per_job=n, chunk=2, opts=opts, ndt=(kind == "ndt"))
+            tickets = []
+            for split in ("even", "ragged", "rank1_empty", "rank0_empty", "even"):
+                lo, hi = SPLITS[split][rank]
+                tickets.append(pool.submit(scans[lo:hi], inits, first=lo, n_total=n))
+            for t in tickets:
+                got, st = pool.wait(t)
+                np.testing.assert_array_equal(got, want[kind][0], err_msg="pool %s, rank %d" % (kind, rank))
+                assert iters(st) == iters(want[kind][1])
+            pool.close()
+        log.append((rank, "pool"))
         # point sharding: every rank holds a slice of every scan, so the sums really are sums of two parts — equal on both ranks,
         # and equal to the plain batch up to the order of the additions
         pts = multi_gpu.point_sharded_batch(ctx, scans, rank, WORLD)
