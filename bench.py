@@ -409,11 +409,25 @@ def main():
         """Exactly n steps, begun and ended in here; at most `depth` alignments in flight. Pool: a step = one job — its scans are
         submitted (the copy into free slots starts at once and runs beside the pool's iterations) and collected by ticket."""
         inflight, begun, res = [], 0, None
+        if use_pool:
+            # a step is submitted as soon as the pool has free source regions for it (its copy then runs ahead of the slots coming free,
+            # scan by scan: a job stays open until its slowest scan is done) and collected in order once it is done; at most 4 x depth
+            # steps are outstanding.
+            # Every decision depends on the flags all ranks see, so the ranks of a sharded run make the same calls in the same order.
+            while begun < n or inflight:
+                while begun < n and len(inflight) < 4 * depth and (not inflight or pool.info()["free_regions"] >= n_total):
+                    inflight.append(pool.submit(scans_c, inits, first=lo, n_total=n_total))
+                    begun += 1
+                if pool.done(inflight[0]):
+                    res = pool.wait(inflight.pop(0))
+                else:
+                    pool.step(True)
+            return res
         while begun < n or inflight:
             while begun < n and len(inflight) < depth:
-                inflight.append(pool.submit(scans_c, inits, first=lo, n_total=n_total) if use_pool else begin_step())
+                inflight.append(begin_step())
                 begun += 1
-            res = pool.wait(inflight.pop(0)) if use_pool else ctx.align_batch_end(inflight.pop(0))
+            res = ctx.align_batch_end(inflight.pop(0))
         return res
 
     def barrier():

@@ -203,19 +203,21 @@ LOCGPU_API int locgpu_icp_set_target_bcast(locgpu_ctx* ctx, const void* pts, siz
  * The reference's loops stop per scan (icp_registration.cpp:358-376, ndt_registration.cpp:393-462): the late Gauss–Newton
  * iterations of a batch hold a handful of open scans, and a small batch pays every iteration's fixed costs for little work. A pool
  * owns `slots` scan slots in HBM and runs ONE launch sequence per iteration over the union of the open scans of every job admitted so
- * far; a job = a set of scans with their initial poses, submitted at any time (its points are copied into free slots on the copy
- * stream while the pool iterates) and collected by ticket. Every `chunk` iterations the host reads the flags: finished scans leave,
- * waiting jobs enter. A job of `scans_per_job` scans gets, bit for bit, the poses locgpu_*_align_batch gives a plain batch of those
+ * far; a job = a set of scans with their initial poses, submitted at any time (its points are copied into free source regions on
+ * the copy stream while the pool iterates, ahead of the slots) and collected by ticket. Every `chunk` iterations the host reads the
+ * flags: finished scans leave, waiting scans enter one by one as slots come free. A job of `scans_per_job` scans gets, bit for bit, the poses locgpu_*_align_batch gives a plain batch of those
  * scans (same kernels; the partial sums are split as that batch would split them).
  * The pool matches against the target (tree or NDT voxels) the context holds when its chunks run, with the options given here.
- * Calls on a pool follow the context's rule: one caller thread. The host clouds of a submit must stay valid until the next
- * locgpu_pool_submit / locgpu_pool_wait on the pool has returned.
+ * Calls on a pool follow the context's rule: one caller thread. The host clouds of a submit must stay valid until
+ * locgpu_pool_wait has returned for its ticket (they are packed by the context's upload service beside the caller).
  * With a communicator on the context (locgpu_comm_init) a job is SHARDED like a sharded batch — n_total scans, this rank holds the
  * points of [first_scan, first_scan + n_local) — submit and wait are collective calls made in the same order on every rank, and
  * each pooled iteration has one all-reduce of [slots][32] doubles; every rank ends with every pose. */
 typedef struct locgpu_pool locgpu_pool;
 typedef struct locgpu_pool_opts {
-    int32_t slots;          /* scans the pool holds at a time                                                        */
+    int32_t slots;          /* scans the pool iterates at a time                                                     */
+    int32_t prefetch;       /* source regions beyond `slots`: scans whose points are in HBM ahead of a free slot     */
+                            /* (-1 = as many as slots). A job is accepted as soon as it has regions.                 */
     int32_t scans_per_job;  /* the job size whose plain-batch bits a job gets (0: as a batch of `slots` scans)        */
     int32_t chunk;          /* iterations between two looks at the flags, 1..8 (0 = 4)                               */
     int32_t matcher;        /* 0 = ICP with `icp`; 1 = NDT against the context's NDT target (locgpu_ndt_set_target)  */
@@ -225,14 +227,21 @@ typedef struct locgpu_pool_opts {
 LOCGPU_API void locgpu_pool_opts_default(locgpu_pool_opts* o);
 LOCGPU_API int locgpu_pool_create(locgpu_ctx* ctx, const locgpu_pool_opts* opts, locgpu_pool** out);
 LOCGPU_API void locgpu_pool_destroy(locgpu_pool* pool);
-/* init_poses: n_total × 7. Returns once the job has slots (it lets running scans finish when the pool is full) and its copy has been
- * started; *ticket identifies it. Unsharded: n_local = n_total, first_scan = 0. */
+/* init_poses: n_total × 7. Returns once the job has source regions (it lets running scans finish when there are none) and its copy
+ * has been started; *ticket identifies it. Unsharded: n_local = n_total, first_scan = 0. */
 LOCGPU_API int locgpu_pool_submit(locgpu_pool* pool, const void* const* srcs, const size_t* counts, size_t stride_bytes, int n_local, int first_scan,
                                   int n_total, const double* init_poses, int64_t* ticket);
 /* Runs the pool until every scan of the job has finished; out_poses n_total × 7, stats (optional) n_total. A ticket is good once. */
 LOCGPU_API int locgpu_pool_wait(locgpu_pool* pool, int64_t ticket, double* out_poses, locgpu_align_stats* stats);
-/* out = {slots, free slots, jobs not collected, pooled iterations launched, Σ over them of the open scans this rank held, open scans} */
-LOCGPU_API int locgpu_pool_info(const locgpu_pool* pool, int64_t out[6]);
+/* One turn of the pool without collecting anything: look at the chunk in flight (block != 0: wait for it; with several ranks a
+ * non-blocking look is a no-op), let finished scans out and waiting jobs in, enqueue the next chunk. For callers that keep the pool
+ * full — submit whenever locgpu_pool_info reports room — instead of waiting for the oldest ticket. *done: every scan of the job has
+ * finished (locgpu_pool_wait returns at once). */
+LOCGPU_API int locgpu_pool_step(locgpu_pool* pool, int block);
+LOCGPU_API int locgpu_pool_done(const locgpu_pool* pool, int64_t ticket, int* done);
+/* out = {slots, free slots, jobs not collected, pooled iterations launched, Σ over them of the open scans this rank held, open scans,
+ *        source regions, free source regions} */
+LOCGPU_API int locgpu_pool_info(const locgpu_pool* pool, int64_t out[8]);
 /* With locgpu_profile_enable on: out[0] = device ms of the chunks run since the last reset (HIP events on the pool's stream), out[1] = chunks. */
 LOCGPU_API int locgpu_pool_profile_read(locgpu_pool* pool, double out[2], int reset);
 

@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "locgpu_icp_align_batch_begin", "locgpu_ndt_align_batch_begin", "locgpu_align_batch_end",
     "locgpu_comm_unique_id", "locgpu_comm_init", "locgpu_comm_info", "locgpu_batch_create_sharded", "locgpu_icp_set_target_bcast",
     "locgpu_pool_opts_default", "locgpu_pool_create", "locgpu_pool_destroy", "locgpu_pool_submit", "locgpu_pool_wait", "locgpu_pool_info",
-    "locgpu_pool_profile_read",
+    "locgpu_pool_profile_read", "locgpu_pool_step", "locgpu_pool_done",
 ]
 COMM_ID_BYTES = 128
 NO_INTENSITY = ctypes.c_size_t(-1).value
@@ -65,7 +65,7 @@ class NdtOpts(ctypes.Structure):
 
 
 class PoolOpts(ctypes.Structure):
-    _fields_ = [("slots", ctypes.c_int32), ("scans_per_job", ctypes.c_int32), ("chunk", ctypes.c_int32), ("matcher", ctypes.c_int32),
+    _fields_ = [("slots", ctypes.c_int32), ("prefetch", ctypes.c_int32), ("scans_per_job", ctypes.c_int32), ("chunk", ctypes.c_int32), ("matcher", ctypes.c_int32),
                 ("max_points", ctypes.c_uint64), ("icp", IcpOpts)]
 
 
@@ -139,6 +139,7 @@ def lib():
             "locgpu_pool_opts_default": (None, [vp]), "locgpu_pool_create": (i32, [vp, vp, vp]), "locgpu_pool_destroy": (None, [vp]),
             "locgpu_pool_submit": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, vp]), "locgpu_pool_wait": (i32, [vp, ctypes.c_int64, vp, vp]),
             "locgpu_pool_info": (i32, [vp, vp]), "locgpu_pool_profile_read": (i32, [vp, vp, i32]),
+            "locgpu_pool_step": (i32, [vp, i32]), "locgpu_pool_done": (i32, [vp, ctypes.c_int64, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -672,13 +673,14 @@ class Batch:
 class Pool:
     """The open-scan pool (locgpu_pool): jobs of scans submitted at any time, iterated together, collected by ticket."""
 
-    def __init__(self, ctx, slots, max_points, scans_per_job=0, chunk=0, opts=None, ndt=False):
+    def __init__(self, ctx, slots, max_points, scans_per_job=0, chunk=0, opts=None, ndt=False, prefetch=-1):
         self.ctx = ctx
         self._h = ctypes.c_void_p()
-        self._keep = {}
+        self._keep, self._n = {}, {}
         o = PoolOpts()
         lib().locgpu_pool_opts_default(ctypes.byref(o))
         o.slots, o.scans_per_job, o.chunk, o.matcher, o.max_points = int(slots), int(scans_per_job), int(chunk), (1 if ndt else 0), int(max_points)
+        o.prefetch = int(prefetch)
         if opts is not None:
             o.icp = opts
         ctx._check(lib().locgpu_pool_create(ctx._h, ctypes.byref(o), ctypes.byref(self._h)))
@@ -695,8 +697,7 @@ class Pool:
             sc, ptrs, cnts, stride = [], None, None, 16
         rc = lib().locgpu_pool_submit(self._h, ptrs, cnts, stride, len(sc), int(first), n_total, ip.ctypes.data, ctypes.byref(t))
         self.ctx._check(rc)
-        self._keep = {t.value: (sc, ptrs, cnts, n_total)}  # the clouds of a submit stay alive until the next call on the pool
-        self._n = getattr(self, "_n", {})
+        self._keep[t.value] = (sc, ptrs, cnts)  # the clouds of a submit stay alive until its ticket has been waited for
         self._n[t.value] = n_total
         return t.value
 
@@ -706,13 +707,24 @@ class Pool:
             raise LocGpuError(-1, "pool.wait: unknown ticket (a ticket is good once)")
         out = np.zeros((n, 7))
         st = (AlignStats * n)()
-        self.ctx._check(lib().locgpu_pool_wait(self._h, ctypes.c_int64(ticket), out.ctypes.data, st))
+        rc = lib().locgpu_pool_wait(self._h, ctypes.c_int64(ticket), out.ctypes.data, st)
+        self._keep.pop(ticket, None)
+        self.ctx._check(rc)
         return out, [_stats_dict(s) for s in st]
 
+    def step(self, block=True):
+        """One turn of the pool (look at the chunk in flight, scans out, jobs in, next chunk) without collecting a job."""
+        self.ctx._check(lib().locgpu_pool_step(self._h, 1 if block else 0))
+
+    def done(self, ticket):
+        d = ctypes.c_int(0)
+        self.ctx._check(lib().locgpu_pool_done(self._h, ctypes.c_int64(ticket), ctypes.byref(d)))
+        return bool(d.value)
+
     def info(self):
-        out = (ctypes.c_int64 * 6)()
+        out = (ctypes.c_int64 * 8)()
         self.ctx._check(lib().locgpu_pool_info(self._h, out))
-        return dict(slots=out[0], free=out[1], jobs=out[2], iterations=out[3], scan_iterations=out[4], open=out[5])
+        return dict(slots=out[0], free=out[1], jobs=out[2], iterations=out[3], scan_iterations=out[4], open=out[5], regions=out[6], free_regions=out[7])
 
     def profile_read(self, reset=True):
         out = (ctypes.c_double * 2)()

@@ -15,16 +15,17 @@ template <int KMAX, int D, bool COUNT>
 __global__ __launch_bounds__(kBlock) void icp_search_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                             const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                             uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, int k, float alpha_eff,
-                                                            int skip_nonfinite, unsigned long long* __restrict__ visit_totals, uint32_t* __restrict__ touched) {
+                                                            int skip_nonfinite, unsigned long long* __restrict__ visit_totals, uint32_t* __restrict__ touched,
+                                                            const int* __restrict__ active, const int* __restrict__ src_of) {
     __shared__ uint32_t s_far[D][kBlock];
     __shared__ float s_d2[D][kBlock];
-    const int scan = blockIdx.y;
+    const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kBlock + tid;
     if (i >= counts[scan]) return;
     const size_t gi = (size_t)scan * max_n + i;
-    const float4 p = src[gi];
+    const float4 p = src[(size_t)(src_of ? src_of[scan] : scan) * max_n + i];
     uint32_t out[KMAX];
     int cnt = 0;
     uint32_t nvis = 0, lvis = 0;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
                                                              unsigned int tree_bytes, uint32_t dummy, int skip_nonfinite, uint32_t* __restrict__ redo_list,
                                                              unsigned int* __restrict__ redo_count, uint32_t* __restrict__ deep_list,
                                                              unsigned int* __restrict__ deep_count, unsigned long long* __restrict__ search_stats,
-                                                             const int* __restrict__ active) {
+                                                             const int* __restrict__ active, const int* __restrict__ src_of) {
     extern __shared__ uint2 s_dyn[];
     constexpr int ROWB = LANES * 8;
     static_assert(DF * ROWB >= 64 * 2 * 8, "exact stack columns do not fit");
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     const int i = blockIdx.x * LANES + tid;
     if (tid >= LANES || i >= counts[scan]) return;
     const size_t gi = (size_t)scan * max_n + i;
-    const float4 p = load_once(&src[gi]);
+    // a scan pool keeps the points in an arena of source regions and says which one a slot reads (scan_pool.hip); else slot = region
+    const float4 p = load_once(&src[(size_t)(src_of ? src_of[scan] : scan) * max_n + i]);
     // pcl::isFinite, icp cpp:64 (P2P only): such a point has no neighbours; its lane stays in the wave with nothing to do (the list
     // it stores at the end is the empty one)
     const bool finite = !skip_nonfinite || (isfinite(p.x) && isfinite(p.y) && isfinite(p.z));
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* _
                                                                   const PoseState* __restrict__ st, uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                   float alpha_eff, unsigned int tree_bytes, uint32_t dummy, const uint32_t* __restrict__ list,
                                                                   const unsigned int* __restrict__ n_list, uint32_t* __restrict__ redo_list,
-                                                                  unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats) {
+                                                                  unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats,
+                                                                  const int* __restrict__ src_of) {
     extern __shared__ uint2 s_dyn[];
     constexpr int ROWB = 64 * 8;
     if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();  // see icp_search_walk_kernel
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* _
         w.qx = w.qy = w.qz = 0.f;
         if (valid) {
             const int scan = (int)(gi / (uint32_t)max_n);
-            const float4 p = src[gi];
+            const float4 p = src_of ? src[(size_t)src_of[scan] * max_n + (gi - (uint32_t)scan * (uint32_t)max_n)] : src[gi];
             const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
             w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
         }
@@ -215,7 +218,8 @@ template <int KMAX, int D>
 __global__ __launch_bounds__(64) void icp_search_redo_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                              const PoseState* __restrict__ st, uint32_t* __restrict__ nn, size_t nn_pitch,
                                                              int max_n, int k, float alpha_eff, const uint32_t* __restrict__ redo_list,
-                                                             const unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats) {
+                                                             const unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats,
+                                                             const int* __restrict__ src_of) {
     __shared__ uint32_t s_far[D][64];
     __shared__ float s_d2[D][64];
     const unsigned int n = *redo_count;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(64) void icp_search_redo_kernel(const uint2* __rest
     for (unsigned int r = blockIdx.x * per_wave + tid; r < n; r += gridDim.x * per_wave) {
         const size_t gi = redo_list[r];
         const int scan = (int)(gi / (size_t)max_n);
-        const float4 p = src[gi];
+        const float4 p = src_of ? src[(size_t)src_of[scan] * max_n + (gi - (size_t)scan * max_n)] : src[gi];
         const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
         KnnHeap<KMAX> heap;
         uint32_t nvis = 0, lvis = 0, out[KMAX];
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                  double max_plane_distance, double* __restrict__ partials, int kPlanePts,
-                                                                 const int* __restrict__ active) {
+                                                                 const int* __restrict__ active, const int* __restrict__ src_of) {
     __shared__ double s_row[8][kAccPad];
     __shared__ double s_slice[kBlock / 32][32];
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             uint32_t slot[5];
 #pragma unroll
             for (int j = 0; j < 5; ++j) slot[j] = __builtin_nontemporal_load(&nn[(size_t)j * nn_pitch + gi]);
-            const float4 p = src[gi];
+            const float4 p = src[(size_t)(src_of ? src_of[scan] : scan) * max_n + i];
             if (slot[4] != kInvalidSlot) {  // nn.size() > 3: k=5 yields 5 or (k > size_) none
                 D3 nb[5];
 #pragma unroll
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __
                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                  const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                  double max_nn_distance, double* __restrict__ partials, int pts,
-                                                                 const int* __restrict__ active) {
+                                                                 const int* __restrict__ active, const int* __restrict__ src_of) {
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;
     double acc[28];
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void icp_point_accum_kernel(const uint2* __
         const size_t gi = (size_t)scan * max_n + i;
         const uint32_t s0 = nn[gi];
         if (s0 != kInvalidSlot) {
-            const float4 p = src[gi];
+            const float4 p = src[(size_t)(src_of ? src_of[scan] : scan) * max_n + i];
             const D3 q{(double)p.x, (double)p.y, (double)p.z};
             const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
             const D3 e3 = leaf_point(tree, s0) - qs;
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
                                                                 const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                                 const uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                 double max_line_distance, double* __restrict__ partials, int pts,
-                                                                const int* __restrict__ active) {
+                                                                const int* __restrict__ active, const int* __restrict__ src_of) {
     __shared__ double s_row[8][kAccPad];
     __shared__ double s_slice[kBlock / 32][32];
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
         uint32_t slot[5];  // one round trip for the five indices and the point (see the plane kernel)
 #pragma unroll
         for (int j = 0; j < 5; ++j) slot[j] = nn[(size_t)j * nn_pitch + gi];
-        const float4 p = src[gi];
+        const float4 p = src[(size_t)(src_of ? src_of[scan] : scan) * max_n + i];
         if (slot[4] != kInvalidSlot) {  // nn.size() == 5
             const D3 q{(double)p.x, (double)p.y, (double)p.z};
             const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
@@ -731,13 +735,13 @@ void launch_nn_to_index(const uint2* tree, const uint32_t* nn, size_t nn_pitch, 
 
 template <int KMAX, int D>
 static void launch_search_kd(const SearchArgs& a, hipStream_t s) {
-    dim3 grid((a.max_n + kBlock - 1) / kBlock, a.n_scans);
+    dim3 grid((a.max_n + kBlock - 1) / kBlock, a.active ? a.n_active : a.n_scans);
     if (a.visit_totals)
         hipLaunchKernelGGL((icp_search_kernel<KMAX, D, true>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals, a.touched);
+                           a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals, a.touched, a.active, a.src_of);
     else
         hipLaunchKernelGGL((icp_search_kernel<KMAX, D, false>), grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals, nullptr);
+                           a.k, a.alpha_eff, a.skip_nonfinite, a.visit_totals, nullptr, a.active, a.src_of);
 }
 
 template <int KMAX>
@@ -797,7 +801,7 @@ static bool launch_walk_kd(const SearchArgs& a, hipStream_t s) {
         // 16-lane kernel answers its ties itself: no redo launch on the latency path
         dim3 g1((a.max_n + 15) / 16, n_launch);
         hipLaunchKernelGGL((icp_search_walk_kernel<K, D + 2, 16>), g1, dim3(64), (D + 2) * 16 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.alpha_eff, 0, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active);
+                           a.alpha_eff, 0, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of);
         return true;
     }
     // rows 0/1 of the DF stored rows hold the candidates of the un-stored levels, the other DF-2 rows one level each. Queries whose
@@ -807,16 +811,16 @@ static bool launch_walk_kd(const SearchArgs& a, hipStream_t s) {
     dim3 g2((a.max_n + 63) / 64, n_launch);
     if (stamp)  // diagnostic build: counts rounds per lane and per wave (search_stats[4], [9], [12], [13]; per query at redo_list[pitch + gi]); timing meaningless
         hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, 64, true>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.alpha_eff, Tw, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active);
+                           a.alpha_eff, Tw, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of);
     else
         hipLaunchKernelGGL((icp_search_walk_kernel<K, DF>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.alpha_eff, Tw, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active);
+                           a.alpha_eff, Tw, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of);
     // 2048 one-wave blocks of 17 KB LDS are all resident at once (nine fit a CU): the first iteration's ≈140 k deep queries take one
     // traversal per wave instead of two or three in sequence (search 18.07 → 17.80 ms per 256-scan step; 4608: 17.96)
     hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(kDeepWaves), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
-                       a.alpha_eff, rsrc_bytes, dummy, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count, a.search_stats);
+                       a.alpha_eff, rsrc_bytes, dummy, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count, a.search_stats, a.src_of);
     hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
-                       a.alpha_eff, a.redo_list, a.redo_count, a.search_stats);
+                       a.alpha_eff, a.redo_list, a.redo_count, a.search_stats, a.src_of);
     return true;
 }
 template <int K, int D>
@@ -838,7 +842,7 @@ static bool launch_walk_k(const SearchArgs& a, hipStream_t s) {
 template <int K>
 static bool launch_redo_k(const SearchArgs& a, hipStream_t s) {
 #define LOCGPU_REDO(D) hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k, \
-                                          a.alpha_eff, a.redo_list, a.redo_count, a.search_stats)
+                                          a.alpha_eff, a.redo_list, a.redo_count, a.search_stats, a.src_of)
     if (a.depth <= 32) LOCGPU_REDO(32);
     else if (a.depth <= 40) LOCGPU_REDO(40);
     else if (a.depth <= 64) LOCGPU_REDO(64);
@@ -859,7 +863,7 @@ static bool launch_walk_list_k(const SearchArgs& a, const uint32_t* list, const 
     const uint32_t dummy = (uint32_t)(a.tree_bytes / 8);
     const unsigned int rsrc_bytes = (unsigned int)a.tree_bytes + 16u;
 #define LOCGPU_LIST(D) hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(kDeepWaves), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, \
-                                          a.alpha_eff, rsrc_bytes, dummy, list, n_list, a.redo_list, a.redo_count, a.search_stats)
+                                          a.alpha_eff, rsrc_bytes, dummy, list, n_list, a.redo_list, a.redo_count, a.search_stats, a.src_of)
     if (a.depth <= 32) LOCGPU_LIST(32);
     else if (a.depth <= 40) LOCGPU_LIST(40);
     else if (a.depth <= 64) LOCGPU_LIST(64);
@@ -928,13 +932,13 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
     const dim3 grid((blocks + pts - 1) / pts, a.active ? a.n_active : a.n_scans);
     if (method == 2) {
         if (plane_fit_mode() == 1)
-            hipLaunchKernelGGL(icp_plane_accum_kernel<1>, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
+            hipLaunchKernelGGL(icp_plane_accum_kernel<1>, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active, a.src_of);
         else
-            hipLaunchKernelGGL(icp_plane_accum_kernel<0>, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
+            hipLaunchKernelGGL(icp_plane_accum_kernel<0>, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active, a.src_of);
     } else if (method == 1)
-        hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
+        hipLaunchKernelGGL(icp_line_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active, a.src_of);
     else
-        hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active);
+        hipLaunchKernelGGL(icp_point_accum_kernel, grid, dim3(kBlock), 0, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.gate, a.partials, pts, a.active, a.src_of);
     return (int)grid.x;
 }
 

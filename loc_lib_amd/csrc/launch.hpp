@@ -32,6 +32,8 @@ struct SearchArgs {
     // iterations hold a handful of scans: 460 k empty workgroups cost ≈96 µs per launch). nullptr = every scan.
     const int* active = nullptr;
     int n_active = 0;
+    // Scan pools: the points of scan slot s are region src_of[s] of `src` (an arena of max_n-point regions); nullptr = region s.
+    const int* src_of = nullptr;
     // instrumented pass only: bitmap over the tree's 8-byte slots (one bit each, zeroed by the caller, counted and cleared again
     // by launch_count_touched) — which slots this search launch reads at all
     uint32_t* touched = nullptr;
@@ -49,6 +51,7 @@ struct AccumArgs {
     double* partials;   // [n_scans][blocks_per_scan][kAccW]
     const int* active = nullptr;  // see SearchArgs
     int n_active = 0;
+    const int* src_of = nullptr;  // see SearchArgs
     // > 0: split the sums as a plain batch of this many scans would (a scan pool of many slots serving jobs of that size), so that
     // a pooled scan's partial sums — hence its pose — are the plain batch's bit for bit. 0: by n_scans.
     int split_scans = 0;

@@ -616,7 +616,7 @@ static int make_batch(locgpu_ctx* ctx, const void* const* srcs, const size_t* co
     if (rc != LOCGPU_OK) return rc;
     if (n_scans > 0) {
         rc = upload_start(b, srcs, counts, stride_bytes);
-        if (rc == LOCGPU_OK) rc = upload_join(ctx);
+        if (rc == LOCGPU_OK) rc = upload_join_batch(b);
         if (rc == LOCGPU_OK && !hip_ok(ctx, upload_wait_landed(b), "batch_create: H2D")) rc = LOCGPU_ERR_NO_DEVICE;
     }
     if (rc != LOCGPU_OK) { free_batch(b); return rc; }

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                                                            const double* __restrict__ mu, const double* __restrict__ info, size_t cap_mask,
                                                            double inv_voxel, double res_th, int n_nearby, const float4* __restrict__ src,
                                                            const int* __restrict__ counts, const PoseState* __restrict__ st, int max_n,
-                                                           double* __restrict__ partials, const int* __restrict__ active) {
+                                                           double* __restrict__ partials, const int* __restrict__ active, const int* __restrict__ src_of) {
 #pragma clang fp contract(fast)
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
     for (int v = 0; v < 28; ++v) acc[v] = 0.0;
     if (i < counts[scan]) {
-        const float4 p = src[(size_t)scan * max_n + i];
+        const float4 p = src[(size_t)(src_of ? src_of[scan] : scan) * max_n + i];
         const D3 q{(double)p.x, (double)p.y, (double)p.z};
         const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
         const int kx = (int)(qs.x * inv_voxel), ky = (int)(qs.y * inv_voxel), kz = (int)(qs.z * inv_voxel);
@@ -612,10 +612,10 @@ hipError_t inc_ndt_ingest(IncNdtState& st, const float4* host_pts, const float4*
 }
 
 void launch_inc_accum(const IncNdtState* st, double res_th, int n_nearby, const float4* src, const int* counts, const PoseState* ps, int max_n,
-                      int n_scans, double* partials, hipStream_t s, const int* active, int n_active) {
+                      int n_scans, double* partials, hipStream_t s, const int* active, int n_active, const int* src_of) {
     dim3 grid((max_n + kBlock - 1) / kBlock, active ? n_active : n_scans);
     hipLaunchKernelGGL(inc_accum_kernel, grid, dim3(kBlock), 0, s, st->d_keys, st->d_vid, st->d_mu, st->d_info, st->table_cap - 1, st->inv_voxel, res_th,
-                       n_nearby, src, counts, ps, max_n, partials, active);
+                       n_nearby, src, counts, ps, max_n, partials, active, src_of);
 }
 
 size_t inc_ndt_dump(const IncNdtState* st, int32_t* keys, double* mu, double* info, size_t cap) {

@@ -207,7 +207,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                                                            const double* __restrict__ mu, const double* __restrict__ info, size_t cap_mask,
                                                            double inv_voxel, double res_th, int n_nearby, const float4* __restrict__ src,
                                                            const int* __restrict__ counts, const PoseState* __restrict__ st, int max_n,
-                                                           double* __restrict__ partials, int pts, const int* __restrict__ active) {
+                                                           double* __restrict__ partials, int pts, const int* __restrict__ active,
+                                                           const int* __restrict__ src_of) {
     const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
     if (st[scan].done) return;
     double acc[28];
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     for (int pp = 0; pp < pts; ++pp) {  // several points per thread before the 28-value block reduction (≈ as costly as a point)
     const int i = (blockIdx.x * pts + pp) * kBlock + threadIdx.x;
     if (i < counts[scan]) {
-        const float4 p = src[(size_t)scan * max_n + i];
+        const float4 p = src[(size_t)(src_of ? src_of[scan] : scan) * max_n + i];
         const D3 q{(double)p.x, (double)p.y, (double)p.z};
         const D3 qs = se3_apply(st[scan].q, st[scan].t, q);
         int kx, ky, kz;
@@ -346,13 +347,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 }
 
 int launch_ndt_accum(const NdtTable* t, const float4* src, const int* counts, const PoseState* st, int max_n, int n_scans, double* partials,
-                     hipStream_t s, const int* active, int n_active, int split_scans) {
+                     hipStream_t s, const int* active, int n_active, int split_scans, const int* src_of) {
     const int blocks = (max_n + kBlock - 1) / kBlock;
     const long total_blocks = (long)blocks * (split_scans > 0 ? split_scans : n_scans);  // the split — the order of the sums — never depends on `active`
     const int pts = total_blocks >= 8192 ? 8 : (total_blocks >= 4096 ? 4 : (total_blocks >= 2048 ? 2 : 1));
     dim3 grid((blocks + pts - 1) / pts, active ? n_active : n_scans);
     hipLaunchKernelGGL(ndt_accum_kernel, grid, dim3(kBlock), 0, s, t->d_keys, t->d_vid, t->d_mu, t->d_info, t->cap - 1, t->inv_voxel, t->res_outlier_th,
-                       t->n_nearby, src, counts, st, max_n, partials, pts, active);
+                       t->n_nearby, src, counts, st, max_n, partials, pts, active, src_of);
     return (int)grid.x;  // partial blocks per scan
 }
 

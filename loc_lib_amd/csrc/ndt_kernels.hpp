@@ -47,6 +47,6 @@ void ndt_table_free(NdtTable& t);
 // active / n_active (optional): the scans to launch (SearchArgs::active); split_scans > 0: split the partial sums as a plain batch of
 // that many scans would (AccumArgs::split_scans).
 int launch_ndt_accum(const NdtTable* t, const float4* src, const int* counts, const PoseState* st, int max_n, int n_scans, double* partials,
-                     hipStream_t s, const int* active = nullptr, int n_active = 0, int split_scans = 0);
+                     hipStream_t s, const int* active = nullptr, int n_active = 0, int split_scans = 0, const int* src_of = nullptr);
 
 }  // namespace locgpu

@@ -6,12 +6,15 @@
 // every iteration's fixed costs (five dependent launches, one traversal's latency, the solve) for an eighth of the work: 0.0204 ms
 // per scan-iteration against 0.0132 for 256 scans (profiles/r04_baseline_table.json).
 //
-// The pool keeps `slots` scan slots in HBM (points, neighbour lists, partial sums, pose state — the layout of a batch of that many
-// scans) and runs ONE launch sequence per pooled iteration over the union of the open scans of every job admitted so far:
-// search → fit/accumulate → solve over a device-side list of open slots. Jobs (sets of scans with their initial poses) are
-// submitted at any time; their points are copied straight into free slots on the copy stream while the pool iterates; at a chunk
-// boundary (every `chunk` iterations the host reads the flags) finished scans leave — their slots are free again — and waiting jobs
-// enter. A scan's arithmetic is what it would be in a plain batch: the kernels are the same, a scan's blocks do the same work
+// The pool keeps `slots` scan slots in HBM (neighbour lists, partial sums, pose state — the layout of a batch of that many scans)
+// plus an ARENA of source regions (slots + `prefetch` of them, one scan's points each) and runs ONE launch sequence per pooled
+// iteration over the union of the open scans of every job admitted so far: search → fit/accumulate → solve over a device-side
+// list of open slots; a slot says which region holds its points. Jobs (sets of scans with their initial poses) are submitted at
+// any time — all a job needs is free REGIONS: its points are copied there on the copy stream while the pool iterates, ahead of
+// the slots coming free. At a chunk boundary (every `chunk` iterations the host reads the flags) finished scans leave — slot and
+// region are free again — and waiting scans enter ONE BY ONE, oldest job first, as slots are there: the pool stays full without
+// waiting for a whole job's worth of room (round 5 measured the alternative — points copied into the slots themselves, a job
+// admitted as a whole: every refill waited for the copy and the pool ran dry between generations of jobs). A scan's arithmetic is what it would be in a plain batch: the kernels are the same, a scan's blocks do the same work
 // wherever the list finds them, and the split of the partial sums is the one a plain batch of `scans_per_job` scans uses — so a
 // pooled job of that size returns the plain batch's poses bit for bit (tests/test_gpu_pool.py).
 //
@@ -22,6 +25,8 @@
 // the owner of a scan solves it at once; the all-reduce and the replicas' solve run on the communication stream, off the critical
 // path. submit and wait are then collective calls.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -41,13 +46,13 @@ namespace {
 struct PoolJob {
     int64_t ticket = 0;
     int n_total = 0, first = 0, n_local = 0;
-    std::vector<int> slot;     // [n_total] slot of every scan of the job
+    std::vector<int> region;   // [n_total] source region of every scan of the job (points only in the ones this rank holds)
     std::vector<int> counts;   // [n_local] points of the scans this rank holds
+    int next = 0;              // scans [0, next) have been given a slot
     std::vector<double> init;  // [n_total][7]
     std::vector<double> out;   // [n_total][7]
     std::vector<locgpu_align_stats> stats;
     int remaining = 0;         // scans not finished yet
-    bool admitted = false;
     BatchUploadState upl;      // the event behind the copy of its points
 };
 
@@ -67,9 +72,14 @@ struct locgpu_pool {
     bool with_comm = false;   // the context has a communicator: exchange step every iteration
     bool multi_rank = false;  // ... of more than one rank: nothing may depend on this rank's timing
     bool decoupled = false;   // the owner of a slot solves it ahead of the exchange, which runs on the communication stream
+    int regions = 0;                      // source regions in the arena (>= slots)
+    float4* d_arena = nullptr;            // [regions][max_n]
     std::vector<int> free_slots;          // kept sorted descending: pop_back() hands out the smallest free slot
+    std::vector<int> free_regions;        // likewise
     std::vector<PoolJob*> slot_job;       // [slots] nullptr = free
     std::vector<int> slot_idx;            // [slots] index of the scan within its job
+    int* h_src_of = nullptr;              // pinned [slots]: region of the slot's points
+    int* d_src_of = nullptr;
     std::deque<PoolJob*> waiting;         // submitted, not admitted yet (FIFO)
     std::map<int64_t, PoolJob*> jobs;     // every job not yet handed back through locgpu_pool_wait
     int64_t next_ticket = 1;
@@ -118,7 +128,7 @@ void pool_collect(locgpu_pool* P) {
     locgpu_batch* b = P->b;
     for (int s = 0; s < P->slots; ++s) {
         PoolJob* j = P->slot_job[s];
-        if (!j || !j->admitted || !b->h_state[s].done) continue;
+        if (!j || !b->h_state[s].done) continue;
         const PoseState& ps = b->h_state[s];
         const int i = P->slot_idx[s];
         if (ps.status == 1) {  // direct NDT aborted: the reference leaves result_pose unassigned; hand back init_pose (locgpu_api.hip write_results)
@@ -133,6 +143,8 @@ void pool_collect(locgpu_pool* P) {
         j->remaining--;
         P->slot_job[s] = nullptr;
         P->free_slots.insert(std::upper_bound(P->free_slots.begin(), P->free_slots.end(), s, std::greater<int>()), s);
+        const int r = j->region[i];
+        P->free_regions.insert(std::upper_bound(P->free_regions.begin(), P->free_regions.end(), r, std::greater<int>()), r);
     }
     if (P->timed) {
         float ms = 0.f;
@@ -170,24 +182,24 @@ bool pool_launch_iteration(locgpu_pool* P) {
     mark();
     if (P->n_mine > 0) {
         if (!P->ndt) {
-            SearchArgs sa{ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ctx->depth, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, P->k,
+            SearchArgs sa{ctx->d_tree, ctx->tree_slots * sizeof(uint64_t), ctx->depth, P->d_arena, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, P->k,
                           P->alpha_eff, P->prm.method == LOCGPU_P2P ? 1 : 0, nullptr, b->d_redo_list, b->d_redo_count, b->d_redo_list2, b->d_redo_count + 1,
                           ctx->d_search_stats};
-            sa.active = mine; sa.n_active = P->n_mine;
+            sa.active = mine; sa.n_active = P->n_mine; sa.src_of = P->d_src_of;
             if (!ctx->tree_bounded) sa.redo_list = nullptr;  // huge / non-finite map coordinates: exact tree kernel only
             if (!launch_icp_search(sa, s)) { fail(ctx, LOCGPU_ERR_DEPTH, "pool: unsupported k/depth"); return false; }
             mark();
             const double gate = P->prm.method == LOCGPU_P2PLANE ? P->prm.max_plane_distance : (P->prm.method == LOCGPU_P2LINE ? P->prm.max_line_distance : P->prm.max_nn_distance);
-            AccumArgs aa{ctx->d_tree, b->d_src, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
-            aa.active = mine; aa.n_active = P->n_mine; aa.split_scans = P->split_scans;
+            AccumArgs aa{ctx->d_tree, P->d_arena, b->d_counts, b->d_state, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
+            aa.active = mine; aa.n_active = P->n_mine; aa.split_scans = P->split_scans; aa.src_of = P->d_src_of;
             n_partial_blocks = launch_icp_accum(P->prm.method, aa, s);
         } else if (P->prm.method == 4) {
             mark();
-            launch_inc_accum(ctx->inc, ctx->ndt_opts.res_outlier_th, ctx->ndt_opts.nearby_type == 0 ? 1 : 7, b->d_src, b->d_counts, b->d_state, b->max_n, b->n_scans, b->d_partials, s,
-                             mine, P->n_mine);
+            launch_inc_accum(ctx->inc, ctx->ndt_opts.res_outlier_th, ctx->ndt_opts.nearby_type == 0 ? 1 : 7, P->d_arena, b->d_counts, b->d_state, b->max_n, b->n_scans, b->d_partials, s,
+                             mine, P->n_mine, P->d_src_of);
         } else {
             mark();
-            n_partial_blocks = launch_ndt_accum(ctx->ndt, b->d_src, b->d_counts, b->d_state, b->max_n, b->n_scans, b->d_partials, s, mine, P->n_mine, P->split_scans);
+            n_partial_blocks = launch_ndt_accum(ctx->ndt, P->d_arena, b->d_counts, b->d_state, b->max_n, b->n_scans, b->d_partials, s, mine, P->n_mine, P->split_scans, P->d_src_of);
         }
     } else {
         mark();  // nothing local: this rank only takes part in the exchange below
@@ -228,45 +240,55 @@ int pool_launch(locgpu_pool* P) {
     locgpu_batch* b = P->b;
     hipStream_t s = b->stream;
     bool admitted_any = false;
-    while (!P->waiting.empty()) {
+    int open_now = 0;  // scans still running (the flags are fresh: the caller has just read them, or nothing has run since)
+    for (int sl = 0; sl < P->slots; ++sl) open_now += (P->slot_job[sl] && !b->h_state[sl].done) ? 1 : 0;
+    // waiting scans enter one by one, oldest job first, while there are free slots
+    while (!P->waiting.empty() && !P->free_slots.empty()) {
         PoolJob* j = P->waiting.front();
-        if (j->n_local > 0) {
+        if (j->next == 0 && j->n_local > 0) {
             // a copy still on its way must not stall the scans that are running (one rank only: with several ranks every decision
             // has to be the same everywhere, so the stream simply waits for the copy)
-            bool packing = false;
-            const bool unjoined = upload_running_for(ctx, &j->upl, &packing);
-            const bool may_defer = !P->multi_rank && P->n_open > 0;
-            if (may_defer && packing) break;
-            if (unjoined) { const int rc = upload_join(ctx); if (rc != LOCGPU_OK) return rc; }
-            if (j->upl.rc != LOCGPU_OK) return fail(ctx, j->upl.rc, j->upl.err);
+            const bool may_defer = !P->multi_rank && (open_now > 0 || admitted_any);
+            if (may_defer && upload_host_busy(&j->upl)) break;
+            { const int rc = upload_join_state(ctx, &j->upl); if (rc != LOCGPU_OK) return rc; }
             if (may_defer && hipEventQuery(j->upl.done) == hipErrorNotReady) break;
             LOCGPU_HIP(ctx, hipStreamWaitEvent(s, j->upl.done, 0));
         }
-        for (int i = 0; i < j->n_total; ++i) {
-            const int sl = j->slot[i];
+        while (j->next < j->n_total && !P->free_slots.empty()) {
+            const int i = j->next++;
+            const int sl = P->free_slots.back();
+            P->free_slots.pop_back();
+            P->slot_job[sl] = j;
+            P->slot_idx[sl] = i;
             init_state(b->h_state[sl], &j->init[7 * (size_t)i]);
             const bool mine = i >= j->first && i < j->first + j->n_local;
             P->h_owned[sl] = mine ? 1 : 0;
             P->h_counts[sl] = mine ? j->counts[i - j->first] : 0;
+            P->h_src_of[sl] = j->region[i];
+            admitted_any = true;
         }
-        j->admitted = true;
-        admitted_any = true;
-        P->waiting.pop_front();
+        if (j->next == j->n_total) P->waiting.pop_front();
     }
     int n_mine = 0, n_theirs = 0;
     for (int sl = 0; sl < P->slots; ++sl) {
-        PoolJob* j = P->slot_job[sl];
-        if (!j || !j->admitted || b->h_state[sl].done) continue;
+        if (!P->slot_job[sl] || b->h_state[sl].done) continue;
         if (P->h_owned[sl]) P->h_list[n_mine++] = sl;
         else P->h_list[P->slots + n_theirs++] = sl;
     }
     P->n_mine = n_mine; P->n_theirs = n_theirs;
     P->n_open = n_mine + n_theirs;
+    static const bool dbg = getenv("LOCGPU_POOL_DEBUG") != nullptr;  // diagnostic: one line per chunk
+    if (dbg) {
+        static const auto t0 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pool] t=%.3f ms open=%d (mine %d) waiting=%zu free slots=%zu regions=%zu jobs=%zu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                P->n_open, n_mine, P->waiting.size(), P->free_slots.size(), P->free_regions.size(), P->jobs.size());
+    }
     if (P->n_open == 0) return LOCGPU_OK;
     if (admitted_any) {
         // the host's copy of the states is the device's (read back behind the last chunk) plus the new scans' initial poses
         LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, (size_t)P->slots * sizeof(PoseState), hipMemcpyHostToDevice, s));
         LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_counts, P->h_counts, (size_t)P->slots * sizeof(int), hipMemcpyHostToDevice, s));
+        LOCGPU_HIP(ctx, hipMemcpyAsync(P->d_src_of, P->h_src_of, (size_t)P->slots * sizeof(int), hipMemcpyHostToDevice, s));
         if (P->d_owned) LOCGPU_HIP(ctx, hipMemcpyAsync(P->d_owned, P->h_owned, (size_t)P->slots, hipMemcpyHostToDevice, s));
     }
     if (n_mine) LOCGPU_HIP(ctx, hipMemcpyAsync(P->d_list, P->h_list, (size_t)n_mine * sizeof(int), hipMemcpyHostToDevice, s));
@@ -315,6 +337,7 @@ void locgpu_pool_opts_default(locgpu_pool_opts* o) {
     if (!o) return;
     std::memset(o, 0, sizeof(*o));
     o->slots = 256;
+    o->prefetch = -1;
     o->scans_per_job = 32;
     o->chunk = 4;
     o->matcher = 0;
@@ -326,7 +349,7 @@ int locgpu_pool_create(locgpu_ctx* ctx, const locgpu_pool_opts* o, locgpu_pool**
     if (!ctx) return LOCGPU_ERR_INVALID;
     if (!o || !out) return fail(ctx, LOCGPU_ERR_INVALID, "pool_create: bad arguments");
     *out = nullptr;
-    if (o->slots < 1 || o->slots > 65535 || o->max_points == 0 || o->chunk < 0 || o->chunk > kAccRing || o->scans_per_job < 0 || (o->matcher != 0 && o->matcher != 1))
+    if (o->slots < 1 || o->slots > 65535 || o->prefetch < -1 || o->prefetch > 1000000 || o->max_points == 0 || o->chunk < 0 || o->chunk > kAccRing || o->scans_per_job < 0 || (o->matcher != 0 && o->matcher != 1))
         return fail(ctx, LOCGPU_ERR_INVALID, "pool_create: bad options (1 <= slots <= 65535, chunk <= 8, matcher 0 | 1)");
     auto* P = new locgpu_pool();
     P->ctx = ctx;
@@ -347,10 +370,16 @@ int locgpu_pool_create(locgpu_ctx* ctx, const locgpu_pool_opts* o, locgpu_pool**
     rc = alloc_batch(ctx, o->slots, (size_t)o->max_points, &P->b);
     if (rc != LOCGPU_OK) { delete P; return rc; }
     const size_t S = (size_t)P->slots;
+    // the points live in the arena, not in the storage batch's own source array
+    if (P->b->d_src) { (void)hipFree(P->b->d_src); P->b->d_src = nullptr; }
+    P->regions = P->slots + (o->prefetch >= 0 ? o->prefetch : P->slots);
+    if (!hip_ok(ctx, hipMalloc((void**)&P->d_arena, (size_t)P->regions * P->b->max_n * sizeof(float4)), "pool: hipMalloc source arena")) { locgpu_pool_destroy(P); return LOCGPU_ERR_OOM; }
     bool ok = hip_ok(ctx, hipHostMalloc((void**)&P->h_list, 2 * S * sizeof(int)), "pool: hipHostMalloc") &&
               hip_ok(ctx, hipMalloc((void**)&P->d_list, 2 * S * sizeof(int)), "pool: hipMalloc") &&
               hip_ok(ctx, hipHostMalloc((void**)&P->h_counts, S * sizeof(int)), "pool: hipHostMalloc") &&
               hip_ok(ctx, hipHostMalloc((void**)&P->h_owned, S), "pool: hipHostMalloc") &&
+              hip_ok(ctx, hipHostMalloc((void**)&P->h_src_of, S * sizeof(int)), "pool: hipHostMalloc") &&
+              hip_ok(ctx, hipMalloc((void**)&P->d_src_of, S * sizeof(int)), "pool: hipMalloc") &&
               hip_ok(ctx, hipEventCreate(&P->ev_t0), "pool: hipEventCreate") && hip_ok(ctx, hipEventCreate(&P->ev_t1), "pool: hipEventCreate");
     if (ok && P->with_comm)
         ok = hip_ok(ctx, hipMalloc((void**)&P->d_owned, S), "pool: hipMalloc") &&
@@ -360,11 +389,15 @@ int locgpu_pool_create(locgpu_ctx* ctx, const locgpu_pool_opts* o, locgpu_pool**
     if (!ok) { locgpu_pool_destroy(P); return LOCGPU_ERR_OOM; }
     std::memset(P->h_counts, 0, S * sizeof(int));
     std::memset(P->h_owned, 0, S);
+    std::memset(P->h_src_of, 0, S * sizeof(int));
+    if (!hip_ok(ctx, hipMemsetAsync(P->d_src_of, 0, S * sizeof(int), P->b->stream), "pool: hipMemset") || !hip_ok(ctx, hipStreamSynchronize(P->b->stream), "pool: hipMemset")) { locgpu_pool_destroy(P); return LOCGPU_ERR_NO_DEVICE; }
     for (size_t s = 0; s < S; ++s) { std::memset(&P->b->h_state[s], 0, sizeof(PoseState)); P->b->h_state[s].done = 1; }  // a free slot is a finished scan
     P->slot_job.assign(S, nullptr);
     P->slot_idx.assign(S, 0);
     P->free_slots.resize(S);
     for (size_t s = 0; s < S; ++s) P->free_slots[s] = (int)(S - 1 - s);
+    P->free_regions.resize(P->regions);
+    for (int r = 0; r < P->regions; ++r) P->free_regions[r] = P->regions - 1 - r;
     *out = P;
     return LOCGPU_OK;
 }
@@ -373,7 +406,7 @@ void locgpu_pool_destroy(locgpu_pool* P) {
     if (!P) return;
     locgpu_ctx* ctx = P->ctx;
     (void)hipSetDevice(ctx->device);
-    if (ctx->up && ctx->up->worker_active && ctx->up->current == P->b) (void)upload_join(ctx);
+    upload_drain(ctx);  // no job's scans are being packed into the pool's slots any more
     if (P->b) (void)hipStreamSynchronize(P->b->stream);
     if (P->with_comm && ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
     for (auto& kv : P->jobs) job_free(kv.second);
@@ -381,6 +414,9 @@ void locgpu_pool_destroy(locgpu_pool* P) {
     if (P->d_list) (void)hipFree(P->d_list);
     if (P->h_counts) (void)hipHostFree(P->h_counts);
     if (P->h_owned) (void)hipHostFree(P->h_owned);
+    if (P->h_src_of) (void)hipHostFree(P->h_src_of);
+    if (P->d_src_of) (void)hipFree(P->d_src_of);
+    if (P->d_arena) (void)hipFree(P->d_arena);
     if (P->d_owned) (void)hipFree(P->d_owned);
     if (P->d_acc) (void)hipFree(P->d_acc);
     for (hipEvent_t ev : P->stage_ev) (void)hipEventDestroy(ev);
@@ -398,7 +434,7 @@ int locgpu_pool_submit(locgpu_pool* P, const void* const* srcs, const size_t* co
     locgpu_ctx* ctx = P->ctx;
     if (!ticket || !init_poses || n_total < 1 || n_local < 0 || first_scan < 0 || first_scan + n_local > n_total || (n_local > 0 && (!srcs || !counts)) || stride_bytes < 12)
         return pool_fail(P, LOCGPU_ERR_INVALID, "pool_submit: bad arguments");
-    if (n_total > P->slots) return pool_fail(P, LOCGPU_ERR_INVALID, "pool_submit: the job has more scans than the pool has slots");
+    if (n_total > P->regions) return pool_fail(P, LOCGPU_ERR_INVALID, "pool_submit: the job has more scans than the pool has source regions (slots + prefetch)");
     if (!P->with_comm && n_local != n_total)
         return pool_fail(P, LOCGPU_ERR_INVALID, "pool_submit: this rank holds only part of the job and locgpu_comm_init has not been called");
     for (int i = 0; i < n_local; ++i) {
@@ -414,17 +450,19 @@ int locgpu_pool_submit(locgpu_pool* P, const void* const* srcs, const size_t* co
         const int rc = P->ndt ? check_ndt(ctx, prm) : check_icp(ctx, &P->icp, prm, k, a);
         if (rc != LOCGPU_OK) return rc;
     }
-    while ((int)P->free_slots.size() < n_total) {  // room: let scans finish
+    // room in the arena: let scans finish. Every rank accounts n_total regions for the job, whichever scans it holds: the calls a
+    // rank makes must not depend on the shard it happens to hold.
+    while ((int)P->free_regions.size() < n_total) {
         bool progress = false;
         const int rc = pool_pump(P, true, &progress);
         if (rc != LOCGPU_OK) return rc;
-        if (!progress) return pool_fail(P, LOCGPU_ERR_INVALID, "pool_submit: no free slots and nothing running (collect finished jobs with locgpu_pool_wait)");
+        if (!progress) return pool_fail(P, LOCGPU_ERR_INVALID, "pool_submit: no free source regions and nothing running");
     }
     auto* j = new PoolJob();
     j->ticket = P->next_ticket++;
     j->n_total = n_total; j->first = first_scan; j->n_local = n_local;
-    j->slot.resize(n_total);
-    for (int i = 0; i < n_total; ++i) { j->slot[i] = P->free_slots.back(); P->free_slots.pop_back(); }
+    j->region.resize(n_total);
+    for (int i = 0; i < n_total; ++i) { j->region[i] = P->free_regions.back(); P->free_regions.pop_back(); }
     j->counts.resize(n_local);
     for (int i = 0; i < n_local; ++i) j->counts[i] = (int)counts[i];
     j->init.assign(init_poses, init_poses + 7 * (size_t)n_total);
@@ -432,15 +470,14 @@ int locgpu_pool_submit(locgpu_pool* P, const void* const* srcs, const size_t* co
     j->stats.assign(n_total, locgpu_align_stats{});
     j->remaining = n_total;
     if (n_local > 0) {
-        const int rc = upload_start_slots(P->b, &j->upl, srcs, counts, stride_bytes, n_local, j->slot.data() + first_scan);
+        const int rc = upload_start_regions(P->b, &j->upl, P->d_arena, P->regions, srcs, counts, stride_bytes, n_local, j->region.data() + first_scan);
         if (rc != LOCGPU_OK) {
-            for (int i = n_total - 1; i >= 0; --i) P->free_slots.push_back(j->slot[i]);
-            std::sort(P->free_slots.begin(), P->free_slots.end(), std::greater<int>());
+            for (int i = n_total - 1; i >= 0; --i) P->free_regions.push_back(j->region[i]);
+            std::sort(P->free_regions.begin(), P->free_regions.end(), std::greater<int>());
             job_free(j);
             return rc;
         }
     }
-    for (int i = 0; i < n_total; ++i) { P->slot_job[j->slot[i]] = j; P->slot_idx[j->slot[i]] = i; }
     P->jobs[j->ticket] = j;
     P->waiting.push_back(j);
     *ticket = j->ticket;
@@ -468,6 +505,20 @@ int locgpu_pool_wait(locgpu_pool* P, int64_t ticket, double* out_poses, locgpu_a
     return LOCGPU_OK;
 }
 
+int locgpu_pool_step(locgpu_pool* P, int block) {
+    if (!P) return LOCGPU_ERR_INVALID;
+    LOCGPU_HIP(P->ctx, hipSetDevice(P->ctx->device));
+    return pool_pump(P, block != 0);
+}
+
+int locgpu_pool_done(const locgpu_pool* P, int64_t ticket, int* done) {
+    if (!P || !done) return LOCGPU_ERR_INVALID;
+    auto it = P->jobs.find(ticket);
+    if (it == P->jobs.end()) return fail(P->ctx, LOCGPU_ERR_INVALID, "pool_done: unknown ticket");
+    *done = it->second->remaining == 0;
+    return LOCGPU_OK;
+}
+
 int locgpu_pool_profile_read(locgpu_pool* P, double out[2], int reset) {
     if (!P || !out) return LOCGPU_ERR_INVALID;
     out[0] = P->chunk_ms;
@@ -476,8 +527,10 @@ int locgpu_pool_profile_read(locgpu_pool* P, double out[2], int reset) {
     return LOCGPU_OK;
 }
 
-int locgpu_pool_info(const locgpu_pool* P, int64_t out[6]) {
+int locgpu_pool_info(const locgpu_pool* P, int64_t out[8]) {
     if (!P || !out) return LOCGPU_ERR_INVALID;
+    out[6] = P->regions;
+    out[7] = (int64_t)P->free_regions.size();
     out[0] = P->slots;
     out[1] = (int64_t)P->free_slots.size();
     out[2] = (int64_t)P->jobs.size();

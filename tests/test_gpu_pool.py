@@ -30,8 +30,9 @@ def _jobs(small_world, n_jobs, per_job):
 
 @pytest.mark.parametrize("method", ["p2plane", "p2p", "p2line"])
 def test_pool_jobs_get_the_plain_batch_bits(gpu_ctx, api, small_world, method):
-    """Nine four-scan jobs through an eight-slot pool (so jobs wait for slots, scans of different jobs share launches, slots are
-    reused) give poses, iteration counts and stats equal to locgpu_icp_align_batch on a plain batch of each job, bit for bit."""
+    """Nine four-scan jobs through a pool of eight slots and twelve source regions (so submits wait for regions, scans wait for slots
+    and enter one by one, scans of different jobs share launches, slots and regions are reused) give poses, iteration counts and
+    stats equal to locgpu_icp_align_batch on a plain batch of each job, bit for bit."""
     gpu_ctx.icp_set_target(small_world["map"])
     opts = api.icp_opts(method=dict(p2plane=api.P2PLANE, p2p=api.P2P, p2line=api.P2LINE)[method])
     jobs = _jobs(small_world, 9, 4)
@@ -43,16 +44,16 @@ def test_pool_jobs_get_the_plain_batch_bits(gpu_ctx, api, small_world, method):
     its = sorted({st["iterations"] for w in want for st in w[1]})
     assert len(its) >= 3, its  # the jobs really finish at different times
     for chunk in (1, 3):
-        pool = api.Pool(gpu_ctx, slots=8, max_points=6000, scans_per_job=4, chunk=chunk, opts=opts)
-        tickets = [pool.submit(scans, inits) for scans, inits in jobs[:2]]  # the pool is full now
-        for scans, inits in jobs[2:]:
-            tickets.append(pool.submit(scans, inits))  # lets running scans finish until the job has slots
+        pool = api.Pool(gpu_ctx, slots=8, max_points=6000, scans_per_job=4, chunk=chunk, opts=opts, prefetch=4)
+        tickets = [pool.submit(scans, inits) for scans, inits in jobs[:3]]  # the arena is full now
+        for scans, inits in jobs[3:]:
+            tickets.append(pool.submit(scans, inits))  # lets running scans finish until the job has regions
         for t, w in reversed(list(zip(tickets, want))):  # collected in another order than submitted
             got, st = pool.wait(t)
             assert np.array_equal(got, w[0])
             assert st == w[1]
         info = pool.info()
-        assert info["free"] == 8 and info["jobs"] == 0 and info["open"] == 0
+        assert info["free"] == 8 and info["free_regions"] == 12 and info["jobs"] == 0 and info["open"] == 0
         with pytest.raises(RuntimeError):
             pool.wait(tickets[0])  # a ticket is good once
         pool.close()
@@ -84,7 +85,7 @@ def test_pool_refusals(gpu_ctx, api, small_world):
     with pytest.raises(RuntimeError):
         pool.submit([s[:5000]], pose[None])           # more points than a slot holds
     with pytest.raises(RuntimeError):
-        pool.submit([s[:100]] * 3, np.stack([pose] * 3))  # more scans than slots
+        pool.submit([s[:100]] * 5, np.stack([pose] * 5))  # more scans than source regions (slots + prefetch = 4)
     with pytest.raises(RuntimeError):
         pool.submit([s[:100]], np.stack([pose] * 2), first=0, n_total=2)  # part of a job without a communicator
     t = pool.submit([s[:3000], s[:10]], np.stack([pose, pose]))  # the pool still works
