@@ -284,6 +284,9 @@ def main():
                          "all steps begun) with this many scan slots; 0 = plain batches, three alignments in flight; -1 (default) = 256 slots "
                          "whenever a rank's step holds fewer than 256 scans, plain batches otherwise")
     ap.add_argument("--pool-chunk", type=int, default=0, help="pool: iterations between two looks at the flags (0 = the library's default)")
+    ap.add_argument("--pool-lanes", type=int, default=2,
+                    help="pool: split the slots over this many pools on different streams of the context and deal the steps to them: the launches of "
+                         "one fill the tails of the other's (the plain-batch mode's alignments in flight do the same)")
     ap.add_argument("--traffic", choices=["live", "profiles", "none"], default="live",
                     help="roofline counters: live = rocprofv3 --pmc child runs + one diagnostic-build child run now (1 GPU only), profiles = newest committed traffic collection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -377,7 +380,11 @@ def main():
     # in a batch that an alignment in flight (steps g, g-1) is reading. Pool: one plain batch for the instrumented pass.
     bufs = [new_batch() for _ in range(1 if use_pool else (depth if args.resident else depth + 1))]
     scans_c = api.MarshalledScans(scans) if scans else []  # the (pointer, count) arrays a C caller of locgpu_batch_upload_async already holds
-    pool = api.Pool(ctx, slots=pool_slots, max_points=max(pts_per_scan, 1), scans_per_job=n_total, chunk=args.pool_chunk, opts=opts, ndt=(method < 0)) if use_pool else None
+    lanes = max(1, min(args.pool_lanes, 3)) if use_pool else 0
+    while lanes > 1 and 2 * (pool_slots // lanes) < n_total:  # a lane's arena (slots + as many prefetch regions) must hold one step
+        lanes -= 1
+    pools = [api.Pool(ctx, slots=pool_slots // lanes, max_points=max(pts_per_scan, 1), scans_per_job=n_total, chunk=args.pool_chunk, opts=opts, ndt=(method < 0))
+             for _ in range(lanes)]
 
     def align_batch(b):
         return ctx.ndt_align_batch(b, inits) if method < 0 else ctx.icp_align_batch(b, inits, opts)
@@ -405,9 +412,9 @@ def main():
             debug_times.append((time.perf_counter() - t_b, t_b - t_a))
         return b
 
-    def run_steps(n):
+    def run_steps(n, pools=pools):
         """Exactly n steps, begun and ended in here; at most `depth` alignments in flight. Pool: a step = one job — its scans are
-        submitted (the copy into free slots starts at once and runs beside the pool's iterations) and collected by ticket."""
+        submitted (the copy into free source regions starts at once and runs beside the pool's iterations) and collected by ticket."""
         inflight, begun, res = [], 0, None
         if use_pool:
             # a step is submitted as soon as the pool has free source regions for it (its copy then runs ahead of the slots coming free,
@@ -415,13 +422,19 @@ def main():
             # steps are outstanding.
             # Every decision depends on the flags all ranks see, so the ranks of a sharded run make the same calls in the same order.
             while begun < n or inflight:
-                while begun < n and len(inflight) < 4 * depth and (not inflight or pool.info()["free_regions"] >= n_total):
-                    inflight.append(pool.submit(scans_c, inits, first=lo, n_total=n_total))
+                while begun < n and len(inflight) < 4 * depth:
+                    p = max(pools, key=lambda q: q.info()["free_regions"])  # the emptier lane
+                    if inflight and p.info()["free_regions"] < n_total:
+                        break
+                    inflight.append((p, p.submit(scans_c, inits, first=lo, n_total=n_total)))
                     begun += 1
-                if pool.done(inflight[0]):
-                    res = pool.wait(inflight.pop(0))
+                p, t = inflight[0]
+                if p.done(t):
+                    res = p.wait(t)
+                    inflight.pop(0)
                 else:
-                    pool.step(True)
+                    for q in pools:
+                        q.step(True)
             return res
         while begun < n or inflight:
             while begun < n and len(inflight) < depth:
@@ -461,17 +474,17 @@ def main():
         b.upload_wait()
     # ---- kernel durations: `extra` further steps of the same workload, ONE alignment at a time (launches of different batches
     # overlap in the timed region), HIP events on the library's stream around every stage of every iteration
-    n_extra = max(1, args.extra_steps, 2 * depth if use_pool else 0)  # pool: at least two pools' worth, so that the launches profiled are steady-state ones
+    n_extra = max(1, args.extra_steps, -(-4 * pool_slots // max(n_total, 1)) if use_pool else 0)  # pool: four pools' worth, so that most launches profiled are steady-state ones
     ctx.profile_read(reset=True)
     ctx.profile_enable(1)
     if use_pool:
-        run_steps(n_extra)
+        run_steps(n_extra, pools[:1])  # ONE lane: with two, an event interval of one lane would contain the other's kernels
     else:
         for _ in range(n_extra):
             align_batch(bufs[0])
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
-    stage_src = ("HIP events around every stage of %d further steps of the same workload through the pool (%d steps in flight), right behind the timed region" % (n_extra, depth)) if use_pool else \
+    stage_src = ("HIP events around every stage of %d further steps of the same workload through one lane of the pool, right behind the timed region" % n_extra) if use_pool else \
         "HIP events around every stage of %d further steps of the same workload, one alignment at a time, right behind the timed region" % n_extra
 
     if dist is not None:
@@ -514,7 +527,7 @@ def main():
         if args.traffic == "live" and world == 1 and dist is None:
             passthrough = ["--scans-per-gpu", str(args.scans_per_gpu), "--map-points", str(args.map_points), "--method", args.method,
                            "--search", args.search, "--scaling", args.scaling, "--total-scans", str(args.total_scans), "--pool-slots", str(pool_slots),
-                           "--pool-chunk", str(args.pool_chunk)] + (["--resident"] if args.resident else [])
+                           "--pool-chunk", str(args.pool_chunk), "--pool-lanes", str(args.pool_lanes)] + (["--resident"] if args.resident else [])
             counters, counters_note = measure_counters_live(passthrough, steps=(2 * depth if use_pool else 2), pipeline=(0 if use_pool else 1), extra=n_extra)
             if method >= 0 and args.search != "grid":
                 lane_eff, lane_note = measure_lane_efficiency_live(passthrough, steps=(depth if use_pool else 1), pipeline=(0 if use_pool else 1), resident=not use_pool)
@@ -601,7 +614,7 @@ def main():
                     config=dict(workload="%s: %d scans/GPU x %d pts (64x1800, cityblock-v1) vs one %d-pt map, "
                                          "%s, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), %s; %s; %s"
                                          % (cfg_name, B_local, pts_per_scan, args.map_points, "direct NDT (voxel 1.0, NEARBY6)" if method < 0 else args.method.upper() + " ICP", shard, mode,
-                                            ("open-scan pool of %d slots, %d steps in flight" % (pool_slots, depth)) if use_pool else "%d alignment(s) in flight" % depth),
+                                            ("open-scan pool of %d slots in %d lane(s), about %d steps in flight" % (pool_slots, lanes, depth)) if use_pool else "%d alignment(s) in flight" % depth),
                                 scans_per_gpu=B_local, map_points=args.map_points, scan_h2d_in_timed_region=not args.resident, pipeline_depth=depth,
                                 search_mode=dict(tree="tree_faithful_ann", tree_exact="tree_faithful_exact", grid="grid_exact")[args.search], tree_depth=tinfo["depth"],
                                 tree_bytes=tinfo["bytes"]),
@@ -615,7 +628,8 @@ def main():
                     setup_s=dict(map_gen=round(t_map, 2), tree_ingest=round(t_ingest, 2)),
                     roofline=roofline)
         if use_pool:
-            line["pool"] = dict(slots=pool_slots, steps_in_flight=depth, chunk=(args.pool_chunk or 4), **{k: v for k, v in pool.info().items() if k in ("iterations", "scan_iterations")})
+            line["pool"] = dict(slots=pool_slots, lanes=lanes, steps_in_flight=depth, chunk=(args.pool_chunk or 4),
+                                iterations=sum(q.info()["iterations"] for q in pools), scan_iterations=sum(q.info()["scan_iterations"] for q in pools))
         line["scans_per_rank"] = B_local
         line["rccl_ranks"] = (ctx.comm_info()[1] if use_comm else (world if dist is not None else 1))  # ranks RCCL joined: the library's communicator (strong), torch's process group (weak)
         line["rccl_use"] = ("per-iteration all-reduce + tree broadcast inside liblocgpu.so (locgpu_comm_info)" if use_comm else
@@ -648,8 +662,8 @@ def main():
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
 
-    if pool is not None:
-        pool.close()
+    for q in pools:
+        q.close()
     for b in bufs:
         b.close()
     ctx.close()
