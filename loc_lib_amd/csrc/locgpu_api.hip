@@ -936,7 +936,7 @@ static int capture_chunk(locgpu_ctx* ctx, locgpu_batch* b, const GnParams& prm, 
 // first chunk of iterations and returns; align_finish waits for it, enqueues further chunks while scans are still open, and
 // writes the results. The blocking entry points are begin + finish back to back.
 static int ensure_graphs(locgpu_ctx* ctx, locgpu_batch* b, const GnParams& prm, int k, float alpha_eff, bool ndt) {
-    const void* target = !ndt ? (const void*)ctx->d_tree : (prm.method == 4 ? inc_ndt_table_ptr(ctx->inc) : (const void*)ctx->ndt->d_keys);
+    const void* target = !ndt ? (const void*)ctx->d_tree : (prm.method == 4 ? inc_ndt_table_ptr(ctx->inc) : (const void*)ctx->ndt->d_rec);
     const bool same = b->graph_exec && b->graph_k == k && b->graph_alpha == alpha_eff && b->graph_ndt == ndt && b->graph_target == target &&
                       b->graph_epoch == ctx->target_epoch &&
                       b->graph_prm == prm;
@@ -1498,7 +1498,7 @@ int locgpu_ndt_target_info(const locgpu_ctx* ctx, int64_t out[3]) {
     if (!ctx->ndt) { out[0] = out[1] = out[2] = 0; return LOCGPU_ERR_NO_TARGET; }
     out[0] = (int64_t)ctx->ndt->n_vox;
     out[1] = (int64_t)ctx->ndt->cap;
-    out[2] = (int64_t)(ctx->ndt->cap * 12 + ctx->ndt->n_vox * (3 + 9) * 8 + ctx->ndt->n_vox * 12);
+    out[2] = (int64_t)(ctx->ndt->cap * sizeof(NdtSlot) + ctx->ndt->n_vox * sizeof(NdtRecord));
     return LOCGPU_OK;
 }
 
@@ -1515,9 +1515,7 @@ int locgpu_ndt_dump(locgpu_ctx* ctx, int32_t* keys, double* mu, double* info, si
     const size_t n = std::min(cap, ctx->ndt->n_vox);
     if (n == 0) return LOCGPU_OK;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
-    if (keys) LOCGPU_HIP(ctx, hipMemcpy(keys, ctx->ndt->d_vox_key, n * 3 * sizeof(int), hipMemcpyDeviceToHost));
-    if (mu) LOCGPU_HIP(ctx, hipMemcpy(mu, ctx->ndt->d_mu, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    if (info) LOCGPU_HIP(ctx, hipMemcpy(info, ctx->ndt->d_info, n * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    LOCGPU_HIP(ctx, ndt_dump(*ctx->ndt, keys, mu, info, n, ctx->stream));
     return LOCGPU_OK;
 }
 

@@ -8,8 +8,9 @@ Direct NDT with min_pts_in_voxel < 3 (the default is 3) keeps voxels of two or t
 reference inverts it as V·diag(1/λ')·Uᵀ from Eigen's JacobiSVD (ndt_registration.cpp:118-130): for a singular value that is rounding
 noise, U's column is the negated V column about half the time, and the "information" matrix gets a large NEGATIVE eigenvalue. Which
 voxels that happens to is decided by the last bit of the covariance sums — it cannot be reproduced by anything but the same
-instruction sequence on the same sums (the oracle restates it; the device sums with atomics and uses U = V). Those cases are
-counted separately ("rank-deficient voxels"), checked for equal voxel counts only, and stated as a deviation in INTEGRATION.md.
+instruction sequence on the same sums (the oracle restates it; since round 5 the device forms the same sums in the same order — the
+cases that then agree completely are counted). Those cases are counted separately ("rank-deficient voxels"), required to agree in
+their voxel counts only, and stated as a deviation in INTEGRATION.md.
 
     python tools/fuzz_ndt.py [--cases 60]
 """
@@ -38,7 +39,7 @@ def main():
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     worst_t = worst_q = 0.0
-    bad = degenerate = unstable = 0
+    bad = degenerate = degenerate_equal = unstable = 0
     for case in range(a.cases):
         sid = int(rng.integers(0, 256))
         m = synth.make_local_map(int(10 ** rng.uniform(4.3, 5.5)), sid, half=40.0)
@@ -91,13 +92,16 @@ def main():
             if nv_g != nv_o:
                 bad += 1
                 print("MISMATCH case %d (rank-deficient voxels): voxels %d/%d" % (case, nv_g, nv_o), flush=True)
+            # round 5: the device's covariance sums are the oracle's bits, so these cases may agree as well — counted, not required
+            if nv_g == nv_o and st["iterations"] == want["iters"] and st["status"] == want["status"] and dt <= 1e-7 and dq <= 1e-7:
+                degenerate_equal += 1
             del ctx
             continue
         if nv_g != nv_o or st["iterations"] != want["iters"] or st["status"] != want["status"] or dt > 1e-7 or dq > 1e-7:
             # Is the reference itself stable here? An alignment against a handful of voxels (most dropped by min_pts_in_voxel) has
-            # near-singular normal equations: a 1e-9 change of the initial pose sends the ORACLE somewhere else, and the 1e-7
-            # relative difference between the device's atomically summed covariances and the sequential ones does the same to the
-            # device. Such a case is counted as "reference unstable", not as a mismatch.
+            # near-singular normal equations: a 1e-9 change of the initial pose sends the ORACLE somewhere else, and the last-bit
+            # differences between the device's per-point sums (tree-shaped block reductions) and the oracle's sequential ones do the
+            # same to the device. Such a case is counted as "reference unstable", not as a mismatch.
             init2 = np.array(init, dtype=np.float64)
             init2[4:] += 1e-9
             want2 = ref.align(scan, init2)
@@ -111,8 +115,8 @@ def main():
                 case, method, cap, kw, nv_g, nv_o, st["iterations"], want["iters"], st["status"], want["status"], dt, dq), flush=True)
         worst_t, worst_q = max(worst_t, dt), max(worst_q, dq)
         del ctx
-    print("cases %d: mismatches %d, worst pose delta %.2e m / %.2e (quaternion components); %d direct cases with rank-deficient voxels compared by voxel count only; %d cases where the oracle itself is unstable (1e-9 on the initial pose changes its result)" % (
-        a.cases, bad, worst_t, worst_q, degenerate, unstable))
+    print("cases %d: mismatches %d, worst pose delta %.2e m / %.2e (quaternion components); %d direct cases with rank-deficient voxels compared by voxel count only (%d of them agree in pose, iterations and status all the same); %d cases where the oracle itself is unstable (1e-9 on the initial pose changes its result)" % (
+        a.cases, bad, worst_t, worst_q, degenerate, degenerate_equal, unstable))
     return 1 if bad else 0
 
 
