@@ -61,11 +61,11 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(map_xyz, scans, inits, seconds_budget=20.0, method="p2plane"):
+def cpu_baseline(map_xyz, scans, inits, seconds_budget=20.0, method="p2plane", ndt_kw=None):
     """The oracle (CPU restatement of the reference path, single thread like the reference) on a bounded sample."""
     from oracle import locref  # test infrastructure used here only as the reported baseline
 
-    icp = locref.Ndt() if method == "ndt" else locref.Icp(method=dict(p2p=locref.P2P, p2line=locref.P2LINE, p2plane=locref.P2PLANE)[method])
+    icp = locref.Ndt(**(ndt_kw or {})) if method == "ndt" else locref.Icp(method=dict(p2p=locref.P2P, p2line=locref.P2LINE, p2plane=locref.P2PLANE)[method])
     t0 = time.time()
     icp.set_target(map_xyz)
     ingest = time.time() - t0
@@ -264,6 +264,8 @@ def main():
     ap.add_argument("--scans-per-gpu", type=int, default=256)
     ap.add_argument("--method", choices=["p2plane", "p2line", "p2p", "ndt"], default="p2plane",
                     help="matcher to time; the headline metric is p2plane (others are reported for DESIGN.md tables)")
+    ap.add_argument("--ndt-voxel", type=float, default=1.0, help="--method ndt: NdtOptions::voxel_size_ (slam.yaml's localisation node: 1.2)")
+    ap.add_argument("--ndt-nearby", choices=["nearby6", "center"], default="nearby6", help="--method ndt: NdtOptions::nearby_type_")
     ap.add_argument("--map-points", type=int, default=10_000_000)
     ap.add_argument("--search", choices=["tree", "tree_exact", "grid"], default="tree",
                     help="tree = the reference's default alpha=0.1 approximate KD-tree search (headline); tree_exact / grid = "
@@ -361,7 +363,7 @@ def main():
         opts.approximate = 0
     if method < 0:
         t0 = time.time()
-        ctx.ndt_set_target(map_xyz)           # NdtOptions defaults: voxel 1.0, NEARBY6, DIRECT_NDT
+        ctx.ndt_set_target(map_xyz, api.ndt_opts(voxel_size=args.ndt_voxel, nearby_type=(api.NEARBY6 if args.ndt_nearby == "nearby6" else api.CENTER)))  # other NdtOptions: defaults (DIRECT_NDT)
         t_ingest = time.time() - t0
 
     def new_batch():
@@ -510,7 +512,7 @@ def main():
         accum_bytes = q * (16 + 4 * k + 16 * k) + gn_iters * 29 * 8      # src + indices + 5 gathered leaves; partial sums negligible
         if method < 0:
             nv = ctx.ndt_target_info()["num_voxels"]
-            accum_bytes = q * (16 + 7 * 12) + (prof["accum_n"] or 1) * nv * 96  # src + 7 hash probes per point; voxel μ/info once per launch
+            accum_bytes = q * (16 + (7 if args.ndt_nearby == "nearby6" else 1) * 16) + (prof["accum_n"] or 1) * nv * 128  # src + one 16-byte slot probe per voxel looked up; every voxel record (128 B) once per launch
         t_search = prof["search_ms"] * prof["search_n"] / n_extra      # ms per step (profiled steps)
         t_accum = prof["accum_ms"] * prof["accum_n"] / n_extra
         t_solve = prof["solve_ms"] * prof["solve_n"] / n_extra
@@ -527,7 +529,7 @@ def main():
         if args.traffic == "live" and world == 1 and dist is None:
             passthrough = ["--scans-per-gpu", str(args.scans_per_gpu), "--map-points", str(args.map_points), "--method", args.method,
                            "--search", args.search, "--scaling", args.scaling, "--total-scans", str(args.total_scans), "--pool-slots", str(pool_slots),
-                           "--pool-chunk", str(args.pool_chunk), "--pool-lanes", str(args.pool_lanes)] + (["--resident"] if args.resident else [])
+                           "--pool-chunk", str(args.pool_chunk), "--pool-lanes", str(args.pool_lanes), "--ndt-voxel", str(args.ndt_voxel), "--ndt-nearby", args.ndt_nearby] + (["--resident"] if args.resident else [])
             counters, counters_note = measure_counters_live(passthrough, steps=(2 * depth if use_pool else 2), pipeline=(0 if use_pool else 1), extra=n_extra)
             if method >= 0 and args.search != "grid":
                 lane_eff, lane_note = measure_lane_efficiency_live(passthrough, steps=(depth if use_pool else 1), pipeline=(0 if use_pool else 1), resident=not use_pool)
@@ -613,7 +615,7 @@ def main():
                     higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f64", search_dtype="f32", data="synthetic",
                     config=dict(workload="%s: %d scans/GPU x %d pts (64x1800, cityblock-v1) vs one %d-pt map, "
                                          "%s, reference defaults (alpha=0.1 KD-tree ANN, eps=1e-2, max 20 iters), %s; %s; %s"
-                                         % (cfg_name, B_local, pts_per_scan, args.map_points, "direct NDT (voxel 1.0, NEARBY6)" if method < 0 else args.method.upper() + " ICP", shard, mode,
+                                         % (cfg_name, B_local, pts_per_scan, args.map_points, ("direct NDT (voxel %g, %s)" % (args.ndt_voxel, args.ndt_nearby.upper())) if method < 0 else args.method.upper() + " ICP", shard, mode,
                                             ("open-scan pool of %d slots in %d lane(s), about %d steps in flight" % (pool_slots, lanes, depth)) if use_pool else "%d alignment(s) in flight" % depth),
                                 scans_per_gpu=B_local, map_points=args.map_points, scan_h2d_in_timed_region=not args.resident, pipeline_depth=depth,
                                 search_mode=dict(tree="tree_faithful_ann", tree_exact="tree_faithful_exact", grid="grid_exact")[args.search], tree_depth=tinfo["depth"],
@@ -654,7 +656,8 @@ def main():
                                        nominal_bytes_frac=round(a_gbs / HBM_PEAK_GBS, 5),
                                        note="frac at the nominal 2.4 GHz (the chip holds about 1.95 GHz under this load); about two thirds of the instructions are the plane fit; " + stage_src)
         if world == 1 and not args.no_cpu_baseline and args.search == "tree":
-            cb, cpu_poses = cpu_baseline(map_xyz, scans, inits, args.cpu_seconds, args.method)
+            cb, cpu_poses = cpu_baseline(map_xyz, scans, inits, args.cpu_seconds, args.method,
+                                         dict(voxel_size=args.ndt_voxel, nearby_type=(1 if args.ndt_nearby == "nearby6" else 0)))
             n = len(cpu_poses)
             d = np.linalg.norm(np.stack(cpu_poses)[:, 4:] - out_poses[:n, 4:], axis=1)
             cb["max_pose_delta_gpu_vs_cpu_m"] = float(d.max())

@@ -130,12 +130,18 @@ def inc_ndt_section(ctx, locref, reps):
     return out
 
 
-def stream_section(ctx, locref, n_scans, kf_every, num_kfs, scan_leaf, map_leaf, check, async_target=False):
-    """Lio::AddCloud (lio.cpp:206-306) with the matcher and the filters on the GPU; poses start from the perturbed truth."""
-    opts = api.icp_opts(api.P2PLANE)
+def stream_section(ctx, locref, n_scans, kf_every, num_kfs, scan_leaf, map_leaf, check, async_target=False, matcher="p2plane"):
+    """Lio::AddCloud (lio.cpp:206-306) with the matcher and the filters on the GPU; poses start from the perturbed truth.
+    matcher: p2plane (the rows of rounds 1-4), p2p (slam.yaml's lio_mapping default: matching_method 1, icp_option.method 0) or
+    ndt_inc_center (its NDT option block: incremental voxels, CENTER)."""
+    ndt = matcher == "ndt_inc_center"
+    opts = api.icp_opts(api.P2P if matcher == "p2p" else api.P2PLANE)
+    nopts = api.ndt_opts(method=api.INCREMENTAL_NDT, nearby_type=api.CENTER) if ndt else None
     sub = api.Submap(ctx, num_kfs, map_leaf)
     lm = locref.LocalMap(num_kfs, map_leaf, order=locref.SORT_STABLE) if check else None
-    icp_ref = locref.Icp(method=locref.P2PLANE) if check else None
+    icp_ref = None
+    if check:
+        icp_ref = locref.Ndt(method=locref.INCREMENTAL_NDT, nearby_type=locref.CENTER) if ndt else locref.Icp(method=(locref.P2P if matcher == "p2p" else locref.P2PLANE))
     stage = dict(gen=0.0, upload=0.0, filter=0.0, match=0.0, keyframe=0.0, target=0.0)
     poses, worst = [], 0.0
     raw, filt = api.Cloud(ctx), api.Cloud(ctx)
@@ -156,7 +162,7 @@ def stream_section(ctx, locref, n_scans, kf_every, num_kfs, scan_leaf, map_leaf,
             pose, kf_src, kf_dense = truth, filt, True  # first frame (lio.cpp:238-256): the FILTERED scan at last_kf_pose_ seeds the map
         else:
             t = clock()
-            pose, st = ctx.icp_align_cloud(filt, init, opts)
+            pose, st = ctx.ndt_align_cloud(filt, init) if ndt else ctx.icp_align_cloud(filt, init, opts)
             stage["match"] += clock() - t
             if check:
                 want = icp_ref.align(filt.download(), init)["pose"]
@@ -167,7 +173,10 @@ def stream_section(ctx, locref, n_scans, kf_every, num_kfs, scan_leaf, map_leaf,
             sub.add_keyframe(kf_src, pose)
             stage["keyframe"] += clock() - t
             t = clock()
-            ctx.icp_set_target_cloud(sub.cloud(), wait=not async_target)  # async: the host tree build runs under the next scan's upload + filter
+            if ndt:
+                ctx.ndt_set_target_cloud(sub.cloud(), nopts)
+            else:
+                ctx.icp_set_target_cloud(sub.cloud(), wait=not async_target)  # async: the host tree build runs under the next scan's upload + filter
             stage["target"] += clock() - t
             if check:
                 lm.add_keyframe(locref.transform_cloud_f64(pose, kf_src.download(), is_dense=kf_dense), is_dense=kf_dense)
