@@ -44,11 +44,15 @@ public:
 
     // Which GPU the matcher lives on (default 0). Not in the reference; must be called before SetInputTarget.
     void SetDevice(int device_id);
-    // Text of the last liblocgpu error (the reference only logs through glog).
+    // Text of the last liblocgpu error (the reference only logs through glog) — or, when the options name a branch of the reference
+    // that is not on the GPU path (IcpMethod::PCLICP, icp_registration.cpp:385-399; use_initial_translation_ = false, :273,311,351),
+    // the refusal: SetInputTarget, CaculateMatrixHAndB and ScanMatch then return false and touch nothing, instead of quietly running
+    // something else.
     const char* LastError() const;
 
 private:
     bool EnsureContext();
+    const char* Unsupported() const;  // nullptr when the options are on the GPU path
     IcpOptions options_;
     locgpu_ctx* ctx_ = nullptr;
     int device_id_ = 0;

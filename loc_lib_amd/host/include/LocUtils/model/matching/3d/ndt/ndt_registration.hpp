@@ -43,10 +43,13 @@ public:
     float GetFitnessScore() override;
 
     void SetDevice(int device_id);
+    // Text of the last liblocgpu error — or the refusal when the options name a branch that is not on the GPU path (NdtMethod::PCL_NDT,
+    // ndt_registration.cpp:69,246; remove_centroid_ = true, :380-384): SetInputTarget and ScanMatch then return false and touch nothing.
     const char* LastError() const;
 
 private:
     bool EnsureContext();
+    const char* Unsupported() const;  // nullptr when the options are on the GPU path
     NdtOptions options_;
     locgpu_ctx* ctx_ = nullptr;
     int device_id_ = 0;

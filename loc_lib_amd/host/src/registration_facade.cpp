@@ -48,18 +48,22 @@ IcpRegistration::IcpRegistration() {}
 IcpRegistration::IcpRegistration(IcpOptions options) : options_(options) {}
 IcpRegistration::~IcpRegistration() { locgpu_destroy(ctx_); }
 void IcpRegistration::SetDevice(int device_id) { device_id_ = device_id; }
-const char* IcpRegistration::LastError() const { return locgpu_last_error(ctx_); }
+const char* IcpRegistration::Unsupported() const {
+    if (options_.method_ == IcpMethod::PCLICP) return "IcpMethod::PCLICP (pcl::IterativeClosestPoint, icp_registration.cpp:385-399) is not on the GPU path: link PCL's ICP for it";
+    if (!options_.use_initial_translation_) return "IcpOptions::use_initial_translation_ = false (icp_registration.cpp:273,311,351: the centroid branch, whose centres the reference never computes) is not on the GPU path";
+    return nullptr;
+}
+const char* IcpRegistration::LastError() const { return Unsupported() ? Unsupported() : locgpu_last_error(ctx_); }
 bool IcpRegistration::EnsureContext() { return ctx_ || locgpu_create(device_id_, &ctx_) == LOCGPU_OK; }
 
 bool IcpRegistration::SetInputTarget(const CloudPtr& input_target) {
-    if (options_.method_ == IcpMethod::PCLICP || !input_target || !EnsureContext()) return false;
+    if (Unsupported() || !input_target || !EnsureContext()) return false;
     has_target_ = locgpu_icp_set_target(ctx_, input_target->points.data(), input_target->points.size(), sizeof(PointType)) == LOCGPU_OK;
     return true;  // the reference returns true whatever happened (icp_registration.cpp:28)
 }
 
 bool IcpRegistration::CaculateMatrixHAndB(const CloudPtr& input_source, const SE3& predict_pose, Mat6d& H, Vec6d& B) {
-    if (options_.method_ == IcpMethod::PCLICP) return true;  // `default: break; return true` (icp cpp:51-54)
-    if (!has_target_ || !input_source) return false;
+    if (Unsupported() || !has_target_ || !input_source) return false;
     const locgpu_icp_opts o = to_c(options_);
     double h[36], b[6];
     int ok = 0;
@@ -73,9 +77,10 @@ bool IcpRegistration::CaculateMatrixHAndB(const CloudPtr& input_source, const SE
 }
 
 bool IcpRegistration::ScanMatch(const CloudPtr& input_source, const SE3& predict_pose, CloudPtr& result_cloud_ptr, SE3& result_pose) {
+    if (Unsupported()) return false;  // a refusal, loudly (LastError): neither result_pose nor the output cloud is touched
     if (!input_source) return true;
     SE3 pose = predict_pose;
-    if (has_target_ && options_.method_ != IcpMethod::PCLICP && !input_source->points.empty()) {
+    if (has_target_ && !input_source->points.empty()) {
         const locgpu_icp_opts o = to_c(options_);
         double out[7];
         if (locgpu_icp_align(ctx_, input_source->points.data(), input_source->points.size(), sizeof(PointType), predict_pose.data(), &o, out,
@@ -94,11 +99,17 @@ NdtRegistration::NdtRegistration() { options_.inv_voxel_size_ = 1.0 / options_.v
 NdtRegistration::NdtRegistration(NdtOptions options) : options_(options) { options_.inv_voxel_size_ = 1.0 / options_.voxel_size_; }
 NdtRegistration::~NdtRegistration() { locgpu_destroy(ctx_); }
 void NdtRegistration::SetDevice(int device_id) { device_id_ = device_id; }
-const char* NdtRegistration::LastError() const { return locgpu_last_error(ctx_); }
+const char* NdtRegistration::Unsupported() const {
+    if (options_.method_ == NdtMethod::PCL_NDT) return "NdtMethod::PCL_NDT (pcl::NormalDistributionsTransform, ndt_registration.cpp:69,246) is not on the GPU path: link PCL's NDT for it";
+    if (options_.remove_centroid_) return "NdtOptions::remove_centroid_ = true (ndt_registration.cpp:380-384) is not on the GPU path";
+    return nullptr;
+}
+const char* NdtRegistration::LastError() const { return Unsupported() ? Unsupported() : locgpu_last_error(ctx_); }
 bool NdtRegistration::EnsureContext() { return ctx_ || locgpu_create(device_id_, &ctx_) == LOCGPU_OK; }
 
 bool NdtRegistration::SetInputTarget(const CloudPtr& input_target) {
-    if (options_.method_ == NdtMethod::PCL_NDT || !input_target || !EnsureContext()) return true;  // ndt cpp:67-83 always true
+    if (Unsupported()) return false;
+    if (!input_target || !EnsureContext()) return true;  // ndt cpp:67-83 always true
     locgpu_ndt_opts o;
     locgpu_ndt_opts_default(&o);
     o.max_iteration = options_.max_iteration_;
@@ -117,8 +128,9 @@ bool NdtRegistration::SetInputTarget(const CloudPtr& input_target) {
 bool NdtRegistration::CaculateMatrixHAndB(const CloudPtr&, const SE3&, Mat6d&, Vec6d&) { return true; }  // empty body in the reference (ndt cpp:43-49)
 
 bool NdtRegistration::ScanMatch(const CloudPtr& input_source, const SE3& predict_pose, CloudPtr& result_cloud_ptr, SE3& result_pose) {
+    if (Unsupported()) return false;  // a refusal, loudly (LastError): neither result_pose nor the output cloud is touched
     if (!input_source) return true;
-    if (has_target_ && options_.method_ != NdtMethod::PCL_NDT && !input_source->points.empty()) {
+    if (has_target_ && !input_source->points.empty()) {
         double out[7];
         locgpu_align_stats st;
         if (locgpu_ndt_align(ctx_, input_source->points.data(), input_source->points.size(), sizeof(PointType), predict_pose.data(), out, &st) ==

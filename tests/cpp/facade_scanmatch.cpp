@@ -52,7 +52,35 @@ static int run_loam(char** argv) {
     return 0;
 }
 
+// refusals mode (no GPU needed: a refusal comes before any context exists): option branches of the reference that are not on the GPU
+// path make SetInputTarget / ScanMatch return false with a text in LastError() and leave the outputs alone — they are not quietly
+// served by something else. facade_scanmatch refusals
+static int run_refusals() {
+    CloudPtr cloud(new PointCloudType);
+    cloud->points.resize(8);
+    CloudPtr out(new PointCloudType);
+    out->points.resize(3);
+    int bad = 0;
+    auto check = [&](MatchingInterface& m, const char* err, const char* what) {
+        SE3 predict, result;
+        for (int i = 0; i < 7; ++i) { predict.data()[i] = 0.125 * (i + 1); result.data()[i] = -1.0 - i; }
+        const bool a = m.SetInputTarget(cloud);
+        const bool b = m.ScanMatch(cloud, predict, out, result);
+        bool untouched = out->points.size() == 3;
+        for (int i = 0; i < 7; ++i) untouched = untouched && result.data()[i] == -1.0 - i;
+        const bool ok = !a && !b && untouched && err && std::strstr(err, what);
+        std::printf("%s: SetInputTarget %d ScanMatch %d outputs untouched %d LastError \"%s\"\n", what, (int)a, (int)b, (int)untouched, err ? err : "");
+        bad += ok ? 0 : 1;
+    };
+    { IcpOptions o(IcpMethod::PCLICP); IcpRegistration m(o); check(m, m.LastError(), "PCLICP"); }
+    { IcpOptions o(IcpMethod::P2PLANE); o.use_initial_translation_ = false; IcpRegistration m(o); check(m, m.LastError(), "use_initial_translation_"); }
+    { NdtOptions o; o.method_ = NdtMethod::PCL_NDT; NdtRegistration m(o); check(m, m.LastError(), "PCL_NDT"); }
+    { NdtOptions o; o.remove_centroid_ = true; NdtRegistration m(o); check(m, m.LastError(), "remove_centroid_"); }
+    return bad ? 5 : 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc == 2 && std::string(argv[1]) == "refusals") return run_refusals();
     if (argc == 8 && std::string(argv[1]) == "loam") return run_loam(argv);
     if (argc != 7) { std::fprintf(stderr, "usage\n"); return 2; }
     const std::string kind = argv[1];

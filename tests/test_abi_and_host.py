@@ -356,3 +356,17 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                          timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert out.returncode != 0 and "--gpus 8 but WORLD_SIZE=1" in out.stderr, out.stderr[-800:]
+
+
+def test_facade_refuses_the_option_branches_that_are_not_on_the_gpu_path():
+    """VERDICT r4: IcpMethod::PCLICP (icp_registration.cpp:385-399), NdtMethod::PCL_NDT (ndt_registration.cpp:69,246),
+    IcpOptions::use_initial_translation_ = false (:273,311,351) and NdtOptions::remove_centroid_ = true (:380-384) used to be ignored by
+    the façade. Now SetInputTarget and ScanMatch return false, LastError() says why, and neither the pose nor the output cloud is
+    touched. A refusal needs no GPU (it comes before a context exists), so this runs in the CPU suite."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "facade_scanmatch")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "loc_lib_amd", "host"), "../../tests/cpp/facade_scanmatch"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([exe, "refusals"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for what in ("PCLICP", "use_initial_translation_", "PCL_NDT", "remove_centroid_"):
+        assert what + ": SetInputTarget 0 ScanMatch 0 outputs untouched 1" in r.stdout, r.stdout

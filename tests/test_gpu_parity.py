@@ -176,6 +176,25 @@ def test_icp_align_matches_oracle(gpu_ctx, api, locref, small_world, method):
     assert dt < 1e-8 and dr < 1e-8  # what we actually expect: summation-order noise only
 
 
+def test_configs0_at_its_exact_size(gpu_ctx, api, locref, synth):
+    """BASELINE.json configs[0] as written — a single 10 k-pt synthetic scan vs the 100 k-pt map (synth.make_map(100000): the whole
+    ±150 m world at 100 k points, not a dense local crop), reference-default point-to-plane ICP through the single-scan host-pointer
+    entry point — for a few scans of the circuit: pose within the north-star tolerance of the oracle, equal iteration counts."""
+    m = synth.make_map(100000)
+    gpu_ctx.icp_set_target(m)
+    icp = locref.Icp(method=locref.P2PLANE)
+    icp.set_target(m)
+    opts = api.icp_opts(method=api.P2PLANE)
+    for sid in (0, 7, 100):
+        s = synth.make_scan(sid, subsample=10000)
+        _, init = synth.make_pose(sid)
+        pg, st = gpu_ctx.icp_align(s, init, opts)
+        ro = icp.align(s, init)
+        dt, dr = pose_delta(pg, ro["pose"])
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (sid, dt, dr)
+        assert st["iterations"] == ro["iters"], (sid, st, ro["iters"])
+
+
 def test_icp_align_nonconverging_runs_max_iterations(gpu_ctx, api, locref, small_world):
     m, s, init = small_world["map"], small_world["scan2k"], small_world["init_pose"]
     gpu_ctx.icp_set_target(m)
