@@ -272,7 +272,7 @@ int locgpu_submap_add_keyframe(locgpu_submap* m, const locgpu_cloud* scan, const
     locgpu_ctx* ctx = m->ctx;
     if (!scan || !scan->ctx) return fail(ctx, LOCGPU_ERR_INVALID, "submap_add_keyframe: bad cloud");
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
-    if (cloud_input_ready(ctx, scan) != hipSuccess) return fail(ctx, LOCGPU_ERR_INVALID, "submap_add_keyframe: the cloud belongs to a context on another GPU");
+    { const hipError_t ce = cloud_input_ready(ctx, scan); if (ce == hipErrorInvalidDevice) return fail(ctx, LOCGPU_ERR_INVALID, "submap_add_keyframe: the cloud belongs to a context on another GPU"); if (!hip_ok(ctx, ce, "submap_add_keyframe: ordering behind the cloud's context")) return LOCGPU_ERR_NO_DEVICE; }
     // key_frame_scan = transformPointCloud(scan, pose.matrix())   lio.cpp:278-279
     locgpu_cloud* kf = new_cloud(ctx);
     hipError_t e;

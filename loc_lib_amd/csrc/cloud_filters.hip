@@ -402,10 +402,15 @@ hipError_t cloud_mark_ready(locgpu_cloud* c) {
     return hipEventRecord(c->ready, c->ctx->stream);
 }
 
+// hipErrorInvalidDevice: the cloud lives on another GPU (the caller's refusal); any other error is HIP's own.
+// Consumers only READ the cloud, and every entry point that takes a foreign cloud returns with its stream synchronised (the align
+// calls and locgpu_submap_add_keyframe are blocking), so the owner's later writes cannot overtake them; a non-blocking consumer would
+// have to record an event here for the owner to wait on.
 hipError_t cloud_input_ready(locgpu_ctx* ctx, const locgpu_cloud* c) {
     if (!c || !c->ctx) return hipErrorInvalidValue;
     if (c->ctx == ctx) return hipSuccess;
-    if (c->ctx->device != ctx->device) return hipErrorInvalidValue;
+    if (c->ctx->device != ctx->device) return hipErrorInvalidDevice;
+    LOCGPU_TRY(hipSetDevice(ctx->device));  // the fallback event below must be created on the consumer's device
     // behind the call that produced the cloud — not behind whatever its owner has enqueued since (a filter stage running a scan
     // ahead would otherwise hold the matcher back: the two stages would take turns instead of overlapping)
     if (c->ready) return hipStreamWaitEvent(ctx->stream, c->ready, 0);

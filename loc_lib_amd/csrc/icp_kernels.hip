@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
 // The deep pass: the same traversal with EVERY level stored (T = 0, D + 2 rows) over the list of queries whose un-stored top
 // levels could not be resolved from two candidates (≈1e-3 of them at 15 rows). One-wave workgroups, grid-stride over the list
 // whose length lives on the device.
-template <int K, int D>
+template <int K, int D, int LANES = 64>
 __global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                                   const PoseState* __restrict__ st, uint32_t* __restrict__ nn, size_t nn_pitch, int max_n,
                                                                   float alpha_eff, unsigned int tree_bytes, uint32_t dummy, const uint32_t* __restrict__ list,
@@ -178,14 +178,16 @@ __global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* _
                                                                   unsigned int* __restrict__ redo_count, unsigned long long* __restrict__ search_stats,
                                                                   const int* __restrict__ src_of) {
     extern __shared__ uint2 s_dyn[];
-    constexpr int ROWB = 64 * 8;
+    constexpr int ROWB = LANES * 8;
+    static_assert((D + 2) * ROWB >= 64 * 2 * 8, "exact stack columns do not fit");
     if ((uint32_t)(size_t)s_dyn != 0u) __builtin_trap();  // see icp_search_walk_kernel
     const unsigned int n = *n_list;
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0 && search_stats) atomicAdd(&search_stats[2], (unsigned long long)n);
+    if (tid >= LANES) return;  // LANES stack columns per wave (see icp_search_walk_kernel)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
     // a short list is spread thin: these are the long traversals, and a wave's time is the longest among its lanes
-    const unsigned int per_wave = min(64u, max(1u, (n + gridDim.x - 1) / gridDim.x));
+    const unsigned int per_wave = min((unsigned int)LANES, max(1u, (n + gridDim.x - 1) / gridDim.x));
     for (unsigned int r0 = blockIdx.x * per_wave; r0 < n; r0 += gridDim.x * per_wave) {
         const unsigned int r = r0 + (unsigned int)tid;
         const bool valid = (unsigned int)tid < per_wave && r < n;
@@ -213,7 +215,10 @@ __global__ __launch_bounds__(64) void icp_search_walk_list_kernel(const uint2* _
 // One-wave workgroups over the list. A short list is dealt one query per WAVE (lane 0): 30 queries sharing a wave would each
 // pay the others' heap-emulation branches and the longest traversal; alone in its wave a query costs its own ≈40 dependent loads.
 // A long list (a lattice map: every distance ties) fills all 64 lanes of every wave.
-constexpr int kRedoWaves = 2048, kDeepWaves = 2048;
+constexpr int kRedoWaves = 2048;
+// The deep pass: full waves, 2048 of them (16 lanes to a wave on 8192 waves — a wave's time is the longest traversal among its lanes,
+// and these are the long ones — was measured: search 17.25 → 17.47 ms per 256-scan step; the pass is issue-bound like the walk kernel)
+constexpr int kDeepLanes = 64, kDeepWaves = 2048;
 template <int KMAX, int D>
 __global__ __launch_bounds__(64) void icp_search_redo_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                              const PoseState* __restrict__ st, uint32_t* __restrict__ nn, size_t nn_pitch,
@@ -577,22 +582,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 }
 
 // Sum of the block partials of one scan, per column, in a fixed order (chunk c takes rows c, c + 8, …; the chunks are then added in
-// order). Eight loads are in flight per thread: a single-scan alignment has 450 rows, and a row-by-row load → add chain made this the
+// order). Many loads are in flight per thread: a single-scan alignment has 450 rows, and a row-by-row load → add chain made this the
 // longest part of the solve kernel. Returns the column total in threads 0..kAccW-1 (0 elsewhere). Ends with the block synchronised.
 __device__ __forceinline__ double reduce_partials(const double* __restrict__ rows, int blocks_per_scan, bool mine, double (*s_sum)[kAccW]) {
     const int col = threadIdx.x & (kAccW - 1), chunk = threadIdx.x / kAccW;
     constexpr int kChunks = kBlock / kAccW;
     double s = 0.0;
     if (mine && col < 28) {
-        for (int b = chunk; b < blocks_per_scan; b += kChunks * 8) {
-            double v[8];
+        constexpr int kFlight = 32;  // loads in flight per thread (round 5: 8 → 32: a one-scan alignment's 450 rows are two rounds instead of seven; the order of the sums — row after row within a chunk — is unchanged, so are the bits)
+        for (int b = chunk; b < blocks_per_scan; b += kChunks * kFlight) {
+            double v[kFlight];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < kFlight; ++u) {
                 const int idx = b + u * kChunks;
                 v[u] = idx < blocks_per_scan ? rows[(size_t)idx * kAccW + col] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+            for (int u = 0; u < kFlight; ++u) s += v[u];
         }
     }
     s_sum[chunk][col] = s;
@@ -779,7 +785,7 @@ static bool no_static_lds() {
 template <int K, int D>
 static bool walk_kernels_ok_kd() {
     return no_static_lds<icp_search_walk_kernel<K, 12>>() && no_static_lds<icp_search_walk_kernel<K, 15>>() && no_static_lds<icp_search_walk_kernel<K, 24>>() &&
-           no_static_lds<icp_search_walk_kernel<K, D + 2, 16>>() && no_static_lds<icp_search_walk_list_kernel<K, D>>();
+           no_static_lds<icp_search_walk_kernel<K, D + 2, 16>>() && no_static_lds<icp_search_walk_list_kernel<K, D, kDeepLanes>>();
 }
 bool search_kernels_lds_ok() {
     static const bool ok = walk_kernels_ok_kd<1, 32>() && walk_kernels_ok_kd<1, 40>() && walk_kernels_ok_kd<1, 64>() &&
@@ -817,7 +823,7 @@ static bool launch_walk_kd(const SearchArgs& a, hipStream_t s) {
                            a.alpha_eff, Tw, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of);
     // 2048 one-wave blocks of 17 KB LDS are all resident at once (nine fit a CU): the first iteration's ≈140 k deep queries take one
     // traversal per wave instead of two or three in sequence (search 18.07 → 17.80 ms per 256-scan step; 4608: 17.96)
-    hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(kDeepWaves), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
+    hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D, kDeepLanes>), dim3(kDeepWaves), dim3(64), (D + 2) * kDeepLanes * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,
                        a.alpha_eff, rsrc_bytes, dummy, a.redo_list2, a.redo_count2, a.redo_list, a.redo_count, a.search_stats, a.src_of);
     hipLaunchKernelGGL((icp_search_redo_kernel<K, D>), dim3(kRedoWaves), dim3(64), 0, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, a.k,
                        a.alpha_eff, a.redo_list, a.redo_count, a.search_stats, a.src_of);
@@ -862,7 +868,7 @@ template <int K>
 static bool launch_walk_list_k(const SearchArgs& a, const uint32_t* list, const unsigned int* n_list, hipStream_t s) {
     const uint32_t dummy = (uint32_t)(a.tree_bytes / 8);
     const unsigned int rsrc_bytes = (unsigned int)a.tree_bytes + 16u;
-#define LOCGPU_LIST(D) hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D>), dim3(kDeepWaves), dim3(64), (D + 2) * 64 * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, \
+#define LOCGPU_LIST(D) hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D, kDeepLanes>), dim3(kDeepWaves), dim3(64), (D + 2) * kDeepLanes * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n, \
                                           a.alpha_eff, rsrc_bytes, dummy, list, n_list, a.redo_list, a.redo_count, a.search_stats, a.src_of)
     if (a.depth <= 32) LOCGPU_LIST(32);
     else if (a.depth <= 40) LOCGPU_LIST(40);

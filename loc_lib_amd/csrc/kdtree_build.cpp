@@ -16,8 +16,31 @@
 // A 16-byte load at a leaf's slot therefore returns the whole point.
 #include "kdtree_build.hpp"
 
-#include <immintrin.h>
 #include <unistd.h>
+#if defined(__SSE2__) && !defined(LOCGPU_SCALAR_VEC)
+#include <immintrin.h>
+#else
+// No SSE (an aarch64 host; or -DLOCGPU_SCALAR_VEC: the CPU suite builds this branch too): the handful of intrinsics below, lane by
+// lane. The reference's sums are scalar float32 adds in index order (math_utils.h:40-45); an SSE lane does exactly that, and so does
+// this — the tree is the same tree.
+#include <cstdint>
+#include <cstring>
+struct alignas(16) __m128 { float v[4]; };
+struct alignas(16) __m128i { int32_t v[4]; };
+static inline __m128 _mm_setzero_ps() { return __m128{{0.f, 0.f, 0.f, 0.f}}; }
+static inline __m128 _mm_set1_ps(float a) { return __m128{{a, a, a, a}}; }
+static inline __m128 _mm_load_ps(const float* p) { __m128 r; std::memcpy(r.v, p, 16); return r; }
+static inline void _mm_store_ps(float* p, __m128 a) { std::memcpy(p, a.v, 16); }
+#define LOCGPU_LANEWISE(name, op) static inline __m128 name(__m128 a, __m128 b) { __m128 r; for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] op b.v[i]; return r; }
+LOCGPU_LANEWISE(_mm_add_ps, +) LOCGPU_LANEWISE(_mm_sub_ps, -) LOCGPU_LANEWISE(_mm_mul_ps, *) LOCGPU_LANEWISE(_mm_div_ps, /)
+#undef LOCGPU_LANEWISE
+static inline __m128i _mm_set_epi32(int e3, int e2, int e1, int e0) { return __m128i{{e0, e1, e2, e3}}; }
+static inline __m128i _mm_set1_epi32(int a) { return __m128i{{a, a, a, a}}; }
+static inline __m128 _mm_castsi128_ps(__m128i a) { __m128 r; std::memcpy(r.v, a.v, 16); return r; }
+static inline __m128 _mm_and_ps(__m128 a, __m128 b) { uint32_t x[4], y[4]; std::memcpy(x, a.v, 16); std::memcpy(y, b.v, 16); for (int i = 0; i < 4; ++i) x[i] &= y[i]; __m128 r; std::memcpy(r.v, x, 16); return r; }
+static inline __m128 _mm_andnot_ps(__m128 a, __m128 b) { uint32_t x[4], y[4]; std::memcpy(x, a.v, 16); std::memcpy(y, b.v, 16); for (int i = 0; i < 4; ++i) x[i] = ~x[i] & y[i]; __m128 r; std::memcpy(r.v, x, 16); return r; }
+static inline void _mm_pause() {}
+#endif
 
 #include <algorithm>
 #include <atomic>

@@ -75,7 +75,7 @@ std::string g_create_err;
 // GN iterations enqueued between two host reads of the convergence flags. Kernels of a finished scan return at once (device-side
 // `done` flag), so running ahead costs ≈2 µs per empty launch while a host round trip costs tens of µs: the first chunk covers the
 // typical alignment (7-8 iterations with the reference's eps), later ones are shorter.
-constexpr int kFirstChunk = 8, kNextChunk = 4;
+constexpr int kFirstChunk = 8, kNextChunk = 4, kLongFirstChunk = 12;
 // A one-scan alignment follows its first chunk with chunks of two: there a chunk boundary (read-back, host, relaunch ≈ 35 µs) costs
 // about what two idle iterations do (3 dispatches of ≈4.6 µs each), and nine iterations — the common case beyond eight — then pay
 // 35 + 15 µs instead of 35 + 45 (tools/single_scan_trace.py).
@@ -87,7 +87,8 @@ inline const float4* batch_src(const locgpu_batch* b) { return b->d_src_ext ? b-
 // changes a result (the same kernels run on the same data in the same order), only where the host looks at the flags.
 inline int first_chunk_len(const locgpu_batch* b) {
     if (b->n_total != 1 || b->sharded || b->last_iterations < 0) return kFirstChunk;
-    return std::min(kFirstChunk, std::max(3, b->last_iterations + 1));
+    // ... up to kLongFirstChunk when the last call needed more than eight: a chunk boundary there cost 33 µs + two idle iterations (round 5)
+    return std::min(kLongFirstChunk, std::max(3, b->last_iterations + 1));
 }
 }  // namespace
 
@@ -1457,7 +1458,15 @@ static int ndt_set_target_dev(locgpu_ctx* ctx, const float4* d_pts, const float4
         if (!ctx->inc) ctx->inc = inc_ndt_create((size_t)o.capacity, o.voxel_size);
         bool bad = false;
         const hipError_t e = inc_ndt_ingest(*ctx->inc, host, d_pts, n, ctx->stream, &bad);
-        if (e != hipSuccess) { hip_ok(ctx, e, "inc_ndt_ingest"); return LOCGPU_ERR_NO_DEVICE; }
+        if (e != hipSuccess) {
+            // an ingest that failed half way (its counters, slot arrays, free stack and table may disagree): the voxel set is gone,
+            // the next SetInputTarget starts from an empty one
+            (void)hipStreamSynchronize(ctx->stream);
+            inc_ndt_destroy(ctx->inc);
+            ctx->inc = nullptr;
+            hip_ok(ctx, e, "inc_ndt_ingest");
+            return LOCGPU_ERR_NO_DEVICE;
+        }
         ctx->ndt_opts = o;
         ctx->target_epoch++;
         if (bad) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_set_target: a point lies outside the +-2^20-voxel key range (it was skipped)");
@@ -1600,7 +1609,7 @@ int locgpu_icp_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const doubl
     int rc = check_icp(ctx, opts, prm, k, alpha_eff);
     if (rc != LOCGPU_OK) return rc;
     if (!src || !src->ctx || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "icp_align_cloud: bad arguments");
-    if (cloud_input_ready(ctx, src) != hipSuccess) return fail(ctx, LOCGPU_ERR_INVALID, "icp_align_cloud: the cloud belongs to a context on another GPU");
+    { const hipError_t ce = cloud_input_ready(ctx, src); if (ce == hipErrorInvalidDevice) return fail(ctx, LOCGPU_ERR_INVALID, "icp_align_cloud: the cloud belongs to a context on another GPU"); if (!hip_ok(ctx, ce, "icp_align_cloud: ordering behind the cloud's context")) return LOCGPU_ERR_NO_DEVICE; }
     locgpu_batch* b = nullptr;
     rc = single_batch_dev(ctx, src->d, src->n, &b);
     if (rc != LOCGPU_OK) return rc;
@@ -1612,7 +1621,7 @@ int locgpu_ndt_align_cloud(locgpu_ctx* ctx, const locgpu_cloud* src, const doubl
     int rc = check_ndt(ctx, prm);
     if (rc != LOCGPU_OK) return rc;
     if (!src || !src->ctx || !init_pose || !out_pose) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_cloud: bad arguments");
-    if (cloud_input_ready(ctx, src) != hipSuccess) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_cloud: the cloud belongs to a context on another GPU");
+    { const hipError_t ce = cloud_input_ready(ctx, src); if (ce == hipErrorInvalidDevice) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_align_cloud: the cloud belongs to a context on another GPU"); if (!hip_ok(ctx, ce, "ndt_align_cloud: ordering behind the cloud's context")) return LOCGPU_ERR_NO_DEVICE; }
     locgpu_batch* b = nullptr;
     rc = single_batch_dev(ctx, src->d, src->n, &b);
     if (rc != LOCGPU_OK) return rc;

@@ -538,7 +538,10 @@ static hipError_t ingest_replayed(IncNdtState& st, const float4* host_pts, const
         if (h_key[sl] != kNdtEmpty) live.push_back(IncLive{h_key[sl], h_stamp[sl], (int)sl});
     std::vector<uint64_t> keys(n);
     for (size_t i = 0; i < n; ++i) {
-        const int kx = (int)((double)host_pts[i].x * st.inv_voxel), ky = (int)((double)host_pts[i].y * st.inv_voxel), kz = (int)((double)host_pts[i].z * st.inv_voxel);
+        // the conversion the device's inc_key_kernel performs (v_cvt_i32_f64: NaN → 0, saturating) — `(int)` of such a value is
+        // undefined on the host, and the two paths must key a point alike
+        auto cvt = [](double v) { return v != v ? 0 : (v >= 2147483647.0 ? 2147483647 : (v <= -2147483648.0 ? (-2147483647 - 1) : (int)v)); };
+        const int kx = cvt((double)host_pts[i].x * st.inv_voxel), ky = cvt((double)host_pts[i].y * st.inv_voxel), kz = cvt((double)host_pts[i].z * st.inv_voxel);
         keys[i] = ndt_key_in_range(kx, ky, kz) ? ndt_pack(kx, ky, kz) : kIncNoKey;
     }
     std::vector<unsigned char> keep;

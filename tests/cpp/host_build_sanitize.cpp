@@ -9,6 +9,7 @@
 #include "kdtree_build.hpp"
 int main() {
     std::mt19937 rng(7);
+    uint64_t sum = 1469598103934665603ull;  // FNV-1a over every tree's slots: two builds of the builder (SSE / lane-by-lane) must print the same
     for (int trial = 0; trial < 40; ++trial) {
         size_t n = trial < 5 ? (size_t)trial + 1 : (size_t)(rng() % 200000) + 1;
         std::vector<float> xyz(3 * n);
@@ -20,7 +21,9 @@ int main() {
         if (!locgpu::build_packed_kdtree(xyz.data(), n, t, err)) { std::printf("build failed: %s\n", err.c_str()); return 1; }
         if (t.leaf_slots.size() != t.num_leaves) { std::printf("leaf list mismatch\n"); return 1; }
         for (uint32_t sl : t.leaf_slots) if (((uint32_t)(t.slots[sl] >> 32) >> 30) != 3u) { std::printf("leaf list points at a non-leaf\n"); return 1; }
+        for (uint64_t w : t.slots) { sum ^= w; sum *= 1099511628211ull; }
     }
+    std::printf("tree checksum %016llx\n", (unsigned long long)sum);
     std::puts("asan harness ok");
     return 0;
 }

@@ -370,3 +370,20 @@ def test_facade_refuses_the_option_branches_that_are_not_on_the_gpu_path():
     assert r.returncode == 0, r.stdout + r.stderr
     for what in ("PCLICP", "use_initial_translation_", "PCL_NDT", "remove_centroid_"):
         assert what + ": SetInputTarget 0 ScanMatch 0 outputs untouched 1" in r.stdout, r.stdout
+
+
+def test_host_tree_build_without_sse_builds_the_same_trees(tmp_path):
+    """ADVICE r4: kdtree_build.cpp used SSE intrinsics unconditionally. The lane-by-lane fallback (what an aarch64 host compiles;
+    forced here with -DLOCGPU_SCALAR_VEC) must build bit-identical trees: forty clouds, one checksum over all their slots."""
+    import subprocess
+    csrc = os.path.join(ROOT, "loc_lib_amd", "csrc")
+    sums = []
+    for tag, extra in (("sse", []), ("scalar", ["-DLOCGPU_SCALAR_VEC"])):
+        exe = str(tmp_path / ("host_build_" + tag))
+        cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I", csrc] + extra + [os.path.join(ROOT, "tests", "cpp", "host_build_sanitize.cpp"),
+               os.path.join(csrc, "kdtree_build.cpp"), "-o", exe, "-pthread"]
+        subprocess.check_call(cmd)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "asan harness ok" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+        sums.append([ln for ln in r.stdout.splitlines() if ln.startswith("tree checksum")][0])
+    assert sums[0] == sums[1], sums
