@@ -36,7 +36,7 @@ def row_from_bench(name, j):
                 cpu_cores=r3.get("cores"), gpu_scans_s=j["value"], ms_per_step=j["ms_per_step"], scan_h2d_in_timed_region=cfg.get("scan_h2d_in_timed_region"),
                 search_hbm_frac=(j.get("roofline") or {}).get("hbm_frac"),
                 gpu_iter_ms_per_scan=j.get("icp_iter_ms_per_scan"), gn_iterations_per_scan=j.get("gn_iterations_per_scan"),
-                search_roofline_frac=(j.get("roofline") or {}).get("frac"), traffic_bytes=(j.get("roofline") or {}).get("traffic"),
+                search_roofline_frac=(j.get("roofline") or {}).get("frac"), nominal_bytes_frac=(j.get("roofline") or {}).get("nominal_bytes_frac"), traffic_bytes=(j.get("roofline") or {}).get("traffic"),
                 pose_delta_m=cb.get("max_pose_delta_gpu_vs_cpu_m"), gpu_over_cpu=cb.get("gpu_over_cpu"))
 
 
@@ -81,14 +81,20 @@ def main():
     rows.append(row_from_bench("2: 115200-pt scans vs 1M-pt map, P2Plane (64 scans per step)", run_bench("--map-points", "1000000", "--scans-per-gpu", "64", "--traffic", "none", *steps)))
     rows.append(row_from_bench("3a: vs 10M-pt map, P2Plane (64 scans per step)", run_bench("--scans-per-gpu", "64", "--traffic", "none", *steps)))
     rows.append(row_from_bench("3b: vs 10M-pt map, direct NDT (64 scans per step)", run_bench("--scans-per-gpu", "64", "--method", "ndt", "--traffic", "none", *steps)))
-    rows.append(row_from_bench("3c: vs 10M-pt map, P2Plane (32 scans per step: what one of eight ranks holds of configs[3])", run_bench("--scans-per-gpu", "32", "--traffic", "none", *steps)))
+    small = ["--steps", "12", "--warmup", "2"] if a.quick else ["--steps", "80", "--warmup", "8"]
+    rows.append(row_from_bench("3c: vs 10M-pt map, P2Plane (32 scans per step: what one of eight ranks holds of configs[3]) — through the open-scan pool (the default for small steps)",
+                               run_bench("--scans-per-gpu", "32", "--traffic", "none", *small)))
+    rows.append(row_from_bench("3c': the same as plain batches, three alignments in flight (rounds 1-4)", run_bench("--scans-per-gpu", "32", "--pool-slots", "0", "--no-cpu-baseline", "--traffic", "none", *small)))
     rows.append(row_from_bench("4: 256 scans vs 10M-pt map, P2Plane, one GPU (the default bench line: three alignments in flight)", run_bench(*steps)))
     fast = ["--no-cpu-baseline", "--traffic", "none"]
     rows.append(row_from_bench("4p: the same with one alignment at a time (--pipeline 1)", run_bench("--pipeline", "1", *fast, *steps)))
     rows.append(row_from_bench("4q: the same with two alignments in flight (--pipeline 2)", run_bench("--pipeline", "2", *fast, *steps)))
     for n in (256, 64, 32):
-        rows.append(row_from_bench("4s: configs[3] as written on ONE rank: %d scans in all, sharded batch, RCCL all-reduce every iteration" % n,
-                                   run_bench("--scaling", "strong", "--total-scans", str(n), *fast, "--steps", str(max(10, 640 // n)), "--warmup", "2")))
+        rows.append(row_from_bench("4s: configs[3] as written on ONE rank: %d scans in all, RCCL all-reduce every iteration%s" % (n, "" if n == 256 else " — open-scan pool"),
+                                   run_bench("--scaling", "strong", "--total-scans", str(n), *fast, "--steps", str(max(10, 2560 // n)), "--warmup", "4")))
+        if n != 256:
+            rows.append(row_from_bench("4s': %d scans in all as plain sharded batches, three alignments in flight (rounds 1-4)" % n,
+                                       run_bench("--scaling", "strong", "--total-scans", str(n), "--pool-slots", "0", *fast, "--steps", str(max(10, 2560 // n)), "--warmup", "4")))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "perf", "pipeline_microbench.py"), "--only", "stream"], capture_output=True, text=True, timeout=900)
     st = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])["stream"]
     rows.append(dict(config="5: streaming loop (upload, removeNaN, voxel filter, P2Plane vs local map, keyframe every 5th: submap + re-ingest with the tree built on a worker thread)",
@@ -96,13 +102,13 @@ def main():
                      gpu_scans_s_blocking_target=st.get("blocking_target", {}).get("scans_per_s")))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(dict(rows=rows, host_threads=os.cpu_count(), usable_cores=len(os.sched_getaffinity(0))), open(a.out, "w"), indent=1)
-    print("| config | CPU R1 scans/s (1 thread) | CPU R2 scans/s (1 thread) | CPU R3 scans/s (cores) | GPU×1 scans/s | GPU ms per scan-iteration | search roofline frac (algorithmic / HBM traffic) | pose Δ vs oracle [m] |")
+    print("| config | CPU R1 scans/s (1 thread) | CPU R2 scans/s (1 thread) | CPU R3 scans/s (cores) | GPU×1 scans/s | GPU ms per scan-iteration | dominant kernel: VALU issue frac / nominal-bytes frac / HBM frac | pose Δ vs oracle [m] |")
     print("|---|---|---|---|---|---|---|---|")
     f = lambda v, p="%.3g": "—" if v is None else p % v
     for r in rows:
         print("| %s | %s | %s | %s | %s | %s | %s / %s | %s |" % (r["config"], f(r.get("cpu_r1_scans_s")), f(r.get("cpu_r2_scans_s")),
               ("%s (%s)" % (f(r.get("cpu_r3_scans_s")), r.get("cpu_cores"))) if r.get("cpu_r3_scans_s") else "—", f(r.get("gpu_scans_s"), "%.4g"),
-              f(r.get("gpu_iter_ms_per_scan")), f(r.get("search_roofline_frac")), f(r.get("search_hbm_frac")), f(r.get("pose_delta_m"), "%.1e")))
+              f(r.get("gpu_iter_ms_per_scan")), f(r.get("search_roofline_frac")) + " / " + f(r.get("nominal_bytes_frac")), f(r.get("search_hbm_frac")), f(r.get("pose_delta_m"), "%.1e")))
 
 
 if __name__ == "__main__":

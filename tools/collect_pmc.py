@@ -27,10 +27,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
     ap.add_argument("--scans", type=int, default=64)
+    ap.add_argument("--method", default="p2plane", help="bench.py --method (ndt: the direct-NDT accumulate kernel)")
     a = ap.parse_args()
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    cmd_tail = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--resident", "--no-cpu-baseline", "--traffic", "none",
-                "--scans-per-gpu", str(a.scans)]
+    cmd_tail = [os.path.realpath(sys.executable), os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--resident", "--no-cpu-baseline", "--traffic", "none",
+                "--scans-per-gpu", str(a.scans), "--method", a.method]
     for counters in PASSES:
         d = tempfile.mkdtemp(prefix="locgpu_pmc_", dir="/tmp")
         try:
@@ -42,8 +43,8 @@ def main():
                     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    keep = [k for k in agg if any(s in k for s in ("icp_search_walk", "icp_search_fast_kernel", "icp_plane_accum_kernel", "icp_search_redo_kernel", "gn_solve_kernel"))]
-    lines = ["# PMC counters of the hot kernels (mean per dispatch; `bench.py --steps 2 --resident --scans-per-gpu %d`, 10 M-pt map)" % a.scans, "",
+    keep = [k for k in agg if any(s in k for s in ("icp_search_walk", "icp_plane_accum_kernel", "icp_point_accum_kernel", "icp_search_redo_kernel", "gn_solve_kernel", "ndt_accum_kernel"))]
+    lines = ["# PMC counters of the hot kernels (mean per dispatch; `bench.py --steps 2 --resident --scans-per-gpu %d --method %s`, 10 M-pt map)" % (a.scans, a.method), "",
              "Collected by `tools/collect_pmc.py`: one `rocprofv3 --pmc` pass per counter group, nothing else enabled. SQ_*_CYCLES and SQ_WAIT_* count quad-cycles",
              "(MI355X_MICROARCH.md); per-wave values = counter / SQ_WAVES of the same pass.", ""]
     for k in sorted(keep):

@@ -2,7 +2,8 @@
 """Randomised batch-composition probe (run ON the GPU box): batches of 1-40 scans of random sizes (one point to a full scan, ragged,
 some copies of each other, some far / exact / near initial poses so that scans leave the loop at different iterations), against local maps
 of random size — every scan's pose and iteration count against the oracle's single-scan alignment: P2Plane, P2Line and (every other case)
-direct NDT; a third of the cases under hipGraph replay, a third as two batches in flight together. The batch sizes
+direct NDT; a quarter of the cases under hipGraph replay, a quarter as two batches in flight together, a quarter as jobs of an open-scan
+pool with fewer slots than scans (locgpu_pool: scans wait for slots, share launches with other jobs' scans, leave one by one). The batch sizes
 straddle the launch-shape thresholds of the library (thin-wave / full-wave search kernel at 2048 waves, points per thread of the fit
 kernel at 2048 / 4096 / 8192 blocks, open-scan lists from the second chunk on).
 
@@ -68,7 +69,7 @@ def main():
         inits = np.stack(inits)
         ctx = api.Context(0)
         ctx.icp_set_target(m)
-        how = case % 3  # 0: blocking call; 1: the same under hipGraph replay; 2: the scans as TWO batches begun together, then finished
+        how = case % 4  # 0: blocking call; 1: the same under hipGraph replay; 2: the scans as TWO batches begun together, then finished; 3: as jobs of an open-scan pool
         for method in (api.P2PLANE, api.P2LINE, -1):
             if method >= 0:
                 ref = locref.Icp(method=method)
@@ -93,6 +94,17 @@ def main():
                 p2, s2 = ctx.align_batch_end(b2)
                 poses, st = np.concatenate([p1, p2]), list(s1) + list(s2)
                 b1.close(); b2.close()
+            elif how == 3:
+                # one to three jobs through a pool with room for about half of the scans and a random chunk length
+                cuts = sorted(set([0, n_scans] + [int(c) for c in rng.integers(1, max(n_scans, 2), size=2)]))
+                jobs = [(scans[lo:hi], inits[lo:hi]) for lo, hi in zip(cuts[:-1], cuts[1:]) if hi > lo]
+                biggest = max(len(j[0]) for j in jobs)
+                pool = api.Pool(ctx, slots=max(1, n_scans // 2), prefetch=biggest, max_points=max(len(x) for x in scans), scans_per_job=biggest,
+                                chunk=int(rng.integers(1, 5)), opts=(api.icp_opts(method=method) if method >= 0 else None), ndt=(method < 0))
+                tickets = [pool.submit(js, ji) for js, ji in jobs]
+                res = [pool.wait(t) for t in tickets]
+                pool.close()
+                poses, st = np.concatenate([r[0] for r in res]), [x for r in res for x in r[1]]
             else:
                 b = ctx.batch(scans)
                 poses, st = ctx.icp_align_batch(b, inits, api.icp_opts(method=method)) if method >= 0 else ctx.ndt_align_batch(b, inits)
@@ -113,11 +125,15 @@ def main():
                             singular += 1
                             continue
                     # ... or become so on the way: then the CPU restatement itself ends somewhere else when its initial pose is moved by 1e-9
-                    nudged = inits[j].copy()
-                    nudged[4:] += 1e-9
-                    w2 = ref.align(scans[j], nudged)
-                    d2t, d2r = pose_delta(w2["pose"], want["pose"])
-                    if w2["iters"] != want["iters"] or d2t > 1e-6 or d2r > 1e-6:
+                    # (three nudges of 1e-9: all components up, alternating signs, and the rotation — one direction alone can miss it)
+                    shaky = False
+                    for nudge in (np.array([0, 0, 0, 0, 1e-9, 1e-9, 1e-9]), np.array([0, 0, 0, 0, 1e-9, -1e-9, 1e-9]), np.array([1e-9, -1e-9, 1e-9, 0, 0, 0, 0])):
+                        nudged = inits[j] + nudge
+                        nudged[:4] /= np.linalg.norm(nudged[:4])
+                        w2 = ref.align(scans[j], nudged)
+                        d2t, d2r = pose_delta(w2["pose"], want["pose"])
+                        shaky = shaky or w2["iters"] != want["iters"] or d2t > 1e-6 or d2r > 1e-6
+                    if shaky:
                         unstable += 1
                         continue
                     bad += 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity hunt for the hot search kernel (run ON the GPU box): random maps (uniform, clustered, planar sheets, lines, duplicated
-points, lattices), random scans and poses, ANN and exact pruning, k = 5 and 1 — the neighbour lists of icp_search_fast_kernel (read back with
+points, lattices), random scans and poses, ANN and exact pruning, k = 5 and 1 — the neighbour lists of icp_search_walk_kernel (read back with
 locgpu_debug_batch_nn) must equal the oracle's KdTree::GetClosestPoint lists index for index. Odd cases run as a batch large enough for
 the batch kernel (walk + deep pass), even ones through the one-scan kernel; LOCGPU_FAST_STACK=12 makes the rare paths common.
 

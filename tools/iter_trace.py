@@ -33,7 +33,7 @@ def main():
         shutil.rmtree(d, ignore_errors=True)
 
     def key(n):
-        for k, pat in (("walk", "icp_search_walk_kernel"), ("deep", "icp_search_walk_list"), ("cont", "icp_search_walk_cont"), ("redo", "icp_search_redo"),
+        for k, pat in (("walk", "icp_search_walk_kernel"), ("deep", "icp_search_walk_list"), ("redo", "icp_search_redo"),
                        ("refit", "plane_refit"), ("accum", "accum_kernel"), ("solve", "gn_solve")):
             if pat in n:
                 return k
