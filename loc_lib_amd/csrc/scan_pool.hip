@@ -31,6 +31,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "batch_upload.hpp"
@@ -53,8 +54,12 @@ struct PoolJob {
     std::vector<double> out;   // [n_total][7]
     std::vector<locgpu_align_stats> stats;
     int remaining = 0;         // scans not finished yet
-    BatchUploadState upl;      // the event behind the copy of its points
+    // the copy of its points goes in pieces of kUploadPiece scans, each with its own event: the first scans of a large job enter the
+    // pool while its last ones are still on their way (a 256-scan job is 472 MB: 14 ms at PCIe speed)
+    std::vector<std::unique_ptr<BatchUploadState>> upl;
 };
+
+constexpr int kUploadPiece = 32;
 
 constexpr int kAccRing = 8;  // exchange buffers in rotation: one per pooled iteration of a chunk (chunk <= kAccRing)
 
@@ -111,8 +116,10 @@ int pool_fail(locgpu_pool* P, int code, const std::string& msg) { return fail(P-
 
 void job_free(PoolJob* j) {
     if (!j) return;
-    if (j->upl.done_valid && j->upl.done) (void)hipEventSynchronize(j->upl.done);
-    if (j->upl.done) (void)hipEventDestroy(j->upl.done);
+    for (auto& u : j->upl) {
+        if (u->done_valid && u->done) (void)hipEventSynchronize(u->done);
+        if (u->done) (void)hipEventDestroy(u->done);
+    }
     delete j;
 }
 
@@ -245,17 +252,21 @@ int pool_launch(locgpu_pool* P) {
     // waiting scans enter one by one, oldest job first, while there are free slots
     while (!P->waiting.empty() && !P->free_slots.empty()) {
         PoolJob* j = P->waiting.front();
-        if (j->next == 0 && j->n_local > 0) {
-            // a copy still on its way must not stall the scans that are running (one rank only: with several ranks every decision
-            // has to be the same everywhere, so the stream simply waits for the copy)
-            const bool may_defer = !P->multi_rank && (open_now > 0 || admitted_any);
-            if (may_defer && upload_host_busy(&j->upl)) break;
-            { const int rc = upload_join_state(ctx, &j->upl); if (rc != LOCGPU_OK) return rc; }
-            if (may_defer && hipEventQuery(j->upl.done) == hipErrorNotReady) break;
-            LOCGPU_HIP(ctx, hipStreamWaitEvent(s, j->upl.done, 0));
-        }
+        bool stalled = false;
         while (j->next < j->n_total && !P->free_slots.empty()) {
-            const int i = j->next++;
+            const int i = j->next;
+            const bool held = i >= j->first && i < j->first + j->n_local;
+            if (held && (i - j->first) % kUploadPiece == 0) {
+                // the first scan of an upload piece: a copy still on its way must not stall the scans that are running (one rank
+                // only: with several ranks every decision has to be the same everywhere, so the stream simply waits for the copy)
+                BatchUploadState* u = j->upl[(size_t)(i - j->first) / kUploadPiece].get();
+                const bool may_defer = !P->multi_rank && (open_now > 0 || admitted_any);
+                if (may_defer && upload_host_busy(u)) { stalled = true; break; }
+                { const int rc = upload_join_state(ctx, u); if (rc != LOCGPU_OK) return rc; }
+                if (may_defer && hipEventQuery(u->done) == hipErrorNotReady) { stalled = true; break; }
+                LOCGPU_HIP(ctx, hipStreamWaitEvent(s, u->done, 0));
+            }
+            j->next++;
             const int sl = P->free_slots.back();
             P->free_slots.pop_back();
             P->slot_job[sl] = j;
@@ -268,6 +279,7 @@ int pool_launch(locgpu_pool* P) {
             admitted_any = true;
         }
         if (j->next == j->n_total) P->waiting.pop_front();
+        if (stalled) break;  // FIFO: later jobs do not overtake
     }
     int n_mine = 0, n_theirs = 0;
     for (int sl = 0; sl < P->slots; ++sl) {
@@ -469,9 +481,16 @@ int locgpu_pool_submit(locgpu_pool* P, const void* const* srcs, const size_t* co
     j->out.assign(7 * (size_t)n_total, 0.0);
     j->stats.assign(n_total, locgpu_align_stats{});
     j->remaining = n_total;
+    int rc_up = LOCGPU_OK;
+    for (int lo = 0; lo < n_local && rc_up == LOCGPU_OK; lo += kUploadPiece) {
+        const int cnt = std::min(kUploadPiece, n_local - lo);
+        j->upl.emplace_back(new BatchUploadState());
+        rc_up = upload_start_regions(P->b, j->upl.back().get(), P->d_arena, P->regions, srcs + lo, counts + lo, stride_bytes, cnt, j->region.data() + first_scan + lo);
+    }
     if (n_local > 0) {
-        const int rc = upload_start_regions(P->b, &j->upl, P->d_arena, P->regions, srcs, counts, stride_bytes, n_local, j->region.data() + first_scan);
+        const int rc = rc_up;
         if (rc != LOCGPU_OK) {
+            upload_drain(ctx);  // the pieces already queued read the caller's clouds and write regions that go back to the pool
             for (int i = n_total - 1; i >= 0; --i) P->free_regions.push_back(j->region[i]);
             std::sort(P->free_regions.begin(), P->free_regions.end(), std::greater<int>());
             job_free(j);
