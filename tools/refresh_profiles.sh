@@ -26,7 +26,7 @@ timeout 400 python3 tools/collect_pmc.py --out $O/pmc_ndt_kernel.md --scans 64 -
 # ---- latency, counters, tables, traces
 timeout 200 python tools/latency_microbench.py 2>/dev/null | line > $O/latency.json
 timeout 400 python3 tools/collect_pmc.py --out $O/pmc_kernels.md --scans 64 > /dev/null 2>&1
-timeout 600 python tests/perf/pipeline_microbench.py 2>/dev/null | line > $O/pipeline.json
+timeout 600 python tests/perf/pipeline_microbench.py 2>/dev/null | grep '^{' > $O/pipeline.json   # four JSON lines: filters, inc_ndt, cpp_stream, stream
 timeout 1800 python3 tests/perf/baseline_table.py --out $O/baseline_table.json > $O/baseline_table.md 2>/dev/null
 timeout 1500 python3 tests/perf/defaults_table.py --out $O/defaults_table.json > $O/defaults_table.md 2>$O/defaults_table.err
 timeout 300 python3 tools/iter_trace.py --out $O/iteration_trace.txt > /dev/null 2>&1
