@@ -106,6 +106,34 @@ def rank_main(rank, uid, m, scans, inits, want, log):
                 assert iters(st) == iters(want[kind][1])
             pool.close()
         log.append((rank, "pool"))
+        # ... and the way bench.py drives it with several ranks: TWO pools (lanes) per rank, the steps dealt to the emptier one as soon as
+        # it has source regions for them, collected in order, `step` in between — every decision taken on numbers all ranks see
+        # (locgpu_pool_info / locgpu_pool_done), so both ranks make the same calls in the same order
+        lanes = [api.Pool(ctx, slots=6, max_points=10000, scans_per_job=n, opts=opts) for _ in range(2)]
+        lo, hi = SPLITS["even"][rank]
+        inflight, begun, got_all = [], 0, []
+        n_steps = 7
+        while begun < n_steps or inflight:
+            while begun < n_steps and len(inflight) < 6:
+                p = max(lanes, key=lambda q: q.info()["free_regions"])
+                if inflight and p.info()["free_regions"] < n:
+                    break
+                inflight.append((p, p.submit(scans[lo:hi], inits, first=lo, n_total=n)))
+                begun += 1
+            p, t = inflight[0]
+            if p.done(t):
+                got_all.append(p.wait(t))
+                inflight.pop(0)
+            else:
+                for q in lanes:
+                    q.step(True)
+        assert len(got_all) == n_steps
+        for got, st in got_all:
+            np.testing.assert_array_equal(got, want["plane"][0], err_msg="pool lanes, rank %d" % rank)
+            assert iters(st) == iters(want["plane"][1])
+        for q in lanes:
+            q.close()
+        log.append((rank, "pool lanes"))
         # point sharding: every rank holds a slice of every scan, so the sums really are sums of two parts — equal on both ranks,
         # and equal to the plain batch up to the order of the additions
         pts = multi_gpu.point_sharded_batch(ctx, scans, rank, WORLD)
