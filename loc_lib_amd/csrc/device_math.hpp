@@ -452,6 +452,79 @@ __device__ __host__ inline double lu6_det_solve(const double* H, const double* b
     return det;
 }
 
+// The same factorisation, the same arithmetic in the same order, for ONE device thread with everything in registers: the loops are
+// fully unrolled, the pivot row is found with compares and swapped in with selects (a row index that is only known at run time would
+// put the matrix in scratch memory — ≈10× the latency — or, as rounds 2-4 had it, in LDS: ≈200 dependent LDS round trips, half of the
+// solve kernel's 10 µs on the one-scan path). Bit-identical to lu6_det_solve (the host's locgpu_gn_update still uses that one).
+__device__ __forceinline__ double lu6_det_solve_reg(const double* H, const double* b, double* x) {
+    double a[6][6], rhs[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        rhs[r] = b[r];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) a[r][c] = H[6 * r + c];
+    }
+    double det = 1.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        double best = fabs(a[k][k]);
+#pragma unroll
+        for (int r = k + 1; r < 6; ++r) {
+            const double val = fabs(a[r][k]);
+            const bool g = val > best;
+            best = g ? val : best;
+            piv = g ? r : piv;
+        }
+#pragma unroll
+        for (int r = k + 1; r < 6; ++r) {  // swap rows k and piv (whole rows, like the array version; the right-hand side goes along instead of a permutation)
+            const bool sel = piv == r;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double u = a[k][c], v = a[r][c];
+                a[k][c] = sel ? v : u;
+                a[r][c] = sel ? u : v;
+            }
+            const double u = rhs[k], v = rhs[r];
+            rhs[k] = sel ? v : u;
+            rhs[r] = sel ? u : v;
+        }
+        det = piv != k ? -det : det;
+        const double d = a[k][k];
+        det *= d;
+        const bool nz = !(d == 0.0);  // `if (d == 0.0) continue;`
+#pragma unroll
+        for (int r = k + 1; r < 6; ++r) {
+            const double f = a[r][k] / d;
+            a[r][k] = nz ? f : a[r][k];
+#pragma unroll
+            for (int c = k + 1; c < 6; ++c) {
+                const double t = a[r][c] - f * a[k][c];
+                a[r][c] = nz ? t : a[r][c];
+            }
+        }
+    }
+    if (det == 0.0) return det;
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = rhs[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) s -= a[i][j] * y[j];
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s -= a[i][j] * x[j];
+        x[i] = s / a[i][i];
+    }
+    return det;
+}
+
+
+
 // pose.so3() = pose.so3() * SO3::exp(dx.head<3>()); pose.translation() += dx.tail<3>()
 // (icp_registration.cpp:365-366) — Sophus SO3::exp with its small-angle Taylor branch and the
 // first-order renormalisation of the quaternion product.

@@ -622,7 +622,6 @@ __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restri
                                                           GnParams prm, int do_update, double* __restrict__ hb_out, unsigned int* __restrict__ list_counts,
                                                           const int* __restrict__ scans) {
     __shared__ double s_sum[kBlock / kAccW][kAccW];
-    __shared__ double s_lu[36 + 6];
     const int scan = scans ? scans[blockIdx.x] : (int)blockIdx.x;
     // The search stage's work-list counters (walk kernel → deep pass → redo kernel) are consumed by now: zero them for the next iteration's
     // search instead of paying two fill launches per iteration (a single-scan alignment is launch-latency bound).
@@ -642,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restri
     const long long eff = (long long)tot[27];
     PoseState& ps = st[scan];
     bool ok;
-    const double det = lu6_det_solve(H, B, dx, s_lu);  // LU workspace in LDS: its pivoting indexes rows dynamically
+    const double det = lu6_det_solve_reg(H, B, dx);  // in registers: unrolled, pivot rows swapped in with selects (device_math.hpp)
     if (prm.method == 3) {
         // direct NDT: det(H)==0 is tested FIRST and aborts the whole alignment (ndt cpp:435-436)
         if (det == 0.0) {
