@@ -39,21 +39,17 @@
 #include "launch.hpp"
 #include "ndt_inc.hpp"
 #include "ndt_kernels.hpp"
+#include "pool_sched.hpp"
 
 using namespace locgpu;
 
 namespace {
 
-struct PoolJob {
-    int64_t ticket = 0;
-    int n_total = 0, first = 0, n_local = 0;
-    std::vector<int> region;   // [n_total] source region of every scan of the job (points only in the ones this rank holds)
+struct PoolJob : PoolSchedJob {  // pool_sched.hpp: ticket, n_total, first, n_local, region[], next, remaining
     std::vector<int> counts;   // [n_local] points of the scans this rank holds
-    int next = 0;              // scans [0, next) have been given a slot
     std::vector<double> init;  // [n_total][7]
     std::vector<double> out;   // [n_total][7]
     std::vector<locgpu_align_stats> stats;
-    int remaining = 0;         // scans not finished yet
     // the copy of its points goes in pieces of kUploadPiece scans, each with its own event: the first scans of a large job enter the
     // pool while its last ones are still on their way (a 256-scan job is 472 MB: 14 ms at PCIe speed)
     std::vector<std::unique_ptr<BatchUploadState>> upl;
@@ -79,13 +75,9 @@ struct locgpu_pool {
     bool decoupled = false;   // the owner of a slot solves it ahead of the exchange, which runs on the communication stream
     int regions = 0;                      // source regions in the arena (>= slots)
     float4* d_arena = nullptr;            // [regions][max_n]
-    std::vector<int> free_slots;          // kept sorted descending: pop_back() hands out the smallest free slot
-    std::vector<int> free_regions;        // likewise
-    std::vector<PoolJob*> slot_job;       // [slots] nullptr = free
-    std::vector<int> slot_idx;            // [slots] index of the scan within its job
+    std::unique_ptr<PoolSched> sched;     // pool_sched.hpp: free slots and regions, which scan sits where, who waits (pure host logic)
     int* h_src_of = nullptr;              // pinned [slots]: region of the slot's points
     int* d_src_of = nullptr;
-    std::deque<PoolJob*> waiting;         // submitted, not admitted yet (FIFO)
     std::map<int64_t, PoolJob*> jobs;     // every job not yet handed back through locgpu_pool_wait
     int64_t next_ticket = 1;
     bool in_flight = false;               // a chunk (and the read-back of the states behind it) is enqueued
@@ -134,10 +126,10 @@ void init_state(PoseState& ps, const double* pose) {
 void pool_collect(locgpu_pool* P) {
     locgpu_batch* b = P->b;
     for (int s = 0; s < P->slots; ++s) {
-        PoolJob* j = P->slot_job[s];
+        PoolJob* j = static_cast<PoolJob*>(P->sched->job_of(s));
         if (!j || !b->h_state[s].done) continue;
         const PoseState& ps = b->h_state[s];
-        const int i = P->slot_idx[s];
+        const int i = P->sched->idx_of(s);
         if (ps.status == 1) {  // direct NDT aborted: the reference leaves result_pose unassigned; hand back init_pose (locgpu_api.hip write_results)
             for (int c = 0; c < 7; ++c) j->out[7 * i + c] = j->init[7 * i + c];
         } else {
@@ -147,11 +139,7 @@ void pool_collect(locgpu_pool* P) {
         locgpu_align_stats& st = j->stats[i];
         st.iterations = ps.iterations; st.converged = ps.converged; st.status = ps.status; st.reserved = 0;
         st.last_effective_num = ps.last_eff; st.last_dx_norm = ps.last_dx_norm;
-        j->remaining--;
-        P->slot_job[s] = nullptr;
-        P->free_slots.insert(std::upper_bound(P->free_slots.begin(), P->free_slots.end(), s, std::greater<int>()), s);
-        const int r = j->region[i];
-        P->free_regions.insert(std::upper_bound(P->free_regions.begin(), P->free_regions.end(), r, std::greater<int>()), r);
+        P->sched->finish(s);
     }
     if (P->timed) {
         float ms = 0.f;
@@ -246,44 +234,40 @@ int pool_launch(locgpu_pool* P) {
     locgpu_ctx* ctx = P->ctx;
     locgpu_batch* b = P->b;
     hipStream_t s = b->stream;
-    bool admitted_any = false;
     int open_now = 0;  // scans still running (the flags are fresh: the caller has just read them, or nothing has run since)
-    for (int sl = 0; sl < P->slots; ++sl) open_now += (P->slot_job[sl] && !b->h_state[sl].done) ? 1 : 0;
-    // waiting scans enter one by one, oldest job first, while there are free slots
-    while (!P->waiting.empty() && !P->free_slots.empty()) {
-        PoolJob* j = P->waiting.front();
-        bool stalled = false;
-        while (j->next < j->n_total && !P->free_slots.empty()) {
-            const int i = j->next;
-            const bool held = i >= j->first && i < j->first + j->n_local;
-            if (held && (i - j->first) % kUploadPiece == 0) {
-                // the first scan of an upload piece: a copy still on its way must not stall the scans that are running (one rank
-                // only: with several ranks every decision has to be the same everywhere, so the stream simply waits for the copy)
-                BatchUploadState* u = j->upl[(size_t)(i - j->first) / kUploadPiece].get();
-                const bool may_defer = !P->multi_rank && (open_now > 0 || admitted_any);
-                if (may_defer && upload_host_busy(u)) { stalled = true; break; }
-                { const int rc = upload_join_state(ctx, u); if (rc != LOCGPU_OK) return rc; }
-                if (may_defer && hipEventQuery(u->done) == hipErrorNotReady) { stalled = true; break; }
-                LOCGPU_HIP(ctx, hipStreamWaitEvent(s, u->done, 0));
-            }
-            j->next++;
-            const int sl = P->free_slots.back();
-            P->free_slots.pop_back();
-            P->slot_job[sl] = j;
-            P->slot_idx[sl] = i;
-            init_state(b->h_state[sl], &j->init[7 * (size_t)i]);
-            const bool mine = i >= j->first && i < j->first + j->n_local;
-            P->h_owned[sl] = mine ? 1 : 0;
-            P->h_counts[sl] = mine ? j->counts[i - j->first] : 0;
-            P->h_src_of[sl] = j->region[i];
-            admitted_any = true;
-        }
-        if (j->next == j->n_total) P->waiting.pop_front();
-        if (stalled) break;  // FIFO: later jobs do not overtake
+    for (int sl = 0; sl < P->slots; ++sl) open_now += (P->sched->job_of(sl) && !b->h_state[sl].done) ? 1 : 0;
+    // waiting scans enter one by one, oldest job first, while there are free slots (PoolSched::admit)
+    std::vector<PoolAdmitted> admitted;
+    int rc_admit = LOCGPU_OK;
+    P->sched->admit(
+        [&](PoolSchedJob* sj, int i) {
+            PoolJob* j = static_cast<PoolJob*>(sj);
+            if (!j->holds(i) || (i - j->first) % kUploadPiece != 0) return true;
+            // the first scan of an upload piece: a copy still on its way must not stall the scans that are running (one rank
+            // only: with several ranks every decision has to be the same everywhere, so the stream simply waits for the copy)
+            BatchUploadState* u = j->upl[(size_t)(i - j->first) / kUploadPiece].get();
+            const bool may_defer = !P->multi_rank && (open_now > 0 || !admitted.empty());
+            if (may_defer && upload_host_busy(u)) return false;
+            rc_admit = upload_join_state(ctx, u);
+            if (rc_admit != LOCGPU_OK) return false;
+            if (may_defer && hipEventQuery(u->done) == hipErrorNotReady) return false;
+            if (!hip_ok(ctx, hipStreamWaitEvent(s, u->done, 0), "pool: hipStreamWaitEvent")) { rc_admit = LOCGPU_ERR_NO_DEVICE; return false; }
+            return true;
+        },
+        admitted);
+    if (rc_admit != LOCGPU_OK) return rc_admit;
+    for (const PoolAdmitted& a : admitted) {
+        PoolJob* j = static_cast<PoolJob*>(a.job);
+        init_state(b->h_state[a.slot], &j->init[7 * (size_t)a.idx]);
+        const bool mine = j->holds(a.idx);
+        P->h_owned[a.slot] = mine ? 1 : 0;
+        P->h_counts[a.slot] = mine ? j->counts[(size_t)(a.idx - j->first)] : 0;
+        P->h_src_of[a.slot] = j->region[(size_t)a.idx];
     }
+    const bool admitted_any = !admitted.empty();
     int n_mine = 0, n_theirs = 0;
     for (int sl = 0; sl < P->slots; ++sl) {
-        if (!P->slot_job[sl] || b->h_state[sl].done) continue;
+        if (!P->sched->job_of(sl) || b->h_state[sl].done) continue;
         if (P->h_owned[sl]) P->h_list[n_mine++] = sl;
         else P->h_list[P->slots + n_theirs++] = sl;
     }
@@ -293,7 +277,7 @@ int pool_launch(locgpu_pool* P) {
     if (dbg) {
         static const auto t0 = std::chrono::steady_clock::now();
         fprintf(stderr, "[pool] t=%.3f ms open=%d (mine %d) waiting=%zu free slots=%zu regions=%zu jobs=%zu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
-                P->n_open, n_mine, P->waiting.size(), P->free_slots.size(), P->free_regions.size(), P->jobs.size());
+                P->n_open, n_mine, P->sched->waiting(), (size_t)P->sched->free_slots(), (size_t)P->sched->free_regions(), P->jobs.size());
     }
     if (P->n_open == 0) return LOCGPU_OK;
     if (admitted_any) {
@@ -404,12 +388,7 @@ int locgpu_pool_create(locgpu_ctx* ctx, const locgpu_pool_opts* o, locgpu_pool**
     std::memset(P->h_src_of, 0, S * sizeof(int));
     if (!hip_ok(ctx, hipMemsetAsync(P->d_src_of, 0, S * sizeof(int), P->b->stream), "pool: hipMemset") || !hip_ok(ctx, hipStreamSynchronize(P->b->stream), "pool: hipMemset")) { locgpu_pool_destroy(P); return LOCGPU_ERR_NO_DEVICE; }
     for (size_t s = 0; s < S; ++s) { std::memset(&P->b->h_state[s], 0, sizeof(PoseState)); P->b->h_state[s].done = 1; }  // a free slot is a finished scan
-    P->slot_job.assign(S, nullptr);
-    P->slot_idx.assign(S, 0);
-    P->free_slots.resize(S);
-    for (size_t s = 0; s < S; ++s) P->free_slots[s] = (int)(S - 1 - s);
-    P->free_regions.resize(P->regions);
-    for (int r = 0; r < P->regions; ++r) P->free_regions[r] = P->regions - 1 - r;
+    P->sched.reset(new PoolSched(P->slots, P->regions));
     *out = P;
     return LOCGPU_OK;
 }
@@ -464,7 +443,7 @@ int locgpu_pool_submit(locgpu_pool* P, const void* const* srcs, const size_t* co
     }
     // room in the arena: let scans finish. Every rank accounts n_total regions for the job, whichever scans it holds: the calls a
     // rank makes must not depend on the shard it happens to hold.
-    while ((int)P->free_regions.size() < n_total) {
+    while (P->sched->free_regions() < n_total) {
         bool progress = false;
         const int rc = pool_pump(P, true, &progress);
         if (rc != LOCGPU_OK) return rc;
@@ -473,14 +452,12 @@ int locgpu_pool_submit(locgpu_pool* P, const void* const* srcs, const size_t* co
     auto* j = new PoolJob();
     j->ticket = P->next_ticket++;
     j->n_total = n_total; j->first = first_scan; j->n_local = n_local;
-    j->region.resize(n_total);
-    for (int i = 0; i < n_total; ++i) { j->region[i] = P->free_regions.back(); P->free_regions.pop_back(); }
+    if (!P->sched->accept(j)) { job_free(j); return pool_fail(P, LOCGPU_ERR_INVALID, "pool_submit: no free source regions"); }
     j->counts.resize(n_local);
     for (int i = 0; i < n_local; ++i) j->counts[i] = (int)counts[i];
     j->init.assign(init_poses, init_poses + 7 * (size_t)n_total);
     j->out.assign(7 * (size_t)n_total, 0.0);
     j->stats.assign(n_total, locgpu_align_stats{});
-    j->remaining = n_total;
     int rc_up = LOCGPU_OK;
     for (int lo = 0; lo < n_local && rc_up == LOCGPU_OK; lo += kUploadPiece) {
         const int cnt = std::min(kUploadPiece, n_local - lo);
@@ -491,14 +468,12 @@ int locgpu_pool_submit(locgpu_pool* P, const void* const* srcs, const size_t* co
         const int rc = rc_up;
         if (rc != LOCGPU_OK) {
             upload_drain(ctx);  // the pieces already queued read the caller's clouds and write regions that go back to the pool
-            for (int i = n_total - 1; i >= 0; --i) P->free_regions.push_back(j->region[i]);
-            std::sort(P->free_regions.begin(), P->free_regions.end(), std::greater<int>());
+            P->sched->cancel_last(j);
             job_free(j);
             return rc;
         }
     }
     P->jobs[j->ticket] = j;
-    P->waiting.push_back(j);
     *ticket = j->ticket;
     // keep the pool turning while the caller only submits: an idle pool starts at once; a running one is looked at without waiting
     return pool_pump(P, false);
@@ -549,9 +524,9 @@ int locgpu_pool_profile_read(locgpu_pool* P, double out[2], int reset) {
 int locgpu_pool_info(const locgpu_pool* P, int64_t out[8]) {
     if (!P || !out) return LOCGPU_ERR_INVALID;
     out[6] = P->regions;
-    out[7] = (int64_t)P->free_regions.size();
+    out[7] = P->sched ? P->sched->free_regions() : 0;
     out[0] = P->slots;
-    out[1] = (int64_t)P->free_slots.size();
+    out[1] = P->sched ? P->sched->free_slots() : 0;
     out[2] = (int64_t)P->jobs.size();
     out[3] = P->iterations;
     out[4] = P->scan_iterations;

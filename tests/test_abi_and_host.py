@@ -317,6 +317,29 @@ def test_inc_ndt_host_replay_under_sanitizers(tmp_path, san):
     assert r.returncode == 0 and "inc-ndt host harness ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
 
+def test_pool_bookkeeping_is_lock_step_across_ranks_under_sanitizers(tmp_path):
+    """The N > 1 path of the open-scan pool on the CPU: csrc/pool_sched.hpp — the slots, the source regions, the FIFO
+    of waiting jobs: everything scan_pool.hip decides on the host — driven as 2 and as 8 simulated ranks that each hold a different
+    shard of every job. Every rank must give every scan the same slot and region at the same chunk boundary and issue the same
+    number of collectives (RCCL would hang, or sum the wrong rows, otherwise); one rank with copies that arrive late must keep FIFO
+    order and lose no slot or region. ASan + UBSan on."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    csrc = os.path.join(ROOT, "loc_lib_amd", "csrc")
+    exe = str(tmp_path / "pool_sched_sanitize")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-I", csrc,
+           os.path.join(ROOT, "tests", "cpp", "pool_sched_sanitize.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    for args in (["ranks", "2"], ["ranks", "8"], ["stall"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.count(" OK") >= 3, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 # ----------------------------------------------------------------------------------------------- bench.py launcher (no GPU needed)
 def _load_bench():
     import importlib.util
