@@ -208,8 +208,9 @@ int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts,
     // One alignment per batch at a time, and no upload into a batch whose alignment has been begun and not ended: the
     // chunks locgpu_align_batch_end enqueues later read d_src / d_counts / b->counts, which this upload would replace under them.
     // A caller with several alignments in flight rotates depth + 1 batches (bench.py) — the copy always goes to an idle one.
-    // No ordering behind the batch's compute stream is needed beyond that: every ended alignment leaves its stream synchronised
-    // (align_finish synchronises it on its error paths as well).
+    // No ordering behind the batch's compute stream is needed beyond that: an ended alignment leaves its stream synchronised
+    // (align_finish synchronises it on its error paths as well) — or, a paced one-scan alignment, with at most a few launches
+    // queued that return on the scan's `done` flag before they read the counts or the points.
     if (b->pending.active) return fail(ctx, LOCGPU_ERR_INVALID, "batch upload: an alignment of this batch has been begun and not finished");
     const int rc = enqueue(b, b->upl, srcs, counts, stride_bytes, b->n_scans, nullptr, nullptr);
     if (rc == LOCGPU_OK)

@@ -117,6 +117,11 @@ struct locgpu_batch {
     unsigned long long graph_epoch = 0;
     float4* h_src = nullptr;               // pinned staging of the packed source (single-scan path only; reused across calls)
     locgpu::PoseState* h_state = nullptr;  // pinned
+    // one-scan alignments paced from the host (locgpu_api.hip, align_finish): the solve kernel posts the state here after every
+    // iteration — pinned COHERENT memory: [0] a finished scan's GnPostRecord, [kPostWord] call << 32 | iterations << 1 | done, [+1] checksum
+    unsigned long long* h_post = nullptr;
+    static constexpr int kPostWord = 16;  // in 8-byte words: behind the record, 16-byte aligned
+    unsigned int post_call = 0;
     double* h_hb = nullptr;                // pinned
     int* h_active = nullptr;               // pinned, [n_scans]: local indices of the scans still open at the last chunk boundary
     int* d_active = nullptr;               // its device copy (see SearchArgs::active)
@@ -131,6 +136,7 @@ struct locgpu_batch {
         int k = 0;
         float alpha_eff = 0.f;
         bool ndt = false, graph = false;
+        bool paced = false;  // one scan, eager: iterations are launched as the solve kernel posts its progress
         int launched = 0;
         size_t ev_used = 0;
         std::vector<double> init_poses;

@@ -618,35 +618,27 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ row
 // reference's checks and update (icp_registration.cpp:204-211 + 362-375; ndt_registration.cpp:435-459).
 // hb_out (optional): per scan 44 doubles = H (36, row-major), B (6), effective_num, ok.
 // scans (optional): the scans to solve — block i takes scan scans[i] (a scan pool solves its open slots only, scan_pool.hip).
-__global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restrict__ partials, int blocks_per_scan, PoseState* __restrict__ st,
-                                                          GnParams prm, int do_update, double* __restrict__ hb_out, unsigned int* __restrict__ list_counts,
-                                                          const int* __restrict__ scans) {
-    __shared__ double s_sum[kBlock / kAccW][kAccW];
-    const int scan = scans ? scans[blockIdx.x] : (int)blockIdx.x;
-    // The search stage's work-list counters (walk kernel → deep pass → redo kernel) are consumed by now: zero them for the next iteration's
-    // search instead of paying two fill launches per iteration (a single-scan alignment is launch-latency bound).
-    if (list_counts && blockIdx.x == 0 && threadIdx.x < 4) list_counts[threadIdx.x] = 0u;
-    if (st[scan].done) return;
-    const double col_total = reduce_partials(partials + (size_t)scan * blocks_per_scan * kAccW, blocks_per_scan, true, s_sum);
-    if (threadIdx.x < kAccW) s_sum[0][threadIdx.x] = col_total;
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    double tot[28];
-    for (int v = 0; v < 28; ++v) tot[v] = s_sum[0][v];
+__device__ __forceinline__ void gn_update(const double* tot, PoseState& ps, const GnParams& prm, int do_update, double* __restrict__ hb) {
     double H[36], B[6], dx[6] = {0, 0, 0, 0, 0, 0};
     int o = 0;
     for (int i = 0; i < 6; ++i)
         for (int j = i; j < 6; ++j) { H[6 * i + j] = tot[o]; H[6 * j + i] = tot[o]; ++o; }
     for (int i = 0; i < 6; ++i) B[i] = tot[21 + i];
     const long long eff = (long long)tot[27];
-    PoseState& ps = st[scan];
     bool ok;
     const double det = lu6_det_solve_reg(H, B, dx);  // in registers: unrolled, pivot rows swapped in with selects (device_math.hpp)
+    auto write_hb = [&](double okv) {
+        if (!hb) return;
+        for (int i = 0; i < 36; ++i) hb[i] = H[i];
+        for (int i = 0; i < 6; ++i) hb[36 + i] = B[i];
+        hb[42] = (double)eff;
+        hb[43] = okv;
+    };
     if (prm.method == 3) {
         // direct NDT: det(H)==0 is tested FIRST and aborts the whole alignment (ndt cpp:435-436)
         if (det == 0.0) {
             ps.status = 1; ps.done = 1; ps.iterations += 1; ps.last_eff = eff;
-            if (hb_out) { for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i]; for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i]; hb_out[44 * scan + 42] = (double)eff; hb_out[44 * scan + 43] = 0.0; }
+            write_hb(0.0);
             return;
         }
         ok = eff >= prm.min_effective_pts;
@@ -655,18 +647,13 @@ __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restri
         ok = eff >= prm.min_effective_pts;
         if (!ok) {
             ps.status = 2; ps.done = 1; ps.iterations += 1; ps.last_eff = eff;
-            if (hb_out) { for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i]; for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i]; hb_out[44 * scan + 42] = (double)eff; hb_out[44 * scan + 43] = 0.0; }
+            write_hb(0.0);
             return;
         }
     } else {
         ok = (eff >= prm.min_effective_pts) && !(det == 0.0);
     }
-    if (hb_out) {
-        for (int i = 0; i < 36; ++i) hb_out[44 * scan + i] = H[i];
-        for (int i = 0; i < 6; ++i) hb_out[44 * scan + 36 + i] = B[i];
-        hb_out[44 * scan + 42] = (double)eff;
-        hb_out[44 * scan + 43] = ok ? 1.0 : 0.0;
-    }
+    write_hb(ok ? 1.0 : 0.0);
     ps.last_eff = eff;
     if (!do_update) return;
     ps.iterations += 1;
@@ -682,6 +669,47 @@ __global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restri
         if (nrm < prm.eps) { ps.converged = 1; ps.done = 1; }
     }
     if (ps.iterations >= prm.max_iteration) ps.done = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void gn_solve_kernel(const double* __restrict__ partials, int blocks_per_scan, PoseState* __restrict__ st,
+                                                          GnParams prm, int do_update, double* __restrict__ hb_out, unsigned int* __restrict__ list_counts,
+                                                          const int* __restrict__ scans, GnPost post) {
+    __shared__ double s_sum[kBlock / kAccW][kAccW];
+    const int scan = scans ? scans[blockIdx.x] : (int)blockIdx.x;
+    // The search stage's work-list counters (walk kernel → deep pass → redo kernel) are consumed by now: zero them for the next iteration's
+    // search instead of paying two fill launches per iteration (a single-scan alignment is launch-latency bound).
+    if (list_counts && blockIdx.x == 0 && threadIdx.x < 4) list_counts[threadIdx.x] = 0u;
+    if (st[scan].done) return;
+    const double col_total = reduce_partials(partials + (size_t)scan * blocks_per_scan * kAccW, blocks_per_scan, true, s_sum);
+    if (threadIdx.x < kAccW) s_sum[0][threadIdx.x] = col_total;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double tot[28];
+    for (int v = 0; v < 28; ++v) tot[v] = s_sum[0][v];
+    PoseState& ps = st[scan];
+    gn_update(tot, ps, prm, do_update, hb_out ? hb_out + 44 * (size_t)scan : nullptr);
+    if (post.word) {
+        // A one-scan alignment paced from the host (locgpu_api.hip, align_finish): a word in pinned host memory says which iteration
+        // this was — the host launches the next iteration but one when it sees it — and a finished scan's result goes there too: no
+        // chunk of idle launches, no copy, no stream synchronisation on the latency path. Plain stores to fine-grained host memory
+        // (they write through); a system-scope RELEASE here writes the whole L2 back — ≈12 µs per iteration, measured — so the
+        // record is sealed by a checksum instead of a fence: the host takes it when the sum over what it reads matches.
+        const unsigned long long tag = ((unsigned long long)post.call << 32) | ((unsigned long long)(unsigned int)ps.iterations << 1) | (ps.done ? 1ull : 0ull);
+        if (ps.done) {
+            GnPostRecord r;
+            for (int i = 0; i < 4; ++i) r.w[i] = __double_as_longlong(ps.q[i]);
+            for (int i = 0; i < 3; ++i) r.w[4 + i] = __double_as_longlong(ps.t[i]);
+            r.w[7] = __double_as_longlong(ps.last_dx_norm);
+            r.w[8] = (unsigned long long)ps.last_eff;
+            r.w[9] = ((unsigned long long)(unsigned int)ps.converged << 32) | (unsigned int)ps.status;
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            volatile u64x2* to = reinterpret_cast<volatile u64x2*>(post.record);
+            for (int i = 0; i < GnPostRecord::kWords / 2; ++i) to[i] = u64x2{r.w[2 * i], r.w[2 * i + 1]};
+            *reinterpret_cast<volatile u64x2*>(post.word) = u64x2{tag, gn_post_sum(tag, r)};
+        } else {
+            __hip_atomic_store(post.word, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // First half of gn_solve_kernel for sharded batches (see launch.hpp): one block per GLOBAL scan.
@@ -948,8 +976,8 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s) {
 }
 
 void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
-                     unsigned int* list_counts, hipStream_t s, const int* scans) {
-    hipLaunchKernelGGL(gn_solve_kernel, dim3(n_scans), dim3(kBlock), 0, s, partials, blocks_per_scan, st, prm, do_update, hb_out, list_counts, scans);
+                     unsigned int* list_counts, hipStream_t s, const int* scans, const GnPost* post) {
+    hipLaunchKernelGGL(gn_solve_kernel, dim3(n_scans), dim3(kBlock), 0, s, partials, blocks_per_scan, st, prm, do_update, hb_out, list_counts, scans, post ? *post : GnPost{});
 }
 
 void launch_sum_partials(const double* partials, int blocks_per_scan, const PoseState* st_all, int first, int n_local, int n_total, double* acc,

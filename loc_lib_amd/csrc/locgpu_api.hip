@@ -152,6 +152,7 @@ void locgpu::free_batch(locgpu_batch* b) {
     if (b->graph_exec_next) (void)hipGraphExecDestroy(b->graph_exec_next);
     if (b->h_src) (void)hipHostFree(b->h_src);
     if (b->h_state) (void)hipHostFree(b->h_state);
+    if (b->h_post) (void)hipHostFree(b->h_post);
     if (b->h_hb) (void)hipHostFree(b->h_hb);
     if (b->h_active) (void)hipHostFree(b->h_active);
     if (b->d_active) (void)hipFree(b->d_active);
@@ -748,6 +749,7 @@ struct IterLauncher {
     bool replicated_on_comm_stream = false;  // the chunk's read-back must wait for the communication stream as well
     const int* active = nullptr;  // later chunks: the local scans still open (SearchArgs::active); nullptr = all
     int n_active = 0;
+    const GnPost* post = nullptr;  // paced one-scan alignment: the solve kernel posts the state to the host
     bool launch(int do_update);
     void collect_profile();
 };
@@ -859,7 +861,7 @@ bool IterLauncher::launch(int do_update) {
         }
         launch_gn_solve(acc, 1, b->d_state, b->n_total, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s);
     } else {
-        launch_gn_solve(b->d_partials, n_partial_blocks, b->d_state, b->n_scans, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s);
+        launch_gn_solve(b->d_partials, n_partial_blocks, b->d_state, b->n_scans, prm, do_update, b->d_hb, ndt ? nullptr : b->d_redo_count, s, nullptr, post);
     }
     mark();
     return hip_ok(ctx, hipGetLastError(), "kernel launch");
@@ -994,6 +996,72 @@ static int enqueue_chunk(locgpu_ctx* ctx, locgpu_batch* b, bool first_chunk) {
     return LOCGPU_OK;
 }
 
+// A ONE-SCAN alignment is paced from the host instead of chunked: the solve kernel posts the scan's state and an iteration word to
+// pinned host memory (GnPost, icp_kernels.hip); the host keeps `ahead` iterations queued behind the one that is running and launches
+// the next when a post arrives. Against chunks (first_chunk_len / next_chunk above, still what graphs and batches use) a call no
+// longer pays the idle iterations of a chunk that was sized by the previous call (≈14 µs each: three dispatches that find `done`),
+// nor a chunk boundary (read-back + host + relaunch ≈ 33 µs) when the guess was short, nor the copy and the stream synchronisation
+// at the end: the result is in host memory when the done bit arrives. At most `ahead` idle iterations stay queued behind a finished
+// call; they return on the `done` flag before they read anything (an upload or the next call's state copy may follow at once).
+// Same kernels on the same data in the same order: results are the chunked path's bits. LOCGPU_PACE_AHEAD=0 switches it off.
+inline int pace_ahead() {
+    static const int v = [] { const char* e = getenv("LOCGPU_PACE_AHEAD"); return e ? std::max(0, std::min(8, atoi(e))) : 1; }();
+    return v;
+}
+
+static int paced_launch(locgpu_ctx* ctx, locgpu_batch* b, int upto) {
+    locgpu_batch::Pending& P = b->pending;
+    IterLauncher it{ctx, b, P.prm, P.k, P.alpha_eff};
+    it.ndt = P.ndt;
+    const GnPost post{reinterpret_cast<GnPostRecord*>(b->h_post), b->h_post + locgpu_batch::kPostWord, b->post_call};
+    it.post = &post;
+    while (P.launched < upto) {
+        if (!it.launch(1)) return LOCGPU_ERR_NO_DEVICE;
+        P.launched++;
+    }
+    return LOCGPU_OK;
+}
+
+// Wait for a post of this call that is newer than iteration `seen`; returns the word. A post with the done bit is taken only when the
+// state behind it is complete (its checksum matches what this thread reads: the kernel's stores carry no fence).
+static int paced_wait(locgpu_ctx* ctx, locgpu_batch* b, int seen, unsigned long long* out) {
+    const unsigned long long* word = b->h_post + locgpu_batch::kPostWord;
+    auto fresh = [&](unsigned long long* w_out) {
+        const unsigned long long w = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+        if ((unsigned int)(w >> 32) != b->post_call || (int)((w & 0xffffffffull) >> 1) <= seen) return false;
+        if (w & 1ull) {
+            GnPostRecord r;
+            for (int i = 0; i < GnPostRecord::kWords; ++i) r.w[i] = __atomic_load_n(b->h_post + i, __ATOMIC_RELAXED);
+            if (gn_post_sum(w, r) != __atomic_load_n(word + 1, __ATOMIC_RELAXED)) return false;  // still on its way
+            PoseState& ps = b->h_state[0];
+            for (int i = 0; i < 4; ++i) std::memcpy(&ps.q[i], &r.w[i], 8);
+            for (int i = 0; i < 3; ++i) std::memcpy(&ps.t[i], &r.w[4 + i], 8);
+            quat_to_R(ps.q, ps.R);
+            std::memcpy(&ps.last_dx_norm, &r.w[7], 8);
+            ps.last_eff = (long long)r.w[8];
+            ps.iterations = (int)((w & 0xffffffffull) >> 1);
+            ps.converged = (int)(r.w[9] >> 32);
+            ps.status = (int)(r.w[9] & 0xffffffffull);
+            ps.done = 1;
+        }
+        *w_out = w;
+        return true;
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long spins = 1;; ++spins) {
+        if (fresh(out)) return LOCGPU_OK;
+        if ((spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+            // nothing for a long time: is the stream still working? An idle stream with no post means a kernel died or the posts do
+            // not reach the host. (Not earlier: a stream query is a runtime call on the latency path.)
+            const hipError_t q = hipStreamQuery(b->stream);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) { hip_ok(ctx, q, "paced alignment"); return LOCGPU_ERR_NO_DEVICE; }
+            if (fresh(out)) return LOCGPU_OK;
+            return fail(ctx, LOCGPU_ERR_NO_DEVICE, "paced alignment: the stream is idle and the solve kernel's post has not arrived");
+        }
+    }
+}
+
 static int align_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt) {
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     locgpu_batch::Pending& P = b->pending;
@@ -1011,7 +1079,20 @@ static int align_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_pose
     if (!ndt && !b->counters_clean) LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 4 * sizeof(unsigned int), b->stream));
     b->counters_clean = false;  // until this alignment has run to its end
     if (P.graph) { const int rc = ensure_graphs(ctx, b, prm, k, alpha_eff, ndt); if (rc != LOCGPU_OK) return rc; }
-    if (prm.max_iteration > 0) { const int rc = enqueue_chunk(ctx, b, true); if (rc != LOCGPU_OK) return rc; }
+    P.paced = !P.graph && b->n_total == 1 && !b->sharded && !ctx->profile && !ctx->count_visits && prm.max_iteration > 0 && pace_ahead() > 0 && (ndt || alpha_eff >= 0.f);
+    if (P.paced) {
+        if (!b->h_post) {
+            LOCGPU_HIP(ctx, hipHostMalloc((void**)&b->h_post, 256, hipHostMallocCoherent));
+            std::memset(b->h_post, 0, 256);
+        }
+        b->post_call++;  // posts carry the call's number: a word left by the previous call is not this call's
+        LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, sizeof(PoseState), hipMemcpyHostToDevice, b->stream));
+        const int rc = paced_launch(ctx, b, std::min(prm.max_iteration, 1 + pace_ahead()));
+        if (rc != LOCGPU_OK) { (void)hipStreamSynchronize(b->stream); return rc; }
+    } else if (prm.max_iteration > 0) {
+        const int rc = enqueue_chunk(ctx, b, true);
+        if (rc != LOCGPU_OK) return rc;
+    }
     P.active = true;
     return LOCGPU_OK;
 }
@@ -1021,7 +1102,20 @@ static int align_finish(locgpu_ctx* ctx, locgpu_batch* b, double* out_poses, loc
     locgpu_batch::Pending& P = b->pending;
     if (!P.active) return fail(ctx, LOCGPU_ERR_INVALID, "align: no alignment of this batch has been begun");
     P.active = false;
-    while (P.prm.max_iteration > 0) {
+    if (P.paced) {
+        int seen = 0;
+        for (;;) {
+            unsigned long long w = 0;
+            int rc = paced_wait(ctx, b, seen, &w);
+            if (rc == LOCGPU_OK) {
+                seen = (int)((w & 0xffffffffull) >> 1);
+                if ((w & 1ull) || seen >= P.prm.max_iteration) break;
+                rc = paced_launch(ctx, b, std::min(P.prm.max_iteration, seen + 1 + pace_ahead()));
+            }
+            if (rc != LOCGPU_OK) { (void)hipStreamSynchronize(b->stream); return rc; }
+        }
+    }
+    while (!P.paced && P.prm.max_iteration > 0) {
         LOCGPU_HIP(ctx, hipStreamSynchronize(b->stream));
         if (!P.graph) {
             IterLauncher it{ctx, b, P.prm, P.k, P.alpha_eff};

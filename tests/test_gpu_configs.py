@@ -819,6 +819,30 @@ def test_secular_plane_fit_agrees_with_the_four_column_fit(tmp_path):
     assert np.array_equal(hb_a[:, 42:44], hb_b[:, 42:44])  # effective_num, ok
 
 
+def test_paced_one_scan_alignment_equals_the_chunked_one(tmp_path):
+    """A one-scan eager alignment is paced from the host (locgpu_api.hip: the solve kernel posts an iteration word — and the finished
+    scan's result under a checksum — to pinned host memory; the host keeps one iteration queued ahead) instead of running in chunks
+    sized by the call before (LOCGPU_PACE_AHEAD=0). Same kernels, same data, same order: poses, iteration counts and stats are equal
+    bit for bit — P2Plane / P2P / P2Line / direct NDT, a start that converges at once, far starts, runs cut short by max_iteration, a
+    scan that never has enough points, new uploads right behind a call, the host-pointer call. Reference loop: icp_registration.cpp:358-376."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, val in (("paced", "1"), ("chunked", "0")):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_paced_case.py"), f],
+                           env=dict(os.environ, LOCGPU_PACE_AHEAD=val), capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[tag] = np.load(f)
+    a, b = outs["paced"], outs["chunked"]
+    assert len(a["it"]) >= 20 and a["it"].max() >= 9 and a["it"].min() <= 2, a["it"]  # short and long runs both present
+    assert np.array_equal(a["it"], b["it"]), (a["it"], b["it"])
+    assert np.array_equal(a["pose"], b["pose"])
+    assert np.array_equal(a["stats"], b["stats"], equal_nan=True)
+
+
 def test_align_begin_end_two_batches_in_flight(gpu_ctx, api, small_world):
     """locgpu_*_align_batch_begin / locgpu_align_batch_end: two batches (different scans, ragged counts) begun back to back and ended
     in order give bit for bit the poses, iteration counts and stats of the blocking calls — ICP and direct NDT — also when the

@@ -16,13 +16,14 @@ ctx.icp_set_target(m)
 ctx.ndt_set_target(m)
 out = {}
 only = os.environ.get("LAT_ONLY")  # e.g. p2plane_eager: one leg only (for a kernel trace)
+sids = [int(x) for x in os.environ.get("LAT_SCANS", "0,1,2,3,4,5,6,7,8,9,10,11").split(",")]  # which synthetic scans (a trace of one of them)
 for name in ("p2plane", "ndt"):
     for graph in (False, True):
         if only and only != "%s_%s" % (name, "graph" if graph else "eager"):
             continue
         ctx.graph_enable(graph)
         ts, its = [], []
-        for sid in range(12):
+        for sid in sids:
             scan = synth.make_scan(sid)
             _, init = synth.make_pose(sid)
             b = ctx.batch([scan])
@@ -44,7 +45,7 @@ for graph in (False, True):
     ctx.graph_enable(graph)
     opts = api.icp_opts(method=api.P2PLANE)
     ts = []
-    for sid in range(12):
+    for sid in sids:
         scan = synth.make_scan(sid)
         _, init = synth.make_pose(sid)
         ctx.icp_align(scan, init, opts)

@@ -20,11 +20,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--leg", default="p2plane_eager")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--scan", type=int, default=11, help="which synthetic scan (their traversals differ: tools/latency_detail.py)")
     a = ap.parse_args()
     d = tempfile.mkdtemp(prefix="locgpu_strace_", dir="/tmp")
     try:
         subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--", "python3", os.path.join(ROOT, "tools", "latency_microbench.py")],
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp", LAT_ONLY=a.leg), cwd="/tmp", timeout=900, check=True)
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp", LAT_ONLY=a.leg, LAT_SCANS=str(a.scan)), cwd="/tmp", timeout=900, check=True)
         f = glob.glob(os.path.join(d, "**", "t_kernel_trace.csv"), recursive=True)[0]
         rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     finally:
@@ -54,7 +55,7 @@ def main():
     text = "\n".join(out)
     print(text)
     if a.out:
-        open(a.out, "w").write("# tools/single_scan_trace.py --leg %s: the last single-scan call of tools/latency_microbench.py (115 200-pt scan vs the 10 M-pt map)\n%s\n" % (a.leg, text))
+        open(a.out, "w").write("# tools/single_scan_trace.py --leg %s: the last single-scan call of tools/latency_microbench.py (115 200-pt scan %d vs the 10 M-pt map)\n%s\n" % (a.leg, a.scan, text))
 
 
 if __name__ == "__main__":
