@@ -306,12 +306,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(LOCGPU_N
             const double* m = R.mu;
             const double* I = R.info;
             const D3 e{qs.x - m[0], qs.y - m[1], qs.z - m[2]};
-            const double ev[3] = {e.x, e.y, e.z};
-            double res = 0.0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) res += ev[r] * I[3 * r + c] * ev[c];
+            // e.transpose() * v.info_ * e (ndt cpp:416) = (eᵀ·info)·e: the row vector first, then its dot product with e — 12 + 8 FP64
+            // operations in three short chains (a sum over the nine e_r·info_rc·e_c terms is 27 in one long chain)
+            const double t0 = (e.x * I[0] + e.y * I[3]) + e.z * I[6];
+            const double t1 = (e.x * I[1] + e.y * I[4]) + e.z * I[7];
+            const double t2 = (e.x * I[2] + e.y * I[5]) + e.z * I[8];
+            const double res = (t0 * e.x + t1 * e.y) + t2 * e.z;
             const bool accept = found[j] && !(isnan(res) || res > res_th);
             n_acc = accept ? n_acc + 1.0 : n_acc;
             esum.x = accept ? esum.x + e.x : esum.x;

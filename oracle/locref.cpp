@@ -613,9 +613,11 @@ public:
                         const NdtVoxel& v = it->second;
                         const V3 e = qs - v.mu;
                         const double ev[3] = {e.x, e.y, e.z};
-                        double res = 0;
-                        for (int r = 0; r < 3; ++r)
-                            for (int c = 0; c < 3; ++c) res += ev[r] * v.info[3 * r + c] * ev[c];
+                        // `e.transpose() * v.info_ * e` (ndt cpp:416) is (eᵀ·info)·e by C++ precedence: the 1×3 row vector first — Eigen
+                        // evaluates a nested product into a temporary — then its dot product with e
+                        double t[3];
+                        for (int c = 0; c < 3; ++c) t[c] = (ev[0] * v.info[c] + ev[1] * v.info[3 + c]) + ev[2] * v.info[6 + c];
+                        const double res = (t[0] * ev[0] + t[1] * ev[1]) + t[2] * ev[2];
                         if (std::isnan(res) || res > opt.res_outlier_th) continue;
                         const M3 Rh = mul(R, hat(q));
                         double J[3][6];
@@ -669,6 +671,8 @@ public:
                     const NdtVoxel& v = it->second->second;
                     const V3 e = qs - v.mu;
                     const double ev[3] = {e.x, e.y, e.z};
+                    // here the chi² test is formed as e·(info·e): info·e is what the err term below needs anyway (ndt cpp:308 writes the same
+                    // `e.transpose() * v.info_ * e` as the direct variant: the two groupings differ by rounding only, and only in this test)
                     double ie[3];
                     for (int r = 0; r < 3; ++r) ie[r] = (v.info[3 * r] * ev[0] + v.info[3 * r + 1] * ev[1]) + v.info[3 * r + 2] * ev[2];
                     const double res = (ev[0] * ie[0] + ev[1] * ie[1]) + ev[2] * ie[2];
