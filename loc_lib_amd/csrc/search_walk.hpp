@@ -184,9 +184,8 @@ __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, 
 #pragma unroll
         for (int j = 0; j < K; ++j) c[j] = x < d[j];
         if (K >= 2) {
-            const float gap = d[K - 1] - d[K - 2];
-            const float xt = gap == 0.0f ? x : __builtin_inff();
-            slow = xt < d[K - 1] ? 1u : slow;
+            const float gap = d[K - 1] - d[K - 2];  // inf − inf = NaN: an empty set is not a tie
+            slow = (gap == 0.0f) & c[K - 1] ? 1u : slow;  // the AND of two lane masks is scalar work
         }
 #pragma unroll
         for (int j = K - 1; j >= 1; --j) {
@@ -198,7 +197,7 @@ __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, 
         {
             const uint32_t here = id[0];
             id[0] = c[0] ? cur : here;
-            d[0] = __builtin_fminf(d[0], x);
+            d[0] = c[0] ? x : d[0];  // = fminf(d[0], x) without its canonicalising v_max (x is never NaN here: `sane`)
         }
         const int nbound = (int)__float_as_uint(-(d[K - 1] * alpha));
         const int nb = is_leaf ? nbound : (int)0x80000000u;
