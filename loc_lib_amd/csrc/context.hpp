@@ -106,6 +106,9 @@ struct locgpu_batch {
     uint32_t* d_redo_list2 = nullptr;      // [pitch], allocated on first use of the grid search
     uint32_t* d_grid_qkey = nullptr;       // [pitch] grid search: tile of each query
     uint2* d_grid_sorted = nullptr;        // [pitch] grid search: {query, tile} in tile order
+    uint32_t* d_grid_tile_count = nullptr; // [grid_tocc_cap + 1] grid search: queries per occupied tile of this batch's iteration
+    void* d_grid_scan_temp = nullptr;      // [grid_scan_cap] workspace of the scan over them
+    size_t grid_tocc_cap = 0, grid_scan_cap = 0;
     // hipGraph of {H2D state, max_iteration × (search, fit+accumulate, solve), D2H state}, keyed by the launch parameters
     hipGraphExec_t graph_exec = nullptr;       // {H2D state, first chunk of iterations, D2H state}
     hipGraphExec_t graph_exec_next = nullptr;  // {further chunk, D2H state}

@@ -490,17 +490,17 @@ static bool search_grid_k(const GridView& grid, const GridDev& g, const SearchAr
     // work lists: redo_list2 = queries for the fast tree traversal, redo_list = what that hands to the exact redo kernel
     (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);
     (void)hipMemsetAsync(a.redo_count2, 0, sizeof(unsigned int), s);
-    (void)hipMemsetAsync(grid.tile_count, 0, ((size_t)grid.n_tocc + 1) * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(sc.tile_count, 0, ((size_t)grid.n_tocc + 1) * sizeof(uint32_t), s);
     hipLaunchKernelGGL((grid_bin_count_kernel<K>), blocks, dim3(kBlock), 0, s, g, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.skip_nonfinite, sc.qkey,
-                       grid.tile_count, a.redo_list2, a.redo_count2, a.search_stats);
+                       sc.tile_count, a.redo_list2, a.redo_count2, a.search_stats);
     size_t tb = grid.scan_temp_bytes;
-    if (prim::exclusive_sum(grid.scan_temp, tb, grid.tile_count, grid.tile_count, (int)(grid.n_tocc + 1), s) != hipSuccess) return false;
-    hipLaunchKernelGGL(grid_bin_scatter_kernel, blocks, dim3(kBlock), 0, s, a.counts, a.st, a.max_n, sc.qkey, grid.tile_count, sc.sorted);
+    if (prim::exclusive_sum(sc.scan_temp, tb, sc.tile_count, sc.tile_count, (int)(grid.n_tocc + 1), s) != hipSuccess) return false;
+    hipLaunchKernelGGL(grid_bin_scatter_kernel, blocks, dim3(kBlock), 0, s, a.counts, a.st, a.max_n, sc.qkey, sc.tile_count, sc.sorted);
     // after the scatter tile_count[t] = end of tile t's queries; the last entry (never incremented) still holds the total
     const size_t total_q = (size_t)a.max_n * a.n_scans;
     const unsigned waves = (unsigned)std::min<size_t>((total_q + kRangeQ - 1) / kRangeQ, 256u * 8u);
     static const int exp_flags = [] { const char* e = getenv("LOCGPU_GRID_EXP"); return e ? atoi(e) : 0; }();  // timing experiments only (results wrong)
-    hipLaunchKernelGGL((grid_tile_search_kernel<K>), dim3(waves), dim3(64), 0, s, g, sc.sorted, grid.tile_count + grid.n_tocc, a.src, a.st, a.nn, a.nn_pitch,
+    hipLaunchKernelGGL((grid_tile_search_kernel<K>), dim3(waves), dim3(64), 0, s, g, sc.sorted, sc.tile_count + grid.n_tocc, a.src, a.st, a.nn, a.nn_pitch,
                        a.max_n, a.redo_list2, a.redo_count2, exp_flags);
     return launch_icp_search_list(a, a.redo_list2, a.redo_count2, s);  // a.alpha_eff = 1: exact pruning
 }

@@ -39,7 +39,7 @@ struct GridView {
     float origin[3] = {0, 0, 0};
     float cell = 1.f, inv_cell = 1.f, slack = 0.f;
     size_t num_points = 0, num_cells = 0, bytes = 0;
-    // per-iteration query binning (scratch owned by the context)
+    // per-iteration query binning: what a batch's scratch needs (GridSearchScratch); the context's own copy serves locgpu_knn
     uint32_t* tile_count = nullptr;  // [n_tocc + 1]
     void* scan_temp = nullptr;
     size_t scan_temp_bytes = 0;
@@ -62,6 +62,10 @@ void grid_free(GridBuffers& buf);
 struct GridSearchScratch {  // per batch: the queries of one iteration, binned by tile
     uint32_t* qkey;     // [pitch] tile key of query gi (kEmptyCell: not binned)
     uint2* sorted;      // [pitch] {gi, tile key} in tile order
+    // per-tile query counts and the scan's workspace: per BATCH as well — alignments of several batches run at once on different
+    // streams (a context-wide array here was overwritten by the batch next door: a memory fault with three alignments in flight)
+    uint32_t* tile_count;  // [n_tocc + 1]
+    void* scan_temp;       // [GridView::scan_temp_bytes]
 };
 
 // Search stage of one GN iteration in grid mode: bin by tile → tile kernel (LDS-staged candidate blocks) → ring walk for the

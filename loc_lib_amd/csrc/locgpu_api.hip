@@ -148,6 +148,8 @@ void locgpu::free_batch(locgpu_batch* b) {
     if (b->d_redo_list2) (void)hipFree(b->d_redo_list2);
     if (b->d_grid_qkey) (void)hipFree(b->d_grid_qkey);
     if (b->d_grid_sorted) (void)hipFree(b->d_grid_sorted);
+    if (b->d_grid_tile_count) (void)hipFree(b->d_grid_tile_count);
+    if (b->d_grid_scan_temp) (void)hipFree(b->d_grid_scan_temp);
     if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
     if (b->graph_exec_next) (void)hipGraphExecDestroy(b->graph_exec_next);
     if (b->h_src) (void)hipHostFree(b->h_src);
@@ -794,7 +796,7 @@ bool IterLauncher::launch(int do_update) {
             }
             sa.touched = ctx->touched_words ? ctx->d_touched : nullptr;
         }
-        const GridSearchScratch gsc{b->d_grid_qkey, b->d_grid_sorted};
+        const GridSearchScratch gsc{b->d_grid_qkey, b->d_grid_sorted, b->d_grid_tile_count, b->d_grid_scan_temp};
         const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, gsc, s) : launch_icp_search(sa, s);
         if (!ok_search) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
         if (sa.touched) launch_count_touched(sa.touched, (ctx->tree_slots + 2 + 31) / 32, sa.visit_totals, s);
@@ -904,9 +906,27 @@ static int batch_ready(locgpu_ctx* ctx, locgpu_batch* b) {
 }
 
 static int ensure_grid_lists(locgpu_ctx* ctx, locgpu_batch* b, float alpha_eff) {
-    if (alpha_eff < 0.f && !b->d_grid_qkey) {
+    if (alpha_eff >= 0.f) return LOCGPU_OK;
+    if (!b->d_grid_qkey) {
         LOCGPU_HIP(ctx, hipMalloc((void**)&b->d_grid_qkey, b->pitch * sizeof(uint32_t)));
         LOCGPU_HIP(ctx, hipMalloc((void**)&b->d_grid_sorted, b->pitch * sizeof(uint2)));
+    }
+    // the binning's per-tile counts and scan workspace are the batch's own as well (several alignments run at once); sized by the
+    // current target's grid — a new target may have more occupied tiles
+    const size_t tocc = ctx->grid.n_tocc, scan = std::max<size_t>(ctx->grid.scan_temp_bytes, 1);
+    if (!b->d_grid_tile_count || b->grid_tocc_cap < tocc) {
+        LOCGPU_HIP(ctx, hipStreamSynchronize(b->stream));
+        if (b->d_grid_tile_count) (void)hipFree(b->d_grid_tile_count);
+        b->d_grid_tile_count = nullptr;
+        LOCGPU_HIP(ctx, hipMalloc((void**)&b->d_grid_tile_count, (tocc + 1) * sizeof(uint32_t)));
+        b->grid_tocc_cap = tocc;
+    }
+    if (!b->d_grid_scan_temp || b->grid_scan_cap < scan) {
+        LOCGPU_HIP(ctx, hipStreamSynchronize(b->stream));
+        if (b->d_grid_scan_temp) (void)hipFree(b->d_grid_scan_temp);
+        b->d_grid_scan_temp = nullptr;
+        LOCGPU_HIP(ctx, hipMalloc(&b->d_grid_scan_temp, scan));
+        b->grid_scan_cap = scan;
     }
     return LOCGPU_OK;
 }

@@ -892,14 +892,19 @@ def test_align_begin_end_two_batches_in_flight(gpu_ctx, api, small_world):
     bb.close()
 
 
-def test_four_alignments_in_flight_over_three_streams(gpu_ctx, api, small_world):
+@pytest.mark.parametrize("search", ["tree", "grid_exact"])
+def test_four_alignments_in_flight_over_three_streams(gpu_ctx, api, small_world, search):
     """Batches are dealt to the context's three compute streams in turn; a fourth shares a stream with the first. Four alignments
-    begun back to back (ICP, ragged scans, different poses) and ended in a scrambled order give the blocking calls' poses bit for bit."""
+    begun back to back (ICP, ragged scans, different poses) and ended in a scrambled order give the blocking calls' poses bit for bit
+    — with the reference-default tree search and with the exact grid search, whose per-iteration binning scratch was once the
+    context's (round 5: `bench.py --search grid`, three alignments in flight, died of a memory fault; it is the batch's now)."""
     m = small_world["map"]
     s = small_world["scan10k"]
     pose = small_world["init_pose"]
     gpu_ctx.icp_set_target(m)
     opts = api.icp_opts(method=api.P2PLANE)
+    if search == "grid_exact":
+        opts.search_mode = api.SEARCH_GRID_EXACT
     sets = [[s, s[:7000]], [s[::2], s[:9000]], [s[100:4100], s[::3]], [s[5:8005], s[:2500]]]
     inits = []
     for i in range(4):

@@ -1,5 +1,5 @@
 # The ONE entry point that refreshes every profiles/r05_* artefact on one box after the last kernel change:
-#     gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh'
+#     gpurun --timeout 3600 -- 'bash tools/refresh_profiles.sh'
 # Results land in gpurun_out/final (copy what is to be judged into profiles/ as r05_<name>). Every command has its own timeout: a hung
 # kernel must not eat the box. Under rocprofv3 the program itself follows `--` (never a shell or env wrapper).
 set -x
@@ -20,6 +20,9 @@ done
 timeout 300 python bench.py --scaling strong --total-scans 32 --steps 20 --warmup 3 --no-cpu-baseline --traffic none 2>/dev/null | line > $O/bench_strong_1rank_32_pool_20steps_line.json
 timeout 300 python bench.py --scaling strong --total-scans 256 --steps 20 --warmup 5 --no-cpu-baseline --traffic none 2>/dev/null | line > $O/bench_strong_1rank_256_line.json
 timeout 600 python bench.py --scaling strong --total-scans 32 --steps 160 --warmup 8 --no-cpu-baseline 2>/dev/null | line > $O/bench_strong_1rank_32_pool_counters_line.json
+# ---- SetEnableANN(false): the exact search through the tree and through the cell grid (K1b, frozen), with live counters
+timeout 600 python bench.py --search tree_exact --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | line > $O/bench_tree_exact_line.json
+timeout 600 python bench.py --search grid --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | line > $O/bench_grid_line.json
 # ---- direct NDT: the line with live counters (row 3b), kernel stats below
 timeout 600 python bench.py --method ndt --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | line > $O/bench_ndt_line.json
 timeout 400 python3 tools/collect_pmc.py --out $O/pmc_ndt_kernel.md --scans 64 --method ndt > /dev/null 2>&1
@@ -31,6 +34,8 @@ timeout 1800 python3 tests/perf/baseline_table.py --out $O/baseline_table.json >
 timeout 1500 python3 tests/perf/defaults_table.py --out $O/defaults_table.json > $O/defaults_table.md 2>$O/defaults_table.err
 timeout 300 python3 tools/iter_trace.py --out $O/iteration_trace.txt > /dev/null 2>&1
 timeout 300 python3 tools/single_scan_trace.py --out $O/single_scan_trace.txt > /dev/null 2>&1
+timeout 300 python3 tools/single_scan_trace.py --scan 2 --out $O/single_scan_trace_scan2.txt > /dev/null 2>&1   # a scan whose longest traversal is twice scan 11's
+timeout 200 python tools/latency_detail.py > $O/latency_detail.txt 2>/dev/null
 timeout 300 python3 tools/stream_trace.py --mode 0 --window-us 1500 --out $O/stream_trace_sequential.txt > /dev/null 2>&1
 timeout 300 python3 tools/stream_trace.py --mode 1 --window-us 1500 --out $O/stream_trace_two_stage.txt > /dev/null 2>&1
 (timeout 120 ./tools/ubench/tree_build_bench 35133 300; LOCGPU_BUILD_TIMES=1 timeout 60 ./tools/ubench/tree_build_bench 35133 3 2>&1 | tail -4; LOCGPU_BUILD_THREADS=1 timeout 120 ./tools/ubench/tree_build_bench 35133 100; timeout 200 ./tools/ubench/tree_build_bench 10000000 3) > $O/tree_build.txt 2>&1
@@ -45,6 +50,7 @@ stats() {  # stats <name> <bench args…>
 stats bench --steps 20 --warmup 5
 stats bench_pipeline1 --steps 20 --warmup 5 --pipeline 1   # ONE alignment in flight: launch durations that do not overlap — what roofline.avg_launch_ms must agree with
 stats bench_ndt --method ndt --steps 20 --warmup 5 --pipeline 1
+stats bench_grid --search grid --steps 10 --warmup 3 --pipeline 1
 stats bench_strong_1rank_32_pool --scaling strong --total-scans 32 --steps 160 --warmup 8 --pool-lanes 1
 cd $R
 # ---- parity at length
