@@ -210,8 +210,16 @@ int upload_start(locgpu_batch* b, const void* const* srcs, const size_t* counts,
     // A caller with several alignments in flight rotates depth + 1 batches (bench.py) — the copy always goes to an idle one.
     // No ordering behind the batch's compute stream is needed beyond that: an ended alignment leaves its stream synchronised
     // (align_finish synchronises it on its error paths as well) — or, a paced one-scan alignment, with at most a few launches
-    // queued that return on the scan's `done` flag before they read the counts or the points.
+    // queued that return on the scan's `done` flag before they read the counts or the points (and the copies are ordered behind
+    // them all the same, below).
     if (b->pending.active) return fail(ctx, LOCGPU_ERR_INVALID, "batch upload: an alignment of this batch has been begun and not finished");
+    if (b->paced_tail) {
+        // belt and braces for the idle launches a paced alignment may have left queued: the copies go behind them
+        b->paced_tail = false;
+        if (!b->tail_ev && !hip_ok(ctx, hipEventCreateWithFlags(&b->tail_ev, hipEventDisableTiming), "batch upload: hipEventCreate")) return LOCGPU_ERR_NO_DEVICE;
+        if (!hip_ok(ctx, hipEventRecord(b->tail_ev, b->stream), "batch upload: hipEventRecord") ||
+            !hip_ok(ctx, hipStreamWaitEvent(ctx->copy_stream, b->tail_ev, 0), "batch upload: hipStreamWaitEvent")) return LOCGPU_ERR_NO_DEVICE;
+    }
     const int rc = enqueue(b, b->upl, srcs, counts, stride_bytes, b->n_scans, nullptr, nullptr);
     if (rc == LOCGPU_OK)
         for (int s = 0; s < b->n_scans; ++s) b->counts[s] = (int)counts[s];

@@ -125,6 +125,8 @@ struct locgpu_batch {
     unsigned long long* h_post = nullptr;
     static constexpr int kPostWord = 16;  // in 8-byte words: behind the record, 16-byte aligned
     unsigned int post_call = 0;
+    bool paced_tail = false;       // the last alignment was paced: up to pace_ahead idle launches may still be queued on `stream`
+    hipEvent_t tail_ev = nullptr;  // ... behind which the next upload's copies are ordered (batch_upload.hip)
     double* h_hb = nullptr;                // pinned
     int* h_active = nullptr;               // pinned, [n_scans]: local indices of the scans still open at the last chunk boundary
     int* d_active = nullptr;               // its device copy (see SearchArgs::active)

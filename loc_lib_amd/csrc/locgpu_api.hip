@@ -155,6 +155,7 @@ void locgpu::free_batch(locgpu_batch* b) {
     if (b->h_src) (void)hipHostFree(b->h_src);
     if (b->h_state) (void)hipHostFree(b->h_state);
     if (b->h_post) (void)hipHostFree(b->h_post);
+    if (b->tail_ev) (void)hipEventDestroy(b->tail_ev);
     if (b->h_hb) (void)hipHostFree(b->h_hb);
     if (b->h_active) (void)hipHostFree(b->h_active);
     if (b->d_active) (void)hipFree(b->d_active);
@@ -1134,6 +1135,7 @@ static int align_finish(locgpu_ctx* ctx, locgpu_batch* b, double* out_poses, loc
             }
             if (rc != LOCGPU_OK) { (void)hipStreamSynchronize(b->stream); return rc; }
         }
+        b->paced_tail = true;
     }
     while (!P.paced && P.prm.max_iteration > 0) {
         LOCGPU_HIP(ctx, hipStreamSynchronize(b->stream));
