@@ -1083,7 +1083,8 @@ static int paced_wait(locgpu_ctx* ctx, locgpu_batch* b, int seen, unsigned long 
     }
 }
 
-static int align_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt) {
+static int align_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt,
+                       bool blocking = false) {
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
     locgpu_batch::Pending& P = b->pending;
     if (P.active) return fail(ctx, LOCGPU_ERR_INVALID, "align: an alignment of this batch has been begun and not finished");
@@ -1100,7 +1101,8 @@ static int align_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_pose
     if (!ndt && !b->counters_clean) LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 4 * sizeof(unsigned int), b->stream));
     b->counters_clean = false;  // until this alignment has run to its end
     if (P.graph) { const int rc = ensure_graphs(ctx, b, prm, k, alpha_eff, ndt); if (rc != LOCGPU_OK) return rc; }
-    P.paced = !P.graph && b->n_total == 1 && !b->sharded && !ctx->profile && !ctx->count_visits && prm.max_iteration > 0 && pace_ahead() > 0 && (ndt || alpha_eff >= 0.f);
+    // (a blocking call only: between a begin and its end the host is elsewhere, and a chunk keeps the GPU busy meanwhile)
+    P.paced = blocking && !P.graph && b->n_total == 1 && !b->sharded && !ctx->profile && !ctx->count_visits && prm.max_iteration > 0 && pace_ahead() > 0 && (ndt || alpha_eff >= 0.f);
     if (P.paced) {
         if (!b->h_post) {
             LOCGPU_HIP(ctx, hipHostMalloc((void**)&b->h_post, 256, hipHostMallocCoherent));
@@ -1166,7 +1168,7 @@ static int align_finish(locgpu_ctx* ctx, locgpu_batch* b, double* out_poses, loc
 
 static int run_align(locgpu_ctx* ctx, locgpu_batch* b, const double* init_poses, const GnParams& prm, int k, float alpha_eff, bool ndt,
                      double* out_poses, locgpu_align_stats* stats) {
-    const int rc = align_begin(ctx, b, init_poses, prm, k, alpha_eff, ndt);
+    const int rc = align_begin(ctx, b, init_poses, prm, k, alpha_eff, ndt, /*blocking*/ true);
     return rc != LOCGPU_OK ? rc : align_finish(ctx, b, out_poses, stats);
 }
 
