@@ -516,10 +516,11 @@ def main():
         t_search = prof["search_ms"] * prof["search_n"] / n_extra      # ms per step (profiled steps)
         t_accum = prof["accum_ms"] * prof["accum_n"] / n_extra
         t_solve = prof["solve_ms"] * prof["solve_n"] / n_extra
-        search_kernels = ("icp_search_grid",) if args.search == "grid" else ("icp_search_walk_kernel", "icp_search_walk_list_kernel", "icp_search_redo_kernel")
+        search_kernels = (("grid_bin_count_kernel", "grid_bin_scatter_kernel", "grid_tile_search_kernel", "icp_search_walk_list_kernel", "icp_search_redo_kernel")
+                          if args.search == "grid" else ("icp_search_walk_kernel", "icp_search_walk_list_kernel", "icp_search_redo_kernel"))
         accum_kernels = ("ndt_accum_kernel",) if method < 0 else ("icp_%s_accum_kernel" % dict(p2plane="plane", p2line="line", p2p="point")[args.method], "icp_plane_refit_kernel")
         if t_search >= t_accum:
-            kname, kset, kbytes, kt, kn, kavg = ("icp_search_grid_kernel(+pass2+redo)" if args.search == "grid" else "icp_search_walk_kernel(+deep pass+redo)"), search_kernels, search_bytes, t_search, prof["search_n"], prof["search_ms"]
+            kname, kset, kbytes, kt, kn, kavg = ("grid_tile_search_kernel(+binning+leftover walk+redo)" if args.search == "grid" else "icp_search_walk_kernel(+deep pass+redo)"), search_kernels, search_bytes, t_search, prof["search_n"], prof["search_ms"]
         else:
             kname, kset, kbytes, kt, kn, kavg = accum_kernels[0], accum_kernels, accum_bytes, t_accum, prof["accum_n"], prof["accum_ms"]
         launches_per_step = kn / n_extra

@@ -61,9 +61,6 @@ __device__ __forceinline__ float4 load_once(const float4* __restrict__ p) {
 // K1: the traversal of search_walk.hpp. One-wave workgroups; dynamic LDS = DF rows x LANES x 8 B (the stack is the ONLY LDS of the
 // kernel: a row below its bottom must lie outside the allocation). `dummy` = slot of the sentinel leaf.
 // Every lane of the wave must call walk_query (wave-wide ballots inside); a lane without a query passes valid = false.
-#ifndef LOCGPU_WALK_PF
-#define LOCGPU_WALK_PF 0
-#endif
 template <int K, int ROWB, bool STAMP = false>
 __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const uint2* __restrict__ tree, Walk<K>& w, bool valid, float alpha_eff, int T, uint32_t dummy,
                                            uint32_t col_addr, int cap) {
@@ -77,7 +74,7 @@ __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const ui
     } else {
         w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = valid ? 1u : 0u;
     }
-    walk_rounds_capped<K, ROWB, 2, STAMP, (ROWB == 16 * 8 ? LOCGPU_WALK_PF : 0)>(rsrc, w, alpha_eff, dummy, col_addr, cap);
+    walk_rounds_capped<K, ROWB, 2, STAMP>(rsrc, w, alpha_eff, dummy, col_addr, cap);
 #pragma unroll
     for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;  // equal distances in the final set: heap pop order is layout-dependent
 }

@@ -159,7 +159,7 @@ __device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, const 
 //
 // A lane is finished when cur == dummy && avail == 0. Latency: a pop only happens on a leaf, and a lane on a leaf pushes nothing — so
 // the four youngest stack rows are read at the TOP of the round, next to the node load, instead of behind it.
-template <int K, int ROWB, int C, bool STAMP = false, int PF = 0>
+template <int K, int ROWB, int C, bool STAMP = false>
 __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, Walk<K>& w, float alpha, uint32_t dummy, uint32_t col_addr, int cap) {
     const float qx = w.qx, qy = w.qy, qz = w.qz;
     uint32_t cur = w.cur;
@@ -171,7 +171,6 @@ __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, 
     for (int j = 0; j < K; ++j) { d[j] = w.d[j]; id[j] = w.id[j]; }
     uint32_t slow = w.slow, c3n = w.c3n;
     u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
-    uint32_t pf[C > 0 ? C : 1] = {};  // PF: the far children pushed in the last round, being fetched (see the internal steps)
     do {
         if (STAMP) { my_rounds += (cur != dummy || avail > 0) ? 1u : 0u; all_rounds++; }
         const bool is_leaf = n.y >= 0xC0000000u;
@@ -228,12 +227,6 @@ __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, 
         avail = deep ? 0 : avail - used;
         // a lane that popped loads its new node; one that was not on a leaf still holds its internal node in n
         if (moved) n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
-        if (PF) {
-            // the last round's prefetches end here: loads return in order, and the steps below wait for the node load above anyway
-#pragma unroll
-            for (int step = 0; step < C; ++step) asm volatile("" ::"v"(pf[step]));
-        }
-        const bool pf_on = PF == 1 || (PF > 1 && __popcll(__ballot(cur != dummy || avail > 0)) <= PF);
 #pragma unroll
         for (int step = 0; step < C; ++step) {
             if (n.y < 0xC0000000u) {
@@ -249,14 +242,6 @@ __device__ __forceinline__ void walk_rounds_capped(__amdgpu_buffer_rsrc_t rsrc, 
                 avail += (int)nd2 < nbound ? 1 : 0;
                 cur = go_left ? cur1 : right;
                 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
-                if (PF && pf_on) {
-                    // PF (the one-scan kernel, whose launch lasts as long as its longest traversal): a far child that stays on the stack
-                    // is fetched now, behind the node load, so that its pop finds it in the cache instead of waiting for L2 / HBM. A
-                    // right child lies a whole left subtree away; a left child shares its parent's line and needs nothing.
-                    const uint32_t far_slot = go_left ? right : cur1;
-                    const uint32_t want = (((int)nd2 < nbound) & go_left) ? far_slot : dummy;
-                    pf[step] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(want << 3), 0, 0);
-                }
             }
         }
     } while (__ballot(cur != dummy || avail > 0) != 0ull);
