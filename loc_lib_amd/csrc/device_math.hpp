@@ -16,7 +16,8 @@ __device__ __forceinline__ D3 operator+(const D3& a, const D3& b) { return {a.x 
 __device__ __forceinline__ D3 operator-(const D3& a, const D3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ D3 operator*(double s, const D3& a) { return {s * a.x, s * a.y, s * a.z}; }
 // Eigen's fixed-size-3 reduction order: x0 + (x1 + x2).
-__device__ __forceinline__ double dot3(const D3& a, const D3& b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+// Vector3d reductions as the reference's binary evaluates them: (x + y) + z (one SSE2 packet, then the scalar tail: read off LocUtils/libs/libLocUtils.so, e.g. 0x5869a)
+__device__ __forceinline__ double dot3(const D3& a, const D3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ D3 cross3(const D3& a, const D3& b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                         const double* R = st[scan].R;
                         double nR[3];
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) nR[c] = (-n3.x * R[c] + -n3.y * R[3 + c]) + -n3.z * R[6 + c];
+                        for (int c = 0; c < 3; ++c) nR[c] = -n3.x * R[c] + (-n3.y * R[3 + c] + -n3.z * R[6 + c]);  // the reference binary's order (libLocUtils.so 0x58745-0x58801)
                         J[0][0] = nR[1] * q.z - nR[2] * q.y;
                         J[0][1] = nR[2] * q.x - nR[0] * q.z;
                         J[0][2] = nR[0] * q.y - nR[1] * q.x;
@@ -662,9 +662,8 @@ __device__ __forceinline__ void gn_update(const double* tot, PoseState& ps, cons
             for (int i = 0; i < 6; ++i) dx[i] = dx[i] / 16;  // dx = H.inverse()/16 * err (icp cpp:287)
         se3_apply_update(ps.q, ps.t, dx);
         quat_to_R(ps.q, ps.R);
-        double n2 = 0.0;
-        for (int i = 0; i < 6; ++i) n2 += dx[i] * dx[i];
-        const double nrm = sqrt(n2);
+        // dx.norm() as the reference's binary sums it: three packets p0 + (p1 + p2), then low + high (libLocUtils.so 0x5b113-0x5b185)
+        const double nrm = sqrt((dx[0] * dx[0] + (dx[2] * dx[2] + dx[4] * dx[4])) + (dx[1] * dx[1] + (dx[3] * dx[3] + dx[5] * dx[5])));
         ps.last_dx_norm = nrm;
         if (nrm < prm.eps) { ps.converged = 1; ps.done = 1; }
     }

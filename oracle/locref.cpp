@@ -215,7 +215,7 @@ public:
                 if (std::fabs(dis) > opt.max_plane_distance) continue;
                 const M3 hq = hat(q);
                 double nR[3];
-                for (int c = 0; c < 3; ++c) nR[c] = (-n3.x * R(0, c) + -n3.y * R(1, c)) + -n3.z * R(2, c);
+                for (int c = 0; c < 3; ++c) nR[c] = -n3.x * R(0, c) + (-n3.y * R(1, c) + -n3.z * R(2, c));  // the binary: 0x58761-0x58801 (PINNING.md)
                 double J[1][6];
                 for (int c = 0; c < 3; ++c) J[0][c] = (nR[0] * hq(0, c) + nR[1] * hq(1, c)) + nR[2] * hq(2, c);
                 J[0][3] = n3.x; J[0][4] = n3.y; J[0][5] = n3.z;
@@ -240,9 +240,7 @@ public:
             if (ok) {
                 lu6_det_solve(H, err, dx);
                 apply_update(pose, dx);
-                double n2 = 0;
-                for (int i = 0; i < 6; ++i) n2 += dx[i] * dx[i];
-                if (std::sqrt(n2) < opt.eps) break;
+                if (norm6(dx) < opt.eps) break;
             }
         }
         result = pose;
@@ -350,7 +348,7 @@ public:
                 // J = [ -n3^T R hat(q) | n3^T ]
                 const M3 hq = hat(q);
                 double nR[3];
-                for (int c = 0; c < 3; ++c) nR[c] = (-n3.x * R(0, c) + -n3.y * R(1, c)) + -n3.z * R(2, c);
+                for (int c = 0; c < 3; ++c) nR[c] = -n3.x * R(0, c) + (-n3.y * R(1, c) + -n3.z * R(2, c));  // the binary: 0x58761-0x58801 (PINNING.md)
                 double J[1][6];
                 for (int c = 0; c < 3; ++c) J[0][c] = (nR[0] * hq(0, c) + nR[1] * hq(1, c)) + nR[2] * hq(2, c);
                 J[0][3] = n3.x; J[0][4] = n3.y; J[0][5] = n3.z;
@@ -387,9 +385,7 @@ public:
                 if (opt.method == 0)
                     for (int i = 0; i < 6; ++i) dx[i] = dx[i] / 16;  // dx = H.inverse()/16 * err (icp cpp:287)
                 apply_update(pose, dx);
-                double n2 = 0;
-                for (int i = 0; i < 6; ++i) n2 += dx[i] * dx[i];
-                if (std::sqrt(n2) < opt.eps) stop = true;
+                if (norm6(dx) < opt.eps) stop = true;
             }
             if (trace && iter < trace_cap) {
                 std::memcpy(trace[iter].H, H, sizeof(H));
@@ -643,9 +639,7 @@ public:
             std::memcpy(dx, x, sizeof(dx));
             if (trace && iter < trace_cap) std::memcpy(trace[iter].dx, dx, sizeof(dx));
             apply_update(pose, dx);
-            double n2 = 0;
-            for (int i = 0; i < 6; ++i) n2 += dx[i] * dx[i];
-            if (std::sqrt(n2) < opt.eps) break;
+            if (norm6(dx) < opt.eps) break;
         }
         result = pose;
         if (iters_out) *iters_out = iters;
@@ -704,9 +698,7 @@ public:
             lu6_det_solve(H, err, dx);
             if (trace && iter < trace_cap) std::memcpy(trace[iter].dx, dx, sizeof(dx));
             apply_update(pose, dx);
-            double n2 = 0;
-            for (int i = 0; i < 6; ++i) n2 += dx[i] * dx[i];
-            if (std::sqrt(n2) < opt.eps) break;
+            if (norm6(dx) < opt.eps) break;
         }
         result = pose;
         if (iters_out) *iters_out = iters;

@@ -8,9 +8,16 @@
 // tests or fixtures for this path and cannot be compiled in this image (Eigen/Sophus/PCL
 // absent). The third-party arithmetic it leans on is restated here from the
 // libraries' published algorithms:
+// Round 5: the evaluation ORDER of the expressions that feed the reference's decisions (split rule,
+// result-set and expansion tests, correspondence gates, stop test) was read off the reference's own
+// prebuilt binary (LocUtils/libs/libLocUtils.so, never loaded or executed) and the restatement
+// corrected where it had guessed otherwise: oracle/PINNING.md lists every audited expression with
+// its address. That is inspection, not a comparison of outputs: "parity unpinned" stands.
 //   * Eigen 3.3.x (Ubuntu 18.04 ⇒ 3.3.4, unpinned by the reference's CMake):
-//       - fixed-size reductions (`squaredNorm`, `dot`) of length 3 use redux_novec_unroller,
-//         i.e. x0 + (x1 + x2)  (Eigen/src/Core/Redux.h);
+//       - 3-element reductions (`squaredNorm`, `dot`, `norm`): FLOAT vectors are not vectorised,
+//         x0 + (x1 + x2) (Redux.h unroller; kd-tree distances); DOUBLE vectors take one SSE2
+//         packet and the scalar tail, (x0 + x1) + x2 (gates of P2Plane / P2P / P2Line, FitPlane,
+//         FitLine) — both as compiled in the reference's binary;
 //       - Quaternion::_transformVector: uv = 2 (q.vec × v); v + w·uv + q.vec × uv;
 //       - Quaternion::toRotationMatrix;
 //       - 6×6 inverse()/determinant(): PartialPivLU;
@@ -34,7 +41,15 @@ inline V3 operator+(const V3& a, const V3& b) { return {a.x + b.x, a.y + b.y, a.
 inline V3 operator-(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline V3 operator*(double s, const V3& a) { return {s * a.x, s * a.y, s * a.z}; }
 // Eigen fixed-size-3 reduction order: x0 + (x1 + x2).
-inline double dot(const V3& a, const V3& b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+// Vector3d reductions (.dot, .squaredNorm, .norm) as the reference's own binary evaluates them: one SSE2 packet {x, y}, then the
+// scalar tail — (x + y) + z (oracle/PINNING.md: P2Plane `dis` at 0x5869a, FitPlane's residual at 0x79e65, P2P `dis2` at 0x57945 of
+// LocUtils/libs/libLocUtils.so). Vector3f reductions are not vectorised there: x + (y + z) (locref_kdtree.hpp).
+inline double dot(const V3& a, const V3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// dx.norm() of the 6-vector (icp cpp:295,333,371; ndt cpp:364,455): three packets summed p0 + (p1 + p2), then low + high
+// (PINNING.md: AlignP2Plane at 0x5b113-0x5b185)
+inline double norm6(const double* d) {
+    return std::sqrt((d[0] * d[0] + (d[2] * d[2] + d[4] * d[4])) + (d[1] * d[1] + (d[3] * d[3] + d[5] * d[5])));
+}
 inline V3 cross(const V3& a, const V3& b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
