@@ -530,27 +530,29 @@ __device__ __forceinline__ double lu6_det_solve_reg(const double* H, const doubl
 // (icp_registration.cpp:365-366) — Sophus SO3::exp with its small-angle Taylor branch and the
 // first-order renormalisation of the quaternion product.
 __device__ __host__ inline void se3_apply_update(double* q, double* t, const double* dx) {
-    const double theta_sq = dx[0] * dx[0] + (dx[1] * dx[1] + dx[2] * dx[2]);
+    // Sophus::SO3d::expAndTheta, the quaternion product and the renormalisation in the reference binary's own association
+    // (libLocUtils.so 0x66550, 0x5b00d-0x5b10f): theta = sqrt((x² + y²) + z²), Taylor branch iff theta < 1e-10
+    const double theta_sq = (dx[0] * dx[0] + dx[1] * dx[1]) + dx[2] * dx[2];
+    const double theta = sqrt(theta_sq);
     double imag, real;
-    if (theta_sq < 1e-10 * 1e-10) {
+    if (theta < 1e-10) {
         const double theta_po4 = theta_sq * theta_sq;
         imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
         real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
     } else {
-        const double theta = sqrt(theta_sq);
         const double half = 0.5 * theta;
         imag = sin(half) / theta;
         real = cos(half);
     }
     const double bx = imag * dx[0], by = imag * dx[1], bz = imag * dx[2], bw = real;
     const double ax = q[0], ay = q[1], az = q[2], aw = q[3];
-    double rw = aw * bw - ax * bx - ay * by - az * bz;
-    double rx = aw * bx + ax * bw + ay * bz - az * by;
-    double ry = aw * by + ay * bw + az * bx - ax * bz;
-    double rz = aw * bz + az * bw + ax * by - ay * bx;
-    const double sq = rx * rx + ry * ry + rz * rz + rw * rw;
+    double rx = (ay * bz + aw * bx) - (az * by - ax * bw);
+    double ry = (ay * bw + aw * by) + (az * bx - ax * bz);
+    double rz = (aw * bz - ay * bx) + (ax * by + az * bw);
+    double rw = (aw * bw - ay * by) - (ax * bx + az * bz);
+    const double sq = (rz * rz + rx * rx) + (rw * rw + ry * ry);
     if (sq != 1.0) {
-        const double scale = 2.0 / (1.0 + sq);
+        const double scale = 2.0 / (sq + 1.0);
         rx *= scale; ry *= scale; rz *= scale; rw *= scale;
     }
     q[0] = rx; q[1] = ry; q[2] = rz; q[3] = rw;

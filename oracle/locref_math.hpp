@@ -118,29 +118,31 @@ inline V3 transform(const SE3& T, const V3& v) {
 // (icp_registration.cpp:365-366: pose.so3() = pose.so3() * SO3::exp(dx.head<3>()); t += dx.tail<3>()).
 inline void apply_update(SE3& T, const double dx[6]) {
     const V3 w{dx[0], dx[1], dx[2]};
+    // Sophus::SO3d::expAndTheta as compiled in the reference's binary (0x66550; oracle/PINNING.md): theta = sqrt((x² + y²) + z²),
+    // the Taylor branch iff theta < 1e-10 (the comparison is on theta, not on its square)
     const double theta_sq = dot(w, w);
+    const double theta = std::sqrt(theta_sq);
     double imag, real;
-    if (theta_sq < 1e-10 * 1e-10) {
+    if (theta < 1e-10) {
         const double theta_po4 = theta_sq * theta_sq;
         imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
         real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
     } else {
-        const double theta = std::sqrt(theta_sq);
         const double half = 0.5 * theta;
         imag = std::sin(half) / theta;
         real = std::cos(half);
     }
     const double bx = imag * w.x, by = imag * w.y, bz = imag * w.z, bw = real;
     const double ax = T.qx, ay = T.qy, az = T.qz, aw = T.qw;
-    // Eigen quaternion product a*b.
-    double rw = aw * bw - ax * bx - ay * by - az * bz;
-    double rx = aw * bx + ax * bw + ay * bz - az * by;
-    double ry = aw * by + ay * bw + az * bx - ax * bz;
-    double rz = aw * bz + az * bw + ax * by - ay * bx;
-    // Sophus SO3 product: first-order renormalisation when the squared norm drifted.
-    const double sq = rx * rx + ry * ry + rz * rz + rw * rw;
+    // The quaternion product a*b in the association of the binary's SSE2 code (AlignP2Plane 0x5b00d-0x5b0bf: two packets, a swap
+    // and a sign mask), then Sophus' first-order renormalisation on the squared norm summed as (z² + x²) + (w² + y²) (0x5b0c3-0x5b10f)
+    double rx = (ay * bz + aw * bx) - (az * by - ax * bw);
+    double ry = (ay * bw + aw * by) + (az * bx - ax * bz);
+    double rz = (aw * bz - ay * bx) + (ax * by + az * bw);
+    double rw = (aw * bw - ay * by) - (ax * bx + az * bz);
+    const double sq = (rz * rz + rx * rx) + (rw * rw + ry * ry);
     if (sq != 1.0) {
-        const double scale = 2.0 / (1.0 + sq);
+        const double scale = 2.0 / (sq + 1.0);
         rx *= scale; ry *= scale; rz *= scale; rw *= scale;
     }
     T.qx = rx; T.qy = ry; T.qz = rz; T.qw = rw;
