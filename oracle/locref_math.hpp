@@ -40,7 +40,6 @@ struct V3 {
 inline V3 operator+(const V3& a, const V3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 inline V3 operator-(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline V3 operator*(double s, const V3& a) { return {s * a.x, s * a.y, s * a.z}; }
-// Eigen fixed-size-3 reduction order: x0 + (x1 + x2).
 // Vector3d reductions (.dot, .squaredNorm, .norm) as the reference's own binary evaluates them: one SSE2 packet {x, y}, then the
 // scalar tail — (x + y) + z (oracle/PINNING.md: P2Plane `dis` at 0x5869a, FitPlane's residual at 0x79e65, P2P `dis2` at 0x57945 of
 // LocUtils/libs/libLocUtils.so). Vector3f reductions are not vectorised there: x + (y + z) (locref_kdtree.hpp).
