@@ -3,6 +3,8 @@
 The reference ships no golden vectors ("parity unpinned"), so the oracle is checked against closed forms and
 against numpy: brute-force k-NN, numpy.linalg.svd plane/line fits, numpy solve, closed-form SE3 algebra.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -251,3 +253,21 @@ def test_flat_port_equals_reference_style(locref, synth, small_world):
             for i, w in enumerate(want):
                 np.testing.assert_array_equal(poses[i], w["pose"])
                 assert iters[i] == w["iters"]
+
+
+def test_oracle_keeps_the_orders_read_off_the_reference_binary(tmp_path):
+    """oracle/PINNING.md: `Vector3d` reductions are `(x + y) + z` and `dx.norm()` is `(d0² + (d2² + d4²)) + (d1² + (d3² + d5²))` in the
+    reference's own prebuilt binary (P2Plane `dis` 0x5869a, `FitPlane` 0x79e65, P2P `dis2` 0x57945, `AlignP2Plane` 0x5b113). Inputs on
+    which the other associations round differently hold the restatement to them (tests/cpp/oracle_orders.cpp, compiled with the
+    oracle's flags)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "oracle_orders")
+    r = subprocess.run(["g++", "-std=c++17", "-O3", "-ffp-contract=off", "-I", os.path.join(root, "oracle"),
+                        os.path.join(root, "tests", "cpp", "oracle_orders.cpp"), "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "oracle orders ok" in r.stdout, r.stdout + r.stderr
