@@ -504,7 +504,7 @@ def main():
         # roofline of the dominant kernel over the timed region (all launches, partially idle ones included)
         k = 1 if args.method == "p2p" else 5
         q = vc["queries"] if method >= 0 else gn_iters * pts_per_scan
-        search_bytes = q * 16 + vc["nodes"] * 16 + q * 4 * k            # src float4 + one 16-B slot pair per node visit + index lists
+        search_bytes = q * 12 + vc["nodes"] * 16 + vc["leaves"] * 12 + q * 4 * k  # N_q·(12 + 16·V̄_n + 12·V̄_l + 4k)
         if args.search == "grid":
             # SURVEY §8(d) exact/grid formula: 16·N_cand + N_q·(12 + 4k); N_cand (distinct leaves in the cells any query's final
             # search block touches) is bounded below by the leaves the queries actually return: use k·q/4 as a conservative stand-in
@@ -550,14 +550,22 @@ def main():
             f, w = stage_counter(kernels, "FETCH_SIZE"), stage_counter(kernels, "WRITE_SIZE")
             return int((2.0 * f + w) * 1024) if f is not None and w is not None else None  # both count KiB; gfx950 FETCH_SIZE counts half the bytes of wide reads
 
-        SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; a wave64 VALU (or FP64) instruction occupies its SIMD's issue port for 4 cycles
+        # 256 CUs x 4 SIMD-32 units at the nominal 2.4 GHz. /opt/skills/guides/MI355X_MICROARCH.md:53-54 ("A wave (64 lanes) ... issues each
+        # VALU instruction over 2 cycles (32 lanes/cycle x 2)"), :473 (`v_fma_f32` (wave64): 2 cyc throughput; 4 only for one wave alone
+        # on its SIMD) and :41 (peak FP32 vector 157.3 TF = 1024 SIMDs x 32 lanes x 2 flop x 2.4 GHz): a 32-bit wave64 VALU instruction
+        # costs its SIMD 2 issue cycles; an FP64 one 4 (78.6 TF FP64 vector = half the FP32 rate).
+        SIMDS, CLOCK_HZ, CYC_VALU32, CYC_FP64 = 1024, 2.4e9, 2.0, 4.0
+        FP64_COUNTERS = ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"]
 
-        def issue_frac(kernels, names, avg_ms):
-            v = [stage_counter(kernels, nm) for nm in names]
-            if any(x is None for x in v) or avg_ms <= 0:
-                return None, None
-            n_inst = sum(v)
-            return n_inst, n_inst * 4.0 / (SIMDS * CLOCK_HZ * avg_ms / 1e3)
+        def issue_frac(kernels, avg_ms):
+            """(all VALU instructions, FP64 ones among them, issue cycles they cost / issue cycles the chip has in avg_ms)."""
+            v = stage_counter(kernels, "SQ_INSTS_VALU")
+            f = [stage_counter(kernels, nm) for nm in FP64_COUNTERS]
+            if v is None or avg_ms <= 0:
+                return None, None, None
+            f64 = sum(x for x in f if x is not None)
+            cycles = (v - f64) * CYC_VALU32 + f64 * CYC_FP64
+            return v, f64, cycles / (SIMDS * CLOCK_HZ * avg_ms / 1e3)
 
         traffic, traffic_note = hbm_bytes(kset), counters_note
         if traffic is None and args.traffic != "none":
@@ -565,8 +573,8 @@ def main():
             if t2 is not None:
                 traffic, traffic_note = t2, "copied from the newest committed profiles/*traffic*.json of this workload (" + counters_note + ")"
         nominal_gbs = (kbytes / 1e9) / (kt / 1e3) if kt > 0 else 0.0
-        valu_n, valu_frac = issue_frac(kset, ["SQ_INSTS_VALU"], kavg)
-        ISSUE_PEAK = SIMDS * CLOCK_HZ / 4.0 / 1e9  # G wave64 VALU instructions per second the chip can issue at the nominal clock
+        valu_n, valu_f64, valu_frac = issue_frac(kset, kavg)
+        ISSUE_PEAK = SIMDS * CLOCK_HZ / CYC_VALU32 / 1e9  # G 32-bit wave64 VALU instructions per second the chip can issue at the nominal clock
         is_search = kset is search_kernels
         # The bound that binds. Both hot kernels are bound by vector-instruction issue, not by HBM (the tree traversal is a
         # cache-resident pointer chase: ~91 % of its node loads hit L1; its HBM traffic is a few per cent of the roofline), so
@@ -576,8 +584,10 @@ def main():
         roofline = dict(bound="valu_issue", kernel=kname,
                         achieved=(round(valu_n / (kavg / 1e3) / 1e9, 2) if valu_n and kavg > 0 else None), peak=round(ISSUE_PEAK, 1), unit="G wave64-VALU-inst/s",
                         frac=(round(valu_frac, 4) if valu_frac else None),
-                        clock_note="peak = 1024 SIMDs x 2.4 GHz (nominal) / 4 cycles per wave64 VALU instruction; under this load the chip holds about 1.95 GHz "
-                                   "(profiles/r04_pmc_kernels.md), i.e. frac / 0.81 of what it can issue at the clock it runs at",
+                        clock_note="peak = 1024 SIMD-32 units x 2.4 GHz (nominal) / 2 cycles per 32-bit wave64 VALU instruction (MI355X_MICROARCH.md:53-54, :473; "
+                                   "FP64 instructions priced at 4 cycles in frac); under this load the chip holds about 1.95 GHz, i.e. frac / 0.81 of what it can "
+                                   "issue at the clock it runs at; the kernel's own instruction mix sustains 2.45 cycles per instruction in isolation "
+                                   "(tools/ubench/issue_mix.hip)",
                         traffic=traffic,
                         hbm_frac=(round(traffic / (kavg / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and kavg > 0 else None),
                         hbm_peak_gbs=HBM_PEAK_GBS, traffic_source=traffic_note,
@@ -587,7 +597,7 @@ def main():
                                            "NOT met in HBM's own terms (see hbm_frac): the traversal does not need the bytes",
                         algorithmic_bytes_per_launch=int(kbytes / max(launches_per_step, 1)), avg_launch_ms=round(kavg, 5),
                         launches_per_step=launches_per_step,
-                        valu_insts_per_launch=(int(valu_n) if valu_n else None),
+                        valu_insts_per_launch=(int(valu_n) if valu_n else None), fp64_insts_per_launch=(int(valu_f64) if valu_f64 else None),
                         nodes_per_query=round(vc["nodes"] / max(q, 1), 2), leaves_per_query=round(vc["leaves"] / max(q, 1), 2))
         if method >= 0 and args.search != "grid" and is_search:
             # what the stage cannot avoid moving: every query's source point and index list once, and every tree slot any query of the
@@ -595,7 +605,8 @@ def main():
             roofline["compulsory_bytes"] = int((q * (16 + 4 * k) + vc["distinct_slots"] * 8) / max(launches_per_step, 1))
             roofline["lane_efficiency"] = round(lane_eff, 4) if lane_eff else None
             roofline["lane_efficiency_source"] = lane_note
-            roofline["note"] = ("valu_issue frac = SQ_INSTS_VALU x 4 cycles / (SIMDs x launch time) at the nominal clock; lane_efficiency = main-loop rounds the "
+            roofline["note"] = ("valu_issue frac = (32-bit VALU instructions x 2 + FP64 x 4 cycles) / (SIMDs x launch time) at the nominal clock: the kernel is "
+                                "LATENCY-bound (dependent node loads), well below its issue roofline; lane_efficiency = main-loop rounds the "
                                 "lanes need / rounds their waves run (a wave runs until its slowest lane is done)")
         # which BASELINE.json configuration the arguments amount to
         if strong:
@@ -641,15 +652,15 @@ def main():
             line["stamp"] = dict(lane_rounds=stamp["walked"], paid_rounds=stamp["replayed"])
         if method >= 0 and t_accum > 0:
             # the second kernel (fit + accumulate): algorithmic bytes of SURVEY §8(d) against HBM, its measured HBM traffic, and — what
-            # actually bounds it — its VALU and FP64 instruction counts against the issue rate (a wave64 instruction = 4 cycles of its SIMD)
+            # actually bounds it — its VALU and FP64 instruction counts against the issue rate (32-bit wave64 instruction = 2 cycles of its SIMD-32, FP64 = 4)
             a_gbs = (accum_bytes / 1e9) / (t_accum / 1e3)
             k2_traffic = hbm_bytes(accum_kernels)
             k2_avg = prof["accum_ms"]
-            f64_n, f64_frac = issue_frac(accum_kernels, ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"], k2_avg)
-            v_n, v_frac = issue_frac(accum_kernels, ["SQ_INSTS_VALU"], k2_avg)
-            line["roofline_k2"] = dict(bound="valu_issue (two thirds of it FP64)", kernel=accum_kernels[0],
-                                       achieved=(round(v_n / (k2_avg / 1e3) / 1e9, 2) if v_n and k2_avg > 0 else None), peak=round(SIMDS * CLOCK_HZ / 4.0 / 1e9, 1),
-                                       unit="G wave64-VALU-inst/s", frac=(round(v_frac, 4) if v_frac else None),
+            v_n, f64_n, v_frac = issue_frac(accum_kernels, k2_avg)
+            f64_frac = (f64_n * CYC_FP64 / (SIMDS * CLOCK_HZ * k2_avg / 1e3)) if f64_n and k2_avg > 0 else None
+            line["roofline_k2"] = dict(bound="valu_issue (FP64 instructions at 4 cycles, the others at 2)", kernel=accum_kernels[0],
+                                       achieved=(round(v_n / (k2_avg / 1e3) / 1e9, 2) if v_n and k2_avg > 0 else None), peak=round(SIMDS * CLOCK_HZ / CYC_FP64 / 1e9, 1),
+                                       unit="G wave64-VALU-inst/s (peak: all-FP64 stream)", frac=(round(v_frac, 4) if v_frac else None),
                                        fp64_issue_frac=(round(f64_frac, 4) if f64_frac else None),
                                        fp64_insts_per_launch=(int(f64_n) if f64_n else None), valu_insts_per_launch=(int(v_n) if v_n else None),
                                        ms_per_step=round(t_accum, 4), avg_launch_ms=round(k2_avg, 5), traffic=k2_traffic,

@@ -3,6 +3,7 @@
 #include "launch.hpp"
 #include "search_walk.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace locgpu {
@@ -61,7 +62,7 @@ __device__ __forceinline__ float4 load_once(const float4* __restrict__ p) {
 // K1: the traversal of search_walk.hpp. One-wave workgroups; dynamic LDS = DF rows x LANES x 8 B (the stack is the ONLY LDS of the
 // kernel: a row below its bottom must lie outside the allocation). `dummy` = slot of the sentinel leaf.
 // Every lane of the wave must call walk_query (wave-wide ballots inside); a lane without a query passes valid = false.
-template <int K, int ROWB, bool STAMP = false>
+template <int K, int ROWB, bool STAMP = false, int WIN = 0>
 __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const uint2* __restrict__ tree, Walk<K>& w, bool valid, float alpha_eff, int T, uint32_t dummy,
                                            uint32_t col_addr, int cap) {
 #pragma unroll
@@ -70,7 +71,7 @@ __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const ui
     // finite-arithmetic precondition of the traversal (the tree is `bounded`): anything else goes to the exact kernel
     const bool sane = fabsf(w.qx) < 1e18f && fabsf(w.qy) < 1e18f && fabsf(w.qz) < 1e18f;
     if (valid && sane) {
-        walk_descend<K, ROWB>(rsrc, tree, w, T, col_addr);
+        walk_descend<K, ROWB, WIN>(rsrc, tree, w, T, col_addr);
     } else {
         w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = valid ? 1u : 0u;
     }
@@ -104,7 +105,8 @@ __device__ __forceinline__ bool walk_exact_in_wave(const uint2* __restrict__ tre
 
 // LANES = active lanes per wave = stack columns (64; 16 for launches that cannot fill the chip anyway: a wave's time is its
 // longest traversal, and with 128-byte rows every level fits in LDS — T = 0 — so that no query needs the deep pass).
-template <int K, int DF, int LANES = 64, bool STAMP = false>
+// WIN > 0: of the levels ≥ T only the deepest WIN = DF − 2 of each query's first descent are stored (search_walk.hpp, walk_descend).
+template <int K, int DF, int LANES = 64, bool STAMP = false, int WIN = 0>
 __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __restrict__ tree, const float4* __restrict__ src,
                                                              const int* __restrict__ counts, const PoseState* __restrict__ st,
                                                              uint32_t* __restrict__ nn, size_t nn_pitch, int max_n, float alpha_eff, int T,
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
     Walk<K> w;
     w.qx = (float)qs.x; w.qy = (float)qs.y; w.qz = (float)qs.z;
-    walk_query<K, ROWB, STAMP>(rsrc, tree, w, finite, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]), DF);  // DF rows: a stack that outgrows them → deep pass
+    static_assert(WIN <= DF - 2, "the window lies in the rows above the two candidate rows");
+    walk_query<K, ROWB, STAMP, WIN>(rsrc, tree, w, finite, alpha_eff, T, dummy, (uint32_t)(size_t)(&s_dyn[tid]), DF);  // DF rows: a stack that outgrows them → deep pass
     if (STAMP && search_stats) {
         // diagnostic build (LOCGPU_STAMP=1): rounds each lane needed against the rounds its wave ran — the kernel's lane
         // efficiency — and the per-query round counts behind the neighbour-list area of redo_list (2 x pitch entries in this build)
@@ -793,8 +796,8 @@ static int fast_stack_depth() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("LOCGPU_FAST_STACK");
-        v = e ? atoi(e) : 15;
-        if (v != 12 && v != 24) v = 15;
+        v = e ? atoi(e) : 10;
+        if (v != 12 && v != 15 && v != 24) v = 10;
     }
     return v;
 }
@@ -810,7 +813,7 @@ static bool no_static_lds() {
 }
 template <int K, int D>
 static bool walk_kernels_ok_kd() {
-    return no_static_lds<icp_search_walk_kernel<K, 12>>() && no_static_lds<icp_search_walk_kernel<K, 15>>() && no_static_lds<icp_search_walk_kernel<K, 24>>() &&
+    return no_static_lds<icp_search_walk_kernel<K, 10, 64, false, 8>>() && no_static_lds<icp_search_walk_kernel<K, 12>>() && no_static_lds<icp_search_walk_kernel<K, 15>>() && no_static_lds<icp_search_walk_kernel<K, 24>>() &&
            no_static_lds<icp_search_walk_kernel<K, D + 2, 16>>() && no_static_lds<icp_search_walk_list_kernel<K, D, kDeepLanes>>();
 }
 bool search_kernels_lds_ok() {
@@ -822,7 +825,7 @@ bool search_kernels_lds_ok() {
 // The search stage of one Gauss–Newton iteration: walk kernel → deep pass → exact redo (the last two over device-side lists that are
 // almost always short). a.redo_count / a.redo_count2 are zero here: the caller clears them before an alignment's first iteration,
 // gn_solve_kernel after every search.
-template <int K, int D, int DF>
+template <int K, int D, int DF, int WIN = 0>
 static bool launch_walk_kd(const SearchArgs& a, hipStream_t s) {
     static const bool stamp = [] { const char* e = getenv("LOCGPU_STAMP"); return e && atoi(e) != 0; }();
     const uint32_t dummy = (uint32_t)(a.tree_bytes / 8);  // the sentinel leaf behind the tree
@@ -839,13 +842,23 @@ static bool launch_walk_kd(const SearchArgs& a, hipStream_t s) {
     // rows 0/1 of the DF stored rows hold the candidates of the un-stored levels, the other DF-2 rows one level each. Queries whose
     // un-stored levels need more than two candidates, or whose candidate descent outgrows the rows, go through a.redo_list2 to the
     // deep pass (every level stored), ties to the exact redo kernel.
-    const int Tw = a.depth > DF - 2 ? a.depth - (DF - 2) : 0;
+    // DF = 10: the sliding window (WIN = 8); T as for 15 rows — the un-stored top levels are sized by what a TYPICAL descent can store,
+    // the window takes care of the deeper ones (LOCGPU_K1_T_OFFSET: measurement knob)
+    static const int t_off = [] { const char* e = getenv("LOCGPU_K1_T_OFFSET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 13; }();
+    const int stored = WIN ? t_off : DF - 2;
+    const int Tw = a.depth > stored ? a.depth - stored : 0;
     dim3 g2((a.max_n + 63) / 64, n_launch);
+    // LOCGPU_K1_LDS_BYTES (measurement only, profiles/r06_k1_occupancy.md): a larger dynamic LDS allocation than the DF rows need, i.e.
+    // fewer waves per CU. The extra bytes sit ABOVE the stack (a push beyond row DF lands in them instead of off the allocation:
+    // harmless, `cap` sends such a query to the deep pass either way).
+    static const bool lds_knob = getenv("LOCGPU_K1_LDS_BYTES") != nullptr;  // present at the first launch: re-read at every launch (tools/k1_occupancy.py sweeps it in one process)
+    unsigned lds_bytes = DF * 64 * 8;
+    if (lds_knob) { const char* e = getenv("LOCGPU_K1_LDS_BYTES"); lds_bytes = (unsigned)std::max(e ? atoi(e) : 0, DF * 64 * 8); }
     if (stamp)  // diagnostic build: counts rounds per lane and per wave (search_stats[4], [9], [12], [13]; per query at redo_list[pitch + gi]); timing meaningless
-        hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, 64, true>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+        hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, 64, true, WIN>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                            a.alpha_eff, Tw, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of);
     else
-        hipLaunchKernelGGL((icp_search_walk_kernel<K, DF>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
+        hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, 64, false, WIN>), g2, dim3(64), lds_bytes, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
                            a.alpha_eff, Tw, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of);
     // 2048 one-wave blocks of 17 KB LDS are all resident at once (nine fit a CU): the first iteration's ≈140 k deep queries take one
     // traversal per wave instead of two or three in sequence (search 18.07 → 17.80 ms per 256-scan step; 4608: 17.96)
@@ -858,9 +871,20 @@ static bool launch_walk_kd(const SearchArgs& a, hipStream_t s) {
 template <int K, int D>
 static bool launch_walk_d(const SearchArgs& a, hipStream_t s) {
     switch (fast_stack_depth()) {
-        case 12: return launch_walk_kd<K, D, 12>(a, s);
+        default: {  // 10 rows = 5 120 B: 32 waves per CU (profiles/r06_k1_occupancy.md)
+            static const int win = [] { const char* e = getenv("LOCGPU_K1_WIN"); return e ? atoi(e) : 8; }();
+            if (win == 6) return launch_walk_kd<K, D, 10, 6>(a, s);
+            if (win == 7) return launch_walk_kd<K, D, 10, 7>(a, s);
+            return launch_walk_kd<K, D, 10, 8>(a, s);
+        }
+        case 12: {
+            static const int win = [] { const char* e = getenv("LOCGPU_K1_WIN"); return e ? atoi(e) : 0; }();
+            if (win == 8) return launch_walk_kd<K, D, 12, 8>(a, s);
+            if (win == 9) return launch_walk_kd<K, D, 12, 9>(a, s);
+            return launch_walk_kd<K, D, 12>(a, s);
+        }
         case 24: return launch_walk_kd<K, D, 24>(a, s);
-        default: return launch_walk_kd<K, D, 15>(a, s);
+        case 15: return launch_walk_kd<K, D, 15>(a, s);  // round 2-5's shape: 13 fixed levels, 21 waves per CU
     }
 }
 template <int K>

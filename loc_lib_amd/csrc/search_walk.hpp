@@ -55,7 +55,14 @@ __device__ __forceinline__ lds_u32* lds_ptr(uint32_t byte_addr) { return reinter
 // col_addr = LDS byte address of this lane's stack column (row stride ROWB bytes).
 // Every lane still in the loop is on the same level (one level per trip from the root), so "is this level stored" is a scalar
 // question: two loops — candidates only, then stores only — instead of one body that carries both (the kernel is VALU-bound).
-template <int K, int ROWB>
+//
+// WIN > 0 (round 6): the stored levels are a SLIDING WINDOW — the kernel owns only WIN + 2 rows of LDS (10 rows = 5 120 B per wave =
+// 32 waves per CU instead of 21), so of the levels ≥ T only the deepest WIN of a query's own first descent are stored; a level that
+// leaves the window joins the un-stored ones (its d² goes through the same candidate insertion, in the same increasing-depth order).
+// A query whose leaf lies no deeper than T + WIN — the typical one: T is sized by the tree's DEEPEST branch — stores exactly what the
+// fixed scheme stored. The window lives in registers during the descent (the loop is unrolled WIN times, level T + j in pair j mod WIN)
+// and is written to rows 2.. in age order behind it.
+template <int K, int ROWB, int WIN = 0>
 __device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, const uint2* __restrict__ tree, Walk<K>& w, int T, uint32_t col_addr) {
     float c1 = __builtin_inff(), c2 = __builtin_inff(), c3 = __builtin_inff();
     uint32_t f1 = 0, f2 = 0, c1_younger = 0;
@@ -118,7 +125,64 @@ __device__ __forceinline__ void walk_descend(__amdgpu_buffer_rsrc_t rsrc, const 
         cur = go_left ? cur1 : right;
     }
     int rows = 2;
-    if (!at_leaf) {
+    if constexpr (WIN > 0) {
+        if (!at_leaf) {
+            uint32_t wf[WIN], wd[WIN];  // the window: {far slot, bits of −d²} of level T + j in pair j mod WIN
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) { wf[j] = 0u; wd[j] = 0u; }
+            int n3 = 0;        // levels ≥ T this lane has passed
+            int pass = 0;      // wave-uniform: the lanes still in the loop are on the same level
+            bool found = false;
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < WIN; ++j) {
+                    const u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);
+                    const uint32_t meta = n.y;
+                    if (meta >= 0xC0000000u) { found = true; break; }
+                    const float th = as_f32(n.x);
+                    const float qa = meta < 0x40000000u ? qx : (meta < 0x80000000u ? qy : qz);
+                    const float dd = qa - th;
+                    const uint32_t right = meta & 0x3FFFFFFFu;
+                    const bool go_left = qa < th;
+                    const uint32_t cur1 = cur + 1u;
+                    if (pass > 0) {  // level T + n3 − WIN leaves the window: an un-stored level like those above T
+                        const float d2 = -as_f32(wd[j]);
+                        const uint32_t far_slot = wf[j];
+                        const bool lt1 = d2 < c1, lt2 = d2 < c2;
+                        c3 = __builtin_amdgcn_fmed3f(c2, d2, c3);
+                        c2 = __builtin_amdgcn_fmed3f(c1, d2, c2);
+                        c1 = __builtin_fminf(c1, d2);
+                        const uint32_t f2n = lt2 ? far_slot : f2;
+                        f2 = lt1 ? f1 : f2n;
+                        f1 = lt1 ? far_slot : f1;
+                        const uint32_t yn = lt2 ? 0u : c1_younger;
+                        c1_younger = lt1 ? 1u : yn;
+                    }
+                    wf[j] = go_left ? right : cur1;
+                    wd[j] = __float_as_uint(-(dd * dd));
+                    n3++;
+                    cur = go_left ? cur1 : right;
+                }
+                if (found) break;
+                pass++;
+            }
+            // rows 2..: the window in age order. Pair j holds the deepest level ≡ j (mod WIN) the lane passed; with more than WIN
+            // levels passed the oldest one kept sits in pair n3 mod WIN. Pairs the lane never filled are written too (rows above the
+            // stack's top may hold anything).
+            const uint32_t rot = n3 > WIN ? (uint32_t)n3 % (uint32_t)WIN : 0u;
+            rows = 2 + (n3 < WIN ? n3 : WIN);
+            if (__ballot(rot != 0u) == 0ull) {
+#pragma unroll
+                for (int j = 0; j < WIN; ++j) *reinterpret_cast<lds_u32x2*>(col_addr + (uint32_t)(2 + j) * ROWB) = u32x2{wf[j], wd[j]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < WIN; ++j) {
+                    const uint32_t r = (uint32_t)j >= rot ? (uint32_t)j - rot : (uint32_t)j + (uint32_t)WIN - rot;
+                    *reinterpret_cast<lds_u32x2*>(col_addr + (2u + r) * ROWB) = u32x2{wf[j], wd[j]};
+                }
+            }
+        }
+    } else if (!at_leaf) {
         uint32_t row = col_addr + 2u * ROWB;
         for (;;) {  // stored levels
             const u32x4 n = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(cur << 3), 0, 0);

@@ -559,7 +559,7 @@ def test_bench_refuses_more_ranks_than_gpus():
 
 
 # ----------------------------------------------------------------------------------------------- other LDS stack depths
-@pytest.mark.parametrize("rows", ["12", "24"])
+@pytest.mark.parametrize("rows", ["12", "15", "24"])
 def test_search_parity_at_other_stack_depths(rows):
     """The fast traversal stores `LOCGPU_FAST_STACK` stack rows in LDS and keeps the levels above them as candidates (direct
     expansion, replay) — with 12 rows the replay and overflow paths run ~100× more often than at the default 15, with 24 hardly

@@ -19,7 +19,7 @@ def _run(script, *args, env=None, timeout=900):
     return out.stdout
 
 
-@pytest.mark.parametrize("rows", ["15", "12"])
+@pytest.mark.parametrize("rows", ["15", "12", "10"])
 def test_fuzz_search_short(rows):
     """45 cases = five of each map kind, alternating the one-scan and the batch kernel; at 12 stack rows the deep pass and the
     overflow rule run about a hundred times more often."""
