@@ -75,7 +75,10 @@ __device__ __forceinline__ void walk_query(__amdgpu_buffer_rsrc_t rsrc, const ui
     } else {
         w.cur = dummy; w.avail = 0; w.c3n = 0; w.slow = valid ? 1u : 0u;
     }
-    walk_rounds_capped<K, ROWB, 2, STAMP>(rsrc, w, alpha_eff, dummy, col_addr, cap);
+#ifndef LOCGPU_K1_C
+#define LOCGPU_K1_C 2  // internal steps per round (A/B builds: -DLOCGPU_K1_C=1|3)
+#endif
+    walk_rounds_capped<K, ROWB, LOCGPU_K1_C, STAMP>(rsrc, w, alpha_eff, dummy, col_addr, cap);
 #pragma unroll
     for (int j = 0; j + 1 < K; ++j) w.slow |= w.d[j] == w.d[j + 1] ? 1u : 0u;  // equal distances in the final set: heap pop order is layout-dependent
 }
