@@ -4,7 +4,7 @@
  * the KD-tree neighbour search + point-to-plane/-line/-point ICP and direct-NDT Gauss–Newton loop
  * that slam_demo's front-ends run once per scan through LocUtils::MatchingInterface. The reference
  * is plain C++ with no FFI; a maintainer binds these entry points from the reference's own matcher
- * classes (see INTEGRATION.md and facade/). Every entry point names the reference interface it
+ * classes (see INTEGRATION.md and loc_lib_amd/host/). Every entry point names the reference interface it
  * replaces (paths relative to the reference repo root).
  *
  * Conventions
@@ -133,6 +133,30 @@ LOCGPU_API int locgpu_icp_hb(locgpu_ctx* ctx, const void* src, size_t n, size_t 
 /* ---- IcpRegistration::ScanMatch minus the output cloud (icp_registration.cpp:216-239 → AlignP2P/P2Line/P2Plane :267-381). */
 LOCGPU_API int locgpu_icp_align(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7],
                                 const locgpu_icp_opts* opts, double out_pose[7], locgpu_align_stats* stats);
+
+/* ---- IcpRegistration::ScanMatch WHOLE (icp_registration.cpp:216-244): the alignment and the output cloud
+ * `pcl::transformPointCloud(*input_source, *result_cloud_ptr, result_pose.matrix().cast<float>())` (:241) in one call — the source is
+ * uploaded once, the transform runs on the copy that is in HBM from the alignment, and x, y, z come back through pinned staging.
+ * The output cloud: n points of out_stride_bytes each, given either as out_cloud or by out_fn — a callback the library calls ONCE, on a
+ * helper thread, while the alignment runs, with out_user and the point count; it returns the output array (the façade sizes the caller's
+ * pcl::PointCloud there: the first touch of a fresh 3.7 MB array is then off the caller's thread) or NULL for none. Both NULL: no
+ * output cloud. Like pcl::transformPointCloud every output point is the source point with x, y, z replaced: unless the output array
+ * IS the source array (same stride: in place) the first min(stride_bytes, out_stride_bytes) bytes of every source point are copied
+ * — on the helper thread, beside the alignment. Any other overlap of the two clouds is undefined. out_stride_bytes | LOCGPU_OUT_FIELDS_DONE:
+ * the output points already hold their other fields (or the callback puts them there — the façade's does `out->points = src->points`,
+ * one pass over fresh memory instead of a resize and a copy): the library then only writes x, y, z. The callback must not call into
+ * this context. This is what LocUtils::IcpRegistration::ScanMatch binds to. */
+typedef void* (*locgpu_out_cloud_fn)(void* user, size_t n_points);
+#define LOCGPU_OUT_FIELDS_DONE ((size_t)1 << (sizeof(size_t) * 8 - 1))
+LOCGPU_API int locgpu_icp_scan_match(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7],
+                                     const locgpu_icp_opts* opts, double out_pose[7], locgpu_align_stats* stats, void* out_cloud,
+                                     size_t out_stride_bytes, locgpu_out_cloud_fn out_fn, void* out_user);
+/* ---- NdtRegistration::ScanMatch WHOLE (ndt_registration.cpp:238-261). result_pose is IN-OUT like the reference's `SE3& result_pose`:
+ * with stats->status == 1 (det(H) == 0) AlignNdt returns before it assigns it (:435-436), so the caller's value stays and the output
+ * cloud is transformed by that value (:258); otherwise it receives the result. Output cloud as above. */
+LOCGPU_API int locgpu_ndt_scan_match(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7],
+                                     double result_pose[7], locgpu_align_stats* stats, void* out_cloud, size_t out_stride_bytes,
+                                     locgpu_out_cloud_fn out_fn, void* out_user);
 
 /* ---- pcl::transformPointCloud(*src, *out, pose.matrix().cast<float>()) (icp_registration.cpp:241, ndt_registration.cpp:258).
  * Writes x,y,z of each output point (float32 arithmetic); other fields of the output points are left untouched. */

@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "locgpu_comm_unique_id", "locgpu_comm_init", "locgpu_comm_info", "locgpu_batch_create_sharded", "locgpu_icp_set_target_bcast",
     "locgpu_pool_opts_default", "locgpu_pool_create", "locgpu_pool_destroy", "locgpu_pool_submit", "locgpu_pool_wait", "locgpu_pool_info",
     "locgpu_pool_profile_read", "locgpu_pool_step", "locgpu_pool_done",
+    "locgpu_icp_scan_match", "locgpu_ndt_scan_match",
 ]
 COMM_ID_BYTES = 128
 NO_INTENSITY = ctypes.c_size_t(-1).value
@@ -140,6 +141,8 @@ def lib():
             "locgpu_pool_submit": (i32, [vp, vp, vp, sz, i32, i32, i32, vp, vp]), "locgpu_pool_wait": (i32, [vp, ctypes.c_int64, vp, vp]),
             "locgpu_pool_info": (i32, [vp, vp]), "locgpu_pool_profile_read": (i32, [vp, vp, i32]),
             "locgpu_pool_step": (i32, [vp, i32]), "locgpu_pool_done": (i32, [vp, ctypes.c_int64, vp]),
+            "locgpu_icp_scan_match": (i32, [vp, vp, sz, sz, vp, vp, vp, vp, vp, sz, vp, vp]),
+            "locgpu_ndt_scan_match": (i32, [vp, vp, sz, sz, vp, vp, vp, vp, sz, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -273,6 +276,28 @@ class Context:
         self._check(lib().locgpu_icp_align(self._h, s.ctypes.data, s.shape[0], s.strides[0], _pose(init_pose).ctypes.data, ctypes.byref(opts),
                                            out.ctypes.data, ctypes.byref(st)))
         return out, _stats_dict(st)
+
+    # ---- IcpRegistration::ScanMatch whole: pose + output cloud (icp_registration.cpp:216-244)
+    def icp_scan_match(self, src, init_pose, opts, in_place=False):
+        """Returns (pose, stats, output cloud). The output cloud has the source's layout: every field of the source point, x, y, z
+        replaced (pcl::transformPointCloud); in_place=True hands the source array itself as the output cloud."""
+        s = _cloud(src)
+        cloud = s if in_place else np.full_like(s, np.nan)
+        out = np.zeros(7)
+        st = AlignStats()
+        self._check(lib().locgpu_icp_scan_match(self._h, s.ctypes.data, s.shape[0], s.strides[0], _pose(init_pose).ctypes.data, ctypes.byref(opts),
+                                                out.ctypes.data, ctypes.byref(st), cloud.ctypes.data, cloud.strides[0], None, None))
+        return out, _stats_dict(st), cloud
+
+    # ---- NdtRegistration::ScanMatch whole (ndt_registration.cpp:238-261); result_pose in-out (status 1 leaves it as handed in)
+    def ndt_scan_match(self, src, init_pose, result_pose=None):
+        s = _cloud(src)
+        cloud = np.full_like(s, np.nan)
+        out = np.array(_pose(result_pose if result_pose is not None else init_pose), copy=True)
+        st = AlignStats()
+        self._check(lib().locgpu_ndt_scan_match(self._h, s.ctypes.data, s.shape[0], s.strides[0], _pose(init_pose).ctypes.data, out.ctypes.data,
+                                                ctypes.byref(st), cloud.ctypes.data, cloud.strides[0], None, None))
+        return out, _stats_dict(st), cloud
 
     # ---- pcl::transformPointCloud(src, out, pose.matrix().cast<float>())
     def transform_cloud(self, pose, src):

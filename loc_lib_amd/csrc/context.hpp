@@ -11,6 +11,55 @@
 #include "grid_kernels.hpp"
 #include "icp_kernels.hpp"
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+namespace locgpu {
+// One helper thread per context for host work that can run beside a blocking call's GPU work (round 6: the copy of the source cloud's
+// non-coordinate fields into the caller's output cloud during ScanMatch). run() hands over one job, wait() returns when it is done;
+// the caller's thread is the only one that calls either.
+class HostWorker {
+public:
+    ~HostWorker() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        if (t_.joinable()) t_.join();
+    }
+    void run(std::function<void()> job) {
+        wait();
+        { std::lock_guard<std::mutex> g(m_); job_ = std::move(job); busy_ = true; }
+        if (!t_.joinable()) t_ = std::thread([this] { loop(); });
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return !busy_; });
+    }
+private:
+    void loop() {
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [this] { return stop_ || (busy_ && job_); });
+            if (stop_) return;
+            std::function<void()> job = std::move(job_);
+            job_ = nullptr;
+            g.unlock();
+            job();
+            g.lock();
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+    std::thread t_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, stop_ = false;
+};
+}  // namespace locgpu
+
 struct NdtTable;  // ndt_kernels.hpp
 namespace locgpu { struct IncNdtState; struct FilterScratch; }  // ndt_inc.hpp, cloud_filters.hpp
 
@@ -63,6 +112,7 @@ struct locgpu_ctx {
     // reusable one-scan batch for the single-scan entry points
     locgpu_batch* single = nullptr;
     size_t single_cap = 0;
+    locgpu::HostWorker* worker = nullptr;  // locgpu_*_scan_match: host copy of the output cloud's fields beside the alignment
 
     // multi-GPU (locgpu_comm_init): RCCL communicator of the ranks that share sharded batches
     void* comm = nullptr;  // ncclComm_t
@@ -119,6 +169,7 @@ struct locgpu_batch {
     const void* graph_target = nullptr;  // tree / NDT table the capture was made against
     unsigned long long graph_epoch = 0;
     float4* h_src = nullptr;               // pinned staging of the packed source (single-scan path only; reused across calls)
+    hipEvent_t xyz_ev[8] = {};             // one-scan batch: the output cloud's pieces on their way back (write_output_cloud)
     locgpu::PoseState* h_state = nullptr;  // pinned
     // one-scan alignments paced from the host (locgpu_api.hip, align_finish): the solve kernel posts the state here after every
     // iteration — pinned COHERENT memory: [0] a finished scan's GnPostRecord, [kPostWord] call << 32 | iterations << 1 | done, [+1] checksum

@@ -741,17 +741,16 @@ __global__ __launch_bounds__(kBlock) void count_touched_kernel(uint32_t* __restr
 }
 
 // pcl::transformPointCloud with the float32 4×4 (icp_registration.cpp:241): ((m0·x + m1·y) + m2·z) + m3 per row.
-__global__ __launch_bounds__(kBlock) void transform_cloud_kernel(const float4* __restrict__ src, size_t n, const float* __restrict__ m12,
-                                                                 float4* __restrict__ dst) {
+// The 3×4 matrix travels as a kernel argument (no upload in front of the launch); the output is packed x, y, z — what goes back to the
+// caller's cloud, whose other fields are the source's (locgpu_api.hip, write_output_cloud).
+__global__ __launch_bounds__(kBlock) void transform_cloud_kernel(const float4* __restrict__ src, size_t n, M12f m, float* __restrict__ dst_xyz) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 p = src[i];
-    float4 o;
-    o.x = ((m12[0] * p.x + m12[1] * p.y) + m12[2] * p.z) + m12[3];
-    o.y = ((m12[4] * p.x + m12[5] * p.y) + m12[6] * p.z) + m12[7];
-    o.z = ((m12[8] * p.x + m12[9] * p.y) + m12[10] * p.z) + m12[11];
-    o.w = p.w;
-    dst[i] = o;
+    const float* m12 = m.v;
+    dst_xyz[3 * i + 0] = ((m12[0] * p.x + m12[1] * p.y) + m12[2] * p.z) + m12[3];
+    dst_xyz[3 * i + 1] = ((m12[4] * p.x + m12[5] * p.y) + m12[6] * p.z) + m12[7];
+    dst_xyz[3 * i + 2] = ((m12[8] * p.x + m12[9] * p.y) + m12[10] * p.z) + m12[11];
 }
 
 // Test hook: the search stage's slot lists as original point indices (what knn_query_kernel reports), out[(gi * k) + j].
@@ -1015,8 +1014,8 @@ void launch_count_touched(uint32_t* touched, size_t n_words, unsigned long long*
     hipLaunchKernelGGL(count_touched_kernel, dim3(1024), dim3(kBlock), 0, s, touched, n_words, totals);
 }
 
-void launch_transform_cloud(const float4* src, size_t n, const float* m12, float4* dst, hipStream_t s) {
-    hipLaunchKernelGGL(transform_cloud_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, src, n, m12, dst);
+void launch_transform_cloud(const float4* src, size_t n, const M12f& m12, float* dst_xyz, hipStream_t s) {
+    hipLaunchKernelGGL(transform_cloud_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, src, n, m12, dst_xyz);
 }
 
 }  // namespace locgpu

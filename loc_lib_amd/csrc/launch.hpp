@@ -93,7 +93,8 @@ int icp_accum_split(int method, int max_n, int n_scans);  // points per thread o
 // owned (optional, scan pools): per global scan, whether this rank holds its points (then first = 0, n_local = n_total)
 void launch_sum_partials(const double* partials, int blocks_per_scan, const PoseState* st_all, int first, int n_local, int n_total, double* acc,
                          hipStream_t s, const unsigned char* owned = nullptr);
-void launch_transform_cloud(const float4* src, size_t n, const float* m12, float4* dst, hipStream_t s);
+struct M12f { float v[12]; };  // rows of pose.matrix().cast<float>() (icp_registration.cpp:241), a kernel argument
+void launch_transform_cloud(const float4* src, size_t n, const M12f& m12, float* dst_xyz, hipStream_t s);
 // Code-object self-test (once per process): no walk kernel owns static LDS, so every traversal stack starts at LDS address 0 —
 // the precondition of search_walk.hpp's out-of-range rows (tests/test_gpu_lds_semantics.py pins the hardware side).
 bool search_kernels_lds_ok();

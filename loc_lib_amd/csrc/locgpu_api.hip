@@ -156,6 +156,8 @@ void locgpu::free_batch(locgpu_batch* b) {
     if (b->h_state) (void)hipHostFree(b->h_state);
     if (b->h_post) (void)hipHostFree(b->h_post);
     if (b->tail_ev) (void)hipEventDestroy(b->tail_ev);
+    for (hipEvent_t e : b->xyz_ev)
+        if (e) (void)hipEventDestroy(e);
     if (b->h_hb) (void)hipHostFree(b->h_hb);
     if (b->h_active) (void)hipHostFree(b->h_active);
     if (b->d_active) (void)hipFree(b->d_active);
@@ -243,6 +245,7 @@ void locgpu_destroy(locgpu_ctx* ctx) {
     free_target_scratch(ctx);
     for (hipStream_t st : ctx->slot_stream) if (st) (void)hipStreamSynchronize(st);
     if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+    delete ctx->worker;  // joins the helper thread (no job outlives the call that started it)
     free_batch(ctx->single);
     upload_free_ctx(ctx);
     if (ctx->comm) { (void)rccl().CommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
@@ -1395,48 +1398,133 @@ int locgpu_gn_update(const double hb[44], int method, int min_effective_pts, dou
     return LOCGPU_OK;
 }
 
+// The output cloud of ScanMatch (pcl::transformPointCloud(*src, *out, pose.matrix().cast<float>()), icp_registration.cpp:241,
+// ndt_registration.cpp:258): the points of the one-scan batch `b` (they are in HBM from the alignment, or were just uploaded) go through
+// transform_cloud_kernel into the batch's neighbour-list array (dead by now: 20 B per point, 12 needed), come back through the batch's
+// pinned staging and are written x, y, z into the caller's points. No allocation, no second upload, one kernel, one copy.
+static int write_output_cloud(locgpu_ctx* ctx, locgpu_batch* b, const float4* d_points, size_t n, const double pose[7], void* out, size_t out_stride) {
+    double R[9];
+    quat_to_R(pose, R);
+    M12f m;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) m.v[4 * r + c] = (float)R[3 * r + c];
+        m.v[4 * r + 3] = (float)pose[4 + r];
+    }
+    float* d_xyz = reinterpret_cast<float*>(b->d_nn);
+    float* h_xyz = reinterpret_cast<float*>(b->h_src);
+    launch_transform_cloud(d_points, n, m, d_xyz, b->stream);
+    LOCGPU_HIP(ctx, hipGetLastError());
+    // back in up to eight pieces, each with an event: the host writes piece i into the caller's points while the later ones cross PCIe —
+    // the even pieces on the caller's thread, the odd ones on the context's helper thread (12 of every 32 bytes of a 3.7 MB array: the
+    // write is what costs, and two cores do it in half the time)
+    constexpr int kMaxPieces = 8;
+    const size_t piece = std::max<size_t>(32 * 1024, (n + kMaxPieces - 1) / kMaxPieces);
+    const int pieces = (int)((n + piece - 1) / piece);
+    for (int p = 0; p < pieces; ++p) {
+        if (!b->xyz_ev[p]) LOCGPU_HIP(ctx, hipEventCreateWithFlags(&b->xyz_ev[p], hipEventDisableTiming));
+        const size_t lo = (size_t)p * piece, len = std::min(piece, n - lo);
+        LOCGPU_HIP(ctx, hipMemcpyAsync(h_xyz + 3 * lo, d_xyz + 3 * lo, len * 3 * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+        LOCGPU_HIP(ctx, hipEventRecord(b->xyz_ev[p], b->stream));
+    }
+    char* ob = (char*)out;
+    std::atomic<int> failed{0};
+    auto scatter = [&, ob, h_xyz](int first) {
+        for (int p = first; p < pieces; p += 2) {
+            if (hipEventSynchronize(b->xyz_ev[p]) != hipSuccess) { failed = 1; return; }
+            const size_t lo = (size_t)p * piece, hi = std::min(n, lo + piece);
+            for (size_t i = lo; i < hi; ++i) std::memcpy(ob + i * out_stride, h_xyz + 3 * i, 12);
+        }
+    };
+    if (ctx->worker) ctx->worker->wait();  // the copy of the other fields (scan_match_fields) is through
+    const bool two = pieces > 1 && ctx->worker;
+    if (two) ctx->worker->run([&] { (void)hipSetDevice(ctx->device); scatter(1); });
+    scatter(0);
+    if (two) ctx->worker->wait(); else if (pieces > 1) scatter(1);
+    if (failed) return fail(ctx, LOCGPU_ERR_NO_DEVICE, "output cloud: copy back");
+    return LOCGPU_OK;
+}
+
+// "*out = *src" of pcl::transformPointCloud — every field of a source point that the output point has room for — on the context's
+// helper thread so that it runs beside the alignment; with out_fn the helper first ASKS for the output array (a façade sizes the
+// caller's container there: 3.7 MB of first-touch page faults for a full scan, off the caller's thread). scan_match_output waits for
+// it, then writes the coordinates. *dst receives the output array (written by the helper; read after wait()).
+static void scan_match_fields(locgpu_ctx* ctx, const void* src, size_t n, size_t src_stride, void* out, size_t out_stride, locgpu_out_cloud_fn out_fn,
+                              void* user, void** dst) {
+    *dst = out;
+    if (out_stride & LOCGPU_OUT_FIELDS_DONE) {  // the caller (or its callback) leaves the fields in place itself
+        if (!out_fn) return;
+        if (!ctx->worker) ctx->worker = new locgpu::HostWorker();
+        ctx->worker->run([=] { *dst = out_fn(user, n); });
+        return;
+    }
+    if ((!out && !out_fn) || (!out_fn && out == src) || n == 0) return;
+    if (!ctx->worker) ctx->worker = new locgpu::HostWorker();
+    ctx->worker->run([=] {
+        void* o = out_fn ? out_fn(user, n) : out;
+        *dst = o;
+        if (!o || o == src) return;
+        if (src_stride == out_stride) { std::memcpy(o, src, n * src_stride); return; }
+        const size_t w = std::min(src_stride, out_stride);
+        const char* sb = (const char*)src;
+        char* ob = (char*)o;
+        for (size_t i = 0; i < n; ++i) std::memcpy(ob + i * out_stride, sb + i * src_stride, w);
+    });
+}
+static int scan_match_output(locgpu_ctx* ctx, locgpu_batch* b, size_t n, int rc, const double pose[7], void** dst, size_t out_stride) {
+    if (ctx->worker) ctx->worker->wait();
+    if (rc != LOCGPU_OK || !*dst) return rc;
+    return write_output_cloud(ctx, b, b->d_src, n, pose, *dst, out_stride & ~LOCGPU_OUT_FIELDS_DONE);
+}
+
+int locgpu_icp_scan_match(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7], const locgpu_icp_opts* opts,
+                          double out_pose[7], locgpu_align_stats* stats, void* out_cloud, size_t out_stride_bytes, locgpu_out_cloud_fn out_fn, void* out_user) {
+    GnParams prm{};
+    int k;
+    float alpha_eff;
+    int rc = check_icp(ctx, opts, prm, k, alpha_eff);
+    if (rc != LOCGPU_OK) return rc;
+    if (!src || !init_pose || !out_pose || ((out_cloud || out_fn) && (out_stride_bytes & ~LOCGPU_OUT_FIELDS_DONE) < 12)) return fail(ctx, LOCGPU_ERR_INVALID, "icp_scan_match: bad arguments");
+    locgpu_batch* b = nullptr;
+    rc = single_batch(ctx, src, n, stride_bytes, &b);
+    if (rc != LOCGPU_OK) return rc;
+    void* dst = nullptr;
+    scan_match_fields(ctx, src, n, stride_bytes, out_cloud, out_stride_bytes, out_fn, out_user, &dst);
+    rc = run_align(ctx, b, init_pose, prm, k, alpha_eff, false, out_pose, stats);
+    return scan_match_output(ctx, b, n, rc, out_pose, &dst, out_stride_bytes);
+}
+
+int locgpu_ndt_scan_match(locgpu_ctx* ctx, const void* src, size_t n, size_t stride_bytes, const double init_pose[7], double result_pose[7],
+                          locgpu_align_stats* stats, void* out_cloud, size_t out_stride_bytes, locgpu_out_cloud_fn out_fn, void* out_user) {
+    GnParams prm{};
+    int rc = check_ndt(ctx, prm);
+    if (rc != LOCGPU_OK) return rc;
+    if (!src || !init_pose || !result_pose || ((out_cloud || out_fn) && (out_stride_bytes & ~LOCGPU_OUT_FIELDS_DONE) < 12)) return fail(ctx, LOCGPU_ERR_INVALID, "ndt_scan_match: bad arguments");
+    locgpu_batch* b = nullptr;
+    rc = single_batch(ctx, src, n, stride_bytes, &b);
+    if (rc != LOCGPU_OK) return rc;
+    void* dst = nullptr;
+    scan_match_fields(ctx, src, n, stride_bytes, out_cloud, out_stride_bytes, out_fn, out_user, &dst);
+    double pose[7];
+    locgpu_align_stats st{};
+    rc = run_align(ctx, b, init_pose, prm, 0, 1.0f, true, pose, &st);
+    if (stats) *stats = st;
+    // det(H) == 0 (status 1): AlignNdt returns before it assigns result_pose (ndt_registration.cpp:435-436) — the caller's value stays,
+    // and the output cloud is transformed by THAT pose (:258)
+    if (rc == LOCGPU_OK && st.status != 1) std::memcpy(result_pose, pose, sizeof(pose));
+    return scan_match_output(ctx, b, n, rc, result_pose, &dst, out_stride_bytes);
+}
+
 int locgpu_transform_cloud(locgpu_ctx* ctx, const double pose[7], const void* src, size_t n, size_t src_stride_bytes, void* out,
                            size_t out_stride_bytes) {
     if (!ctx) return LOCGPU_ERR_INVALID;
     if (!pose || (n && (!src || !out)) || src_stride_bytes < 12 || out_stride_bytes < 12) return fail(ctx, LOCGPU_ERR_INVALID, "transform_cloud: bad arguments");
     if (n == 0) return LOCGPU_OK;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
-    double R[9];
-    quat_to_R(pose, R);
-    float m12[12];
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) m12[4 * r + c] = (float)R[3 * r + c];
-        m12[4 * r + 3] = (float)pose[4 + r];
-    }
-    std::vector<float4> host(n);
-    const char* base = (const char*)src;
-    for (size_t i = 0; i < n; ++i) { host[i] = float4{0.f, 0.f, 0.f, 0.f}; std::memcpy(&host[i], base + i * src_stride_bytes, 12); }
-    float4 *d_in = nullptr, *d_out = nullptr;
-    float* d_m = nullptr;
-    int rc = LOCGPU_OK;
-    if (!hip_ok(ctx, hipMalloc((void**)&d_in, n * sizeof(float4)), "hipMalloc") || !hip_ok(ctx, hipMalloc((void**)&d_out, n * sizeof(float4)), "hipMalloc") ||
-        !hip_ok(ctx, hipMalloc((void**)&d_m, sizeof(m12)), "hipMalloc"))
-        rc = LOCGPU_ERR_OOM;
-    if (rc == LOCGPU_OK) {
-        hipStream_t s = ctx->stream;
-        bool ok = hip_ok(ctx, hipMemcpyAsync(d_in, host.data(), n * sizeof(float4), hipMemcpyHostToDevice, s), "H2D") &&
-                  hip_ok(ctx, hipMemcpyAsync(d_m, m12, sizeof(m12), hipMemcpyHostToDevice, s), "H2D");
-        if (ok) {
-            launch_transform_cloud(d_in, n, d_m, d_out, s);
-            ok = hip_ok(ctx, hipGetLastError(), "transform launch") &&
-                 hip_ok(ctx, hipMemcpyAsync(host.data(), d_out, n * sizeof(float4), hipMemcpyDeviceToHost, s), "D2H") &&
-                 hip_ok(ctx, hipStreamSynchronize(s), "sync");
-        }
-        if (!ok) rc = LOCGPU_ERR_NO_DEVICE;
-    }
-    if (rc == LOCGPU_OK) {
-        char* ob = (char*)out;
-        for (size_t i = 0; i < n; ++i) std::memcpy(ob + i * out_stride_bytes, &host[i], 12);
-    }
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    if (d_m) (void)hipFree(d_m);
-    return rc;
+    // through the context's one-scan batch: its pinned staging, its source array, its (idle) neighbour-list array — nothing is allocated per call
+    locgpu_batch* b = nullptr;
+    const int rc = single_batch(ctx, src, n, src_stride_bytes, &b);
+    if (rc != LOCGPU_OK) return rc;
+    return write_output_cloud(ctx, b, b->d_src, n, pose, out, out_stride_bytes);
 }
 
 // --------------------------------------------------------------------------------------------- measurement

@@ -41,6 +41,23 @@ bool write_output_cloud(locgpu_ctx* ctx, const CloudPtr& src, const SE3& pose, C
     return locgpu_transform_cloud(ctx, pose.data(), src->points.data(), src->points.size(), sizeof(PointType), out->points.data(),
                                   sizeof(PointType)) == LOCGPU_OK;
 }
+// The output cloud of ScanMatch as locgpu_*_scan_match wants it: a callback the library runs on its helper thread WHILE the alignment
+// runs. It sizes the caller's cloud (header fields as `*out = *src` leaves them; the first touch of a fresh 3.7 MB point array happens
+// here, off the caller's thread) and hands back the point array; the library copies every point's fields into it there and writes
+// x, y, z behind the alignment — one pass over the caller's memory instead of a copy plus a second upload.
+struct OutputCloud { const PointCloudType* src; PointCloudType* out; };
+void* size_output_cloud(void* user, size_t n) {
+    OutputCloud* oc = static_cast<OutputCloud*>(user);
+    if (!oc->out) return nullptr;  // the reference would dereference null here (loc.cpp:215 always allocates it)
+    if (oc->out != oc->src) {
+        oc->out->width = oc->src->width;
+        oc->out->height = oc->src->height;
+        oc->out->is_dense = oc->src->is_dense;
+        oc->out->points = oc->src->points;  // one pass: sized and every field in place (LOCGPU_OUT_FIELDS_DONE); x, y, z follow
+    }
+    (void)n;
+    return oc->out->points.data();
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ ICP
@@ -81,13 +98,18 @@ bool IcpRegistration::ScanMatch(const CloudPtr& input_source, const SE3& predict
     if (!input_source) return true;
     SE3 pose = predict_pose;
     if (has_target_ && !input_source->points.empty()) {
+        // alignment + output cloud in ONE call: the source crosses PCIe once, the transform runs on the copy the alignment left in HBM
         const locgpu_icp_opts o = to_c(options_);
         double out[7];
-        if (locgpu_icp_align(ctx_, input_source->points.data(), input_source->points.size(), sizeof(PointType), predict_pose.data(), &o, out,
-                             nullptr) == LOCGPU_OK)
+        OutputCloud oc{input_source.get(), result_cloud_ptr.get()};
+        if (locgpu_icp_scan_match(ctx_, input_source->points.data(), input_source->points.size(), sizeof(PointType), predict_pose.data(), &o, out,
+                                  nullptr, nullptr, sizeof(PointType) | LOCGPU_OUT_FIELDS_DONE, size_output_cloud, &oc) == LOCGPU_OK) {
             std::memcpy(pose.data(), out, sizeof(out));
+            result_pose = pose;
+            return true;  // icp_registration.cpp:243
+        }
     }
-    result_pose = pose;
+    result_pose = pose;  // no target / empty source / a failed call: the prediction, and the cloud under it
     if (ctx_) write_output_cloud(ctx_, input_source, result_pose, result_cloud_ptr);
     return true;  // icp_registration.cpp:243
 }
@@ -131,12 +153,14 @@ bool NdtRegistration::ScanMatch(const CloudPtr& input_source, const SE3& predict
     if (Unsupported()) return false;  // a refusal, loudly (LastError): neither result_pose nor the output cloud is touched
     if (!input_source) return true;
     if (has_target_ && !input_source->points.empty()) {
-        double out[7];
+        // result_pose is in-out: status 2 (incremental, too few residuals) assigns the current pose (ndt cpp:351); status 1 (det(H) == 0)
+        // means AlignNdt returned before assigning it (ndt cpp:435-436) — the library leaves it as the caller had it and transforms the
+        // output cloud by that value (:258)
+        OutputCloud oc{input_source.get(), result_cloud_ptr.get()};
         locgpu_align_stats st;
-        if (locgpu_ndt_align(ctx_, input_source->points.data(), input_source->points.size(), sizeof(PointType), predict_pose.data(), out, &st) ==
-                LOCGPU_OK && st.status != 1)  // status 2 (incremental, too few residuals): result_pose = current pose (ndt cpp:351)
-            std::memcpy(result_pose.data(), out, sizeof(out));
-        // st.status == 1: det(H)==0 ⇒ AlignNdt returned before assigning result_pose (ndt cpp:435-436): leave it as the caller had it
+        if (locgpu_ndt_scan_match(ctx_, input_source->points.data(), input_source->points.size(), sizeof(PointType), predict_pose.data(),
+                                  result_pose.data(), &st, nullptr, sizeof(PointType) | LOCGPU_OUT_FIELDS_DONE, size_output_cloud, &oc) == LOCGPU_OK)
+            return true;  // ndt_registration.cpp:260
     }
     if (ctx_) write_output_cloud(ctx_, input_source, result_pose, result_cloud_ptr);
     return true;  // ndt_registration.cpp:260

@@ -79,8 +79,88 @@ static int run_refusals() {
     return bad ? 5 : 0;
 }
 
+// time mode: the call slam_demo makes — match_ptr_->ScanMatch(host cloud, predict, fresh output cloud, pose)
+// (loc.cpp:215,229) — timed end to end beside the C ABI's host-pointer alignment (no output cloud) on a second context.
+//   facade_scanmatch time <icp|ndt> <method 0..2> <map.bin> <scans.bin> <n_scans> <poses7.bin> <reps>
+// scans.bin: n_scans clouds of equal size back to back; poses7.bin: n_scans x 7 doubles. Prints one JSON line (ms per call).
+#include <algorithm>
+#include <chrono>
+#include "../../include/locgpu.h"
+static double median(std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; }
+static int run_time(char** argv) {
+    const std::string kind = argv[2];
+    const int method = std::atoi(argv[3]);
+    CloudPtr map = load(argv[4]), all = load(argv[5]);
+    const int n_scans = std::atoi(argv[6]), reps = std::atoi(argv[8]);
+    const size_t per = all->points.size() / (size_t)n_scans;
+    std::vector<CloudPtr> scans;
+    for (int s = 0; s < n_scans; ++s) {
+        CloudPtr c(new PointCloudType);
+        c->points.assign(all->points.begin() + s * per, all->points.begin() + (s + 1) * per);
+        scans.push_back(c);
+    }
+    std::vector<SE3> predict(n_scans);
+    {
+        FILE* f = std::fopen(argv[7], "rb");
+        if (!f) return 2;
+        for (int s = 0; s < n_scans; ++s) if (std::fread(predict[s].data(), 8, 7, f) != 7) return 2;
+        std::fclose(f);
+    }
+    std::shared_ptr<MatchingInterface> match_ptr;
+    locgpu_ctx* ctx = nullptr;
+    if (locgpu_create(0, &ctx) != LOCGPU_OK) return 3;
+    locgpu_icp_opts io;
+    locgpu_icp_opts_default(&io);
+    io.method = method;
+    if (kind == "icp") {
+        IcpOptions o(method == 0 ? IcpMethod::P2P : (method == 1 ? IcpMethod::P2LINE : IcpMethod::P2PLANE));
+        match_ptr = std::make_shared<IcpRegistration>(o);
+        if (locgpu_icp_set_target(ctx, map->points.data(), map->points.size(), sizeof(PointType)) != LOCGPU_OK) return 3;
+    } else {
+        match_ptr = std::make_shared<NdtRegistration>(NdtOptions());
+        locgpu_ndt_opts no;
+        locgpu_ndt_opts_default(&no);
+        if (locgpu_ndt_set_target(ctx, map->points.data(), map->points.size(), sizeof(PointType), &no) != LOCGPU_OK) return 3;
+    }
+    match_ptr->SetInputTarget(map);
+    using clk = std::chrono::steady_clock;
+    std::vector<double> t_facade, t_abi, t_abi_cloud;
+    std::vector<SE3> res_f(n_scans), res_a(n_scans);
+    for (int r = -1; r < reps; ++r) {  // r = -1: warm-up (buffers, first-call setup)
+        for (int s = 0; s < n_scans; ++s) {
+            const auto t0 = clk::now();
+            CloudPtr out(new PointCloudType);  // loc.cpp:215: a fresh output cloud per scan
+            match_ptr->ScanMatch(scans[s], predict[s], out, res_f[s]);
+            const auto t1 = clk::now();
+            if (out->points.size() != per || out->points[per - 1].intensity != scans[s]->points[per - 1].intensity) return 4;
+            double pose[7];
+            const auto t2 = clk::now();
+            const int rc = kind == "icp" ? locgpu_icp_align(ctx, scans[s]->points.data(), per, sizeof(PointType), predict[s].data(), &io, pose, nullptr)
+                                         : locgpu_ndt_align(ctx, scans[s]->points.data(), per, sizeof(PointType), predict[s].data(), pose, nullptr);
+            const auto t3 = clk::now();
+            if (rc != LOCGPU_OK) return 5;
+            std::memcpy(res_a[s].data(), pose, sizeof(pose));
+            if (r >= 0) {
+                t_facade.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+                t_abi.push_back(std::chrono::duration<double, std::milli>(t3 - t2).count());
+            }
+        }
+    }
+    for (int s = 0; s < n_scans; ++s)
+        if (std::memcmp(res_f[s].data(), res_a[s].data(), 56) != 0) return 6;  // the façade's pose is the C ABI's, bit for bit
+    double mf = 0, ma = 0;
+    for (double v : t_facade) mf += v;
+    for (double v : t_abi) ma += v;
+    std::printf("{\"kind\": \"%s\", \"method\": %d, \"points_per_scan\": %zu, \"map_points\": %zu, \"calls\": %zu, "
+                "\"facade_scanmatch_ms_median\": %.4f, \"facade_scanmatch_ms_mean\": %.4f, \"abi_align_host_pointer_ms_median\": %.4f, \"abi_align_host_pointer_ms_mean\": %.4f}\n",
+                kind.c_str(), method, per, map->points.size(), t_facade.size(), median(t_facade), mf / t_facade.size(), median(t_abi), ma / t_abi.size());
+    locgpu_destroy(ctx);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc == 2 && std::string(argv[1]) == "refusals") return run_refusals();
+    if (argc == 9 && std::string(argv[1]) == "time") return run_time(argv);
     if (argc == 8 && std::string(argv[1]) == "loam") return run_loam(argv);
     if (argc != 7) { std::fprintf(stderr, "usage\n"); return 2; }
     const std::string kind = argv[1];

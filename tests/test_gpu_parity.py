@@ -291,6 +291,55 @@ def test_transform_cloud_bit_exact(gpu_ctx, locref, small_world):
     np.testing.assert_array_equal(out_g[:, 4], s[:, 4])
 
 
+@pytest.mark.parametrize("method", ["p2p", "p2line", "p2plane", "ndt"])
+def test_scan_match_whole_equals_align_plus_transform(gpu_ctx, locref, small_world, method):
+    """locgpu_*_scan_match (ScanMatch whole: icp_registration.cpp:216-244, ndt_registration.cpp:238-261): the pose is locgpu_*_align's bit
+    for bit, the output cloud is the oracle's float32 transformPointCloud of the source under that pose bit for bit, every other field
+    of a point is the source's — as a separate output cloud and in place."""
+    from loc_lib_amd import api
+    m = small_world["map"]
+    s = np.zeros((2000, 8), dtype=np.float32)  # pcl::PointXYZI stride (32 bytes)
+    s[:, :3] = small_world["scan2k"][:, :3]
+    s[:, 3] = 1.0
+    s[:, 4] = np.arange(2000)
+    s[:, 5:] = 7.5
+    init = small_world["init_pose"]
+    if method == "ndt":
+        gpu_ctx.ndt_set_target(m)
+        want_pose, want_st = gpu_ctx.ndt_align(s, init)
+        pose, st, cloud = gpu_ctx.ndt_scan_match(s, init)
+    else:
+        gpu_ctx.icp_set_target(m)
+        opts = api.icp_opts(method=dict(p2p=api.P2P, p2line=api.P2LINE, p2plane=api.P2PLANE)[method])
+        want_pose, want_st = gpu_ctx.icp_align(s, init, opts)
+        pose, st, cloud = gpu_ctx.icp_scan_match(s, init, opts)
+    np.testing.assert_array_equal(pose, want_pose)
+    assert st == want_st
+    want_cloud = locref.transform_cloud_f32(pose, s)
+    np.testing.assert_array_equal(cloud.view(np.uint32), want_cloud.view(np.uint32))
+    np.testing.assert_array_equal(cloud[:, 3:], s[:, 3:])
+    if method != "ndt":
+        s2 = s.copy()
+        pose2, _, cloud2 = gpu_ctx.icp_scan_match(s2, init, opts, in_place=True)
+        assert cloud2 is s2
+        np.testing.assert_array_equal(pose2, want_pose)
+        np.testing.assert_array_equal(s2.view(np.uint32), want_cloud.view(np.uint32))
+
+
+def test_ndt_scan_match_det_zero_keeps_the_callers_pose(gpu_ctx, locref):
+    """det(H) == 0: AlignNdt returns before it assigns result_pose (ndt_registration.cpp:435-436) — the caller's value stays, and the
+    output cloud is the source under THAT pose (:258)."""
+    rng = np.random.RandomState(11)
+    m = (rng.rand(200, 3) * 100).astype(np.float32)
+    gpu_ctx.ndt_set_target(m)
+    init = np.array([0, 0, 0, 1.0, 1, 2, 3])
+    mine = np.array([0.0, 0.0, np.sin(0.2), np.cos(0.2), -4.0, 5.0, 6.0])
+    pose, st, cloud = gpu_ctx.ndt_scan_match(m[:50], init, result_pose=mine)
+    assert st["status"] == 1
+    np.testing.assert_array_equal(pose, mine)
+    np.testing.assert_array_equal(cloud.view(np.uint32), locref.transform_cloud_f32(mine, m[:50]).view(np.uint32))
+
+
 # ----------------------------------------------------------------------------------------------- NDT
 def test_ndt_voxel_table_matches_oracle(gpu_ctx, locref, small_world):
     m = small_world["map"]
