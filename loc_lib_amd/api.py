@@ -721,9 +721,10 @@ class Pool:
         else:
             sc, ptrs, cnts, stride = [], None, None, 16
         rc = lib().locgpu_pool_submit(self._h, ptrs, cnts, stride, len(sc), int(first), n_total, ip.ctypes.data, ctypes.byref(t))
+        if t.value:  # the job was accepted (a ticket was handed out): whatever rc says, the upload service may be reading the clouds
+            self._keep[t.value] = (sc, ptrs, cnts)  # they stay alive until the ticket has been waited for
+            self._n[t.value] = n_total
         self.ctx._check(rc)
-        self._keep[t.value] = (sc, ptrs, cnts)  # the clouds of a submit stay alive until its ticket has been waited for
-        self._n[t.value] = n_total
         return t.value
 
     def wait(self, ticket):

@@ -88,6 +88,11 @@ void run_upload(locgpu_ctx* ctx, Uploader& u, UploadRequest& rq) {
     for (int s = 0; s < n_up; ++s)
         for (size_t o = 0; o < rq.counts[s]; o += Uploader::kSlotPoints) units.push_back({s, o, std::min(Uploader::kSlotPoints, rq.counts[s] - o)});
     if (!ensure_slots(u, units.size(), err)) rc = LOCGPU_ERR_OOM;
+    {   // test hook (tests/test_gpu_pool.py): LOCGPU_TEST_FAIL_UPLOAD=n makes the n-th copy into a pool's regions of this process fail
+        static const int fail_at = [] { const char* e = getenv("LOCGPU_TEST_FAIL_UPLOAD"); return e ? atoi(e) : 0; }();
+        static std::atomic<int> seen{0};
+        if (fail_at > 0 && to_slots && ++seen == fail_at) { rc = LOCGPU_ERR_NO_DEVICE; err = "batch upload: injected failure (LOCGPU_TEST_FAIL_UPLOAD)"; }
+    }
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
     std::atomic<long long> wait_us{0}, pack_us{0};

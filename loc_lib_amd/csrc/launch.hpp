@@ -1,5 +1,6 @@
 // loc_lib_amd/csrc/launch.hpp — host-callable launchers of the kernels in icp_kernels.hip / ndt_kernels.hip.
 #pragma once
+#include "gn_post.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -69,21 +70,6 @@ int launch_icp_accum(int method, const AccumArgs& a, hipStream_t s);
 // list_counts (optional): the two search work-list counters, zeroed for the next iteration
 // scans (optional): n_scans indices — block i solves scan scans[i] instead of scan i
 // post (optional, one scan): the solve also writes an iteration word — and, once the scan is done, its result — to pinned host memory
-struct GnPostRecord {  // what the host needs of a finished scan's PoseState
-    static constexpr int kWords = 10;
-    unsigned long long w[kWords];  // q[4], t[3], last_dx_norm (bits) | last_eff | converged << 32 | status
-};
-struct GnPost {
-    GnPostRecord* record = nullptr;      // pinned, coherent host memory, 16-byte aligned
-    unsigned long long* word = nullptr;  // 16-byte aligned: [0] call << 32 | iterations << 1 | done, after every iteration; [1] checksum sealing the record
-    unsigned int call = 0;
-};
-// the checksum of a posted record (kernel and host compute the same)
-__host__ __device__ inline unsigned long long gn_post_sum(unsigned long long tag, const GnPostRecord& r) {
-    unsigned long long sum = tag * 0x9e3779b97f4a7c15ull;
-    for (int i = 0; i < GnPostRecord::kWords; ++i) sum = (sum ^ r.w[i]) * 0x100000001b3ull;
-    return sum;
-}
 void launch_gn_solve(const double* partials, int blocks_per_scan, PoseState* st, int n_scans, const GnParams& prm, int do_update, double* hb_out,
                      unsigned int* list_counts, hipStream_t s, const int* scans = nullptr, const GnPost* post = nullptr);
 int icp_accum_split(int method, int max_n, int n_scans);  // points per thread of the accumulate kernels (the split of the partial sums)

@@ -1048,15 +1048,13 @@ static int paced_launch(locgpu_ctx* ctx, locgpu_batch* b, int upto) {
 
 // Wait for a post of this call that is newer than iteration `seen`; returns the word. A post with the done bit is taken only when the
 // state behind it is complete (its checksum matches what this thread reads: the kernel's stores carry no fence).
+constexpr int kPacedTimeoutS = 30;  // an iteration of the largest alignment this path takes (one scan) lasts well under a millisecond
 static int paced_wait(locgpu_ctx* ctx, locgpu_batch* b, int seen, unsigned long long* out) {
-    const unsigned long long* word = b->h_post + locgpu_batch::kPostWord;
     auto fresh = [&](unsigned long long* w_out) {
-        const unsigned long long w = __atomic_load_n(word, __ATOMIC_ACQUIRE);
-        if ((unsigned int)(w >> 32) != b->post_call || (int)((w & 0xffffffffull) >> 1) <= seen) return false;
+        unsigned long long w;
+        GnPostRecord r;
+        if (!gn_post_take(b->h_post, locgpu_batch::kPostWord, b->post_call, seen, &w, &r)) return false;
         if (w & 1ull) {
-            GnPostRecord r;
-            for (int i = 0; i < GnPostRecord::kWords; ++i) r.w[i] = __atomic_load_n(b->h_post + i, __ATOMIC_RELAXED);
-            if (gn_post_sum(w, r) != __atomic_load_n(word + 1, __ATOMIC_RELAXED)) return false;  // still on its way
             PoseState& ps = b->h_state[0];
             for (int i = 0; i < 4; ++i) std::memcpy(&ps.q[i], &r.w[i], 8);
             for (int i = 0; i < 3; ++i) std::memcpy(&ps.t[i], &r.w[4 + i], 8);
@@ -1074,11 +1072,20 @@ static int paced_wait(locgpu_ctx* ctx, locgpu_batch* b, int seen, unsigned long 
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned long spins = 1;; ++spins) {
         if (fresh(out)) return LOCGPU_OK;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();  // a polite spin: the sibling hyper-thread (the uploader, the helper thread) gets the core's issue slots
+#endif
         if ((spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
             // nothing for a long time: is the stream still working? An idle stream with no post means a kernel died or the posts do
             // not reach the host. (Not earlier: a stream query is a runtime call on the latency path.)
             const hipError_t q = hipStreamQuery(b->stream);
-            if (q == hipErrorNotReady) continue;
+            if (q == hipErrorNotReady) {
+                // a stream that stays busy without ever posting (a hung kernel) must not spin a core for ever: give up after kPacedTimeoutS
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kPacedTimeoutS))
+                    return fail(ctx, LOCGPU_ERR_NO_DEVICE, "paced alignment: no post from the solve kernel within the time-out (the stream is still busy)");
+                std::this_thread::yield();
+                continue;
+            }
             if (q != hipSuccess) { hip_ok(ctx, q, "paced alignment"); return LOCGPU_ERR_NO_DEVICE; }
             if (fresh(out)) return LOCGPU_OK;
             return fail(ctx, LOCGPU_ERR_NO_DEVICE, "paced alignment: the stream is idle and the solve kernel's post has not arrived");

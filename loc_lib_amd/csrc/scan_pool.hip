@@ -32,6 +32,7 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "batch_upload.hpp"
@@ -53,6 +54,13 @@ struct PoolJob : PoolSchedJob {  // pool_sched.hpp: ticket, n_total, first, n_lo
     // the copy of its points goes in pieces of kUploadPiece scans, each with its own event: the first scans of a large job enter the
     // pool while its last ones are still on their way (a 256-scan job is 472 MB: 14 ms at PCIe speed)
     std::vector<std::unique_ptr<BatchUploadState>> upl;
+    // A piece of the job's copy failed: the job is FAILED, not stuck — its remaining scans enter with zero points (they run to
+    // max_iteration without an update; direct NDT: det(H) = 0 at once), leave, give their slots and regions back, and locgpu_pool_wait
+    // reports failed_rc for this ticket while every other job goes on. With several ranks the failure is this rank's alone and no
+    // rank skips anything: the launch sequence and the collectives are those of a healthy job, so nobody waits in an all-reduce
+    // for a rank that has left (the ranks that hold no failed copy see the scan end unconverged).
+    int failed_rc = 0;
+    std::string failed_msg;
 };
 
 constexpr int kUploadPiece = 32;
@@ -100,6 +108,8 @@ struct locgpu_pool {
     long long chunks = 0;
     std::vector<hipEvent_t> stage_ev;     // profile mode 1: four per iteration of the chunk — search | fit+accumulate | solve (+ exchange)
     size_t stage_used = 0;
+    int deferred_rc = 0;                  // a pump failure behind an accepted submit: reported by the next step / wait
+    std::string deferred_msg;
 };
 
 namespace {
@@ -245,17 +255,23 @@ int pool_launch(locgpu_pool* P) {
             if (!j->holds(i) || (i - j->first) % kUploadPiece != 0) return true;
             // the first scan of an upload piece: a copy still on its way must not stall the scans that are running (one rank
             // only: with several ranks every decision has to be the same everywhere, so the stream simply waits for the copy)
+            if (j->failed_rc) return true;  // a failed job's scans enter empty (see PoolJob::failed_rc)
             BatchUploadState* u = j->upl[(size_t)(i - j->first) / kUploadPiece].get();
             const bool may_defer = !P->multi_rank && (open_now > 0 || !admitted.empty());
             if (may_defer && upload_host_busy(u)) return false;
-            rc_admit = upload_join_state(ctx, u);
-            if (rc_admit != LOCGPU_OK) return false;
+            const int urc = upload_join_state(ctx, u);
+            if (urc != LOCGPU_OK) {
+                j->failed_rc = urc;
+                j->failed_msg = ctx->err;
+                for (int& c : j->counts) c = 0;  // scans already in the pool keep their points (their pieces landed); the rest run on nothing
+                return true;
+            }
             if (may_defer && hipEventQuery(u->done) == hipErrorNotReady) return false;
             if (!hip_ok(ctx, hipStreamWaitEvent(s, u->done, 0), "pool: hipStreamWaitEvent")) { rc_admit = LOCGPU_ERR_NO_DEVICE; return false; }
             return true;
         },
         admitted);
-    if (rc_admit != LOCGPU_OK) return rc_admit;
+    if (rc_admit != LOCGPU_OK) return rc_admit;  // a stream error (not a job's copy: that fails its job, above)
     for (const PoolAdmitted& a : admitted) {
         PoolJob* j = static_cast<PoolJob*>(a.job);
         init_state(b->h_state[a.slot], &j->init[7 * (size_t)a.idx]);
@@ -475,8 +491,12 @@ int locgpu_pool_submit(locgpu_pool* P, const void* const* srcs, const size_t* co
     }
     P->jobs[j->ticket] = j;
     *ticket = j->ticket;
-    // keep the pool turning while the caller only submits: an idle pool starts at once; a running one is looked at without waiting
-    return pool_pump(P, false);
+    // keep the pool turning while the caller only submits: an idle pool starts at once; a running one is looked at without waiting.
+    // The job is LIVE from here on (its copy reads the caller's clouds, its ticket must be waited for): a failure of this turn of the
+    // pool is not the submit's — it is kept and returned by the next locgpu_pool_step / locgpu_pool_wait.
+    const int prc = pool_pump(P, false);
+    if (prc != LOCGPU_OK && P->deferred_rc == LOCGPU_OK) { P->deferred_rc = prc; P->deferred_msg = ctx->err; }
+    return LOCGPU_OK;
 }
 
 int locgpu_pool_wait(locgpu_pool* P, int64_t ticket, double* out_poses, locgpu_align_stats* stats) {
@@ -486,6 +506,7 @@ int locgpu_pool_wait(locgpu_pool* P, int64_t ticket, double* out_poses, locgpu_a
     if (it == P->jobs.end() || !out_poses) return pool_fail(P, LOCGPU_ERR_INVALID, "pool_wait: unknown ticket or NULL output");
     PoolJob* j = it->second;
     LOCGPU_HIP(ctx, hipSetDevice(ctx->device));
+    if (P->deferred_rc != LOCGPU_OK) { const int rc = P->deferred_rc; P->deferred_rc = LOCGPU_OK; return pool_fail(P, rc, P->deferred_msg); }
     while (j->remaining > 0) {
         bool progress = false;
         const int rc = pool_pump(P, true, &progress);
@@ -494,14 +515,21 @@ int locgpu_pool_wait(locgpu_pool* P, int64_t ticket, double* out_poses, locgpu_a
     }
     std::memcpy(out_poses, j->out.data(), j->out.size() * sizeof(double));
     if (stats) std::memcpy(stats, j->stats.data(), j->stats.size() * sizeof(locgpu_align_stats));
+    int rc = LOCGPU_OK;
+    if (j->failed_rc) {
+        // the pieces that did not fail may still be read by the upload service: the caller frees its clouds when this returns
+        for (auto& u : j->upl) (void)upload_join_state(ctx, u.get());
+        rc = pool_fail(P, j->failed_rc, "pool: the copy of job " + std::to_string((long long)ticket) + " failed (" + j->failed_msg + "); its poses are not valid");
+    }
     P->jobs.erase(it);
     job_free(j);
-    return LOCGPU_OK;
+    return rc;
 }
 
 int locgpu_pool_step(locgpu_pool* P, int block) {
     if (!P) return LOCGPU_ERR_INVALID;
     LOCGPU_HIP(P->ctx, hipSetDevice(P->ctx->device));
+    if (P->deferred_rc != LOCGPU_OK) { const int rc = P->deferred_rc; P->deferred_rc = LOCGPU_OK; return pool_fail(P, rc, P->deferred_msg); }
     return pool_pump(P, block != 0);
 }
 

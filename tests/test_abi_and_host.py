@@ -340,6 +340,28 @@ def test_pool_bookkeeping_is_lock_step_across_ranks_under_sanitizers(tmp_path):
         assert r.returncode == 0 and r.stdout.count(" OK") >= 3, r.stdout[-1000:] + r.stderr[-3000:]
 
 
+def test_finished_scan_post_rejects_torn_reads(tmp_path):
+    """The finished-scan post of a one-scan alignment paced from the host (csrc/gn_post.hpp): the solve kernel's stores to pinned host
+    memory carry no fence, so the record and its {tag, checksum} pair may arrive in any order. tests/cpp/gn_post_sanitize.cpp plays the
+    device: it makes a new post visible ONE WORD AT A TIME — random orders, the pair overtaking the record, the checksum before the tag —
+    over the previous post's words and asks gn_post_take() after every word: never a yes before every word it hands back is the new
+    post's, never a yes for a stale call number or an iteration already seen, always a yes once everything is there; then a writer
+    thread against a polling reader for 20 000 posts. ASan + UBSan on. (What's weak 9)"""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "gn_post_sanitize")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-pthread",
+           "-I", os.path.join(ROOT, "loc_lib_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "gn_post_sanitize.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "accepted early 0, wrong content 0, missed 0" in r.stdout and "20000 taken, 0 wrong" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 # ----------------------------------------------------------------------------------------------- bench.py launcher (no GPU needed)
 def _load_bench():
     import importlib.util

@@ -588,6 +588,32 @@ def test_cpp_facade_scanmatch(locref, small_world, tmp_path, kind, method):
     np.testing.assert_array_equal(cloud.view(np.uint32), locref.transform_cloud_f32(pose, s[:, :3]).view(np.uint32))
 
 
+def test_cpp_facade_search_plugins(locref, small_world, tmp_path):
+    """KdtreeRegistration::SetTargetCloud / FindNearstPoints / SetEnableANN and BfnnRegistration through SearchPointInterface
+    (search_point_interface.h:9-24, kdtree.cpp:261-288, bfnn.cpp:24-50; tests/cpp/facade_search.cpp) against the oracle's lists:
+    the tree as constructed (ANN, alpha 0.1), exact, ANN with another alpha; brute force — index for index, in order."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "cpp", "facade_search")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    m = np.ascontiguousarray(small_world["map"][:60000, :3], dtype=np.float32)
+    rng = np.random.RandomState(5)
+    q = (m[rng.randint(0, len(m), 300)] + rng.normal(0, 0.05, (300, 3))).astype(np.float32)
+    k = 5
+    m.tofile(tmp_path / "map.bin")
+    q.tofile(tmp_path / "q.bin")
+    r = subprocess.run([exe, str(tmp_path / "map.bin"), str(tmp_path / "q.bin"), str(k), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout + r.stderr)
+    got = np.fromfile(tmp_path / "out.bin", dtype=np.int32).reshape(5, len(q), k)
+    tree = locref.KdTree(m)
+    np.testing.assert_array_equal(got[0], tree.knn(q, k, approximate=True, alpha=0.1))
+    np.testing.assert_array_equal(got[1], tree.knn(q, k, approximate=False))
+    np.testing.assert_array_equal(got[2], tree.knn(q, k, approximate=True, alpha=0.3))
+    want_bf = locref.bfnn_knn(m, q, k)
+    np.testing.assert_array_equal(got[3], want_bf)
+    np.testing.assert_array_equal(got[4], want_bf)
+
+
 def test_cpp_facade_loam(locref, small_world, tmp_path):
     """LoamRegistration (loam_registration.cpp:38-99): edge P2Line + surf P2Plane normal equations summed, own GN loop (eps 1e-3)."""
     import os

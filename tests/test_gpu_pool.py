@@ -112,3 +112,78 @@ def test_sharded_pool_over_rccl_one_rank(api, small_world):
                            capture_output=True, text=True, timeout=900, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         assert "pool over rccl ok" in r.stdout
+
+
+@pytest.mark.parametrize("approx", [1, 0])
+def test_pooled_scans_on_the_64_lane_kernels_equal_the_plain_batch_on_the_16_lane_one(gpu_ctx, api, small_world, approx):
+    """launch_walk_kd picks the search kernel by the number of waves of the LAUNCH — the 16-lane kernel (every level stored,
+    ties answered in the wave) below 2 048 full waves, the 64-lane walk + deep pass + redo chain above — so a pooled scan can run
+    another kernel than in its plain batch. Forty slots x ~6 000 points are ≈ 3 800 waves (the chain), a plain four-scan batch ≈ 380
+    (the 16-lane kernel): the jobs' poses, iteration counts and stats must still be the plain batches' bit for bit, with the
+    reference's alpha-pruned search and with the exact one."""
+    gpu_ctx.icp_set_target(small_world["map"])
+    opts = api.icp_opts(method=api.P2PLANE)
+    opts.approximate = approx
+    jobs = _jobs(small_world, 16, 4)  # the kernel is chosen by ceil(max_points / 64) x open slots: 94 x 40 at first (the chain), the 16-lane kernel once ≤ 21 slots are open
+    want = []
+    for scans, inits in jobs:
+        b = gpu_ctx.batch(scans)
+        want.append(gpu_ctx.icp_align_batch(b, inits, opts))
+        b.close()
+    pool = api.Pool(gpu_ctx, slots=40, max_points=6000, scans_per_job=4, chunk=2, opts=opts, prefetch=8)
+    tickets = [pool.submit(scans, inits) for scans, inits in jobs]
+    assert pool.info()["slots"] == 40
+    for t, w in zip(tickets, want):
+        got, st = pool.wait(t)
+        assert np.array_equal(got, w[0])
+        assert st == w[1]
+    pool.close()
+
+
+_FAILED_COPY_CASE = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from loc_lib_amd import api, synth
+ctx = api.Context(0)
+ctx.icp_set_target(synth.make_local_map(200000, 3, half=40.0))
+opts = api.icp_opts(method=api.P2PLANE)
+s, pose = synth.make_scan(3, subsample=10000, crop_half=36.0), synth.make_pose(3)[1]
+jobs = [([np.ascontiguousarray(s[j::3][:3000 + 100 * i]) for i in range(3)], np.stack([pose] * 3)) for j in range(3)]
+want = []
+for scans, inits in jobs:
+    b = ctx.batch(scans)
+    want.append(ctx.icp_align_batch(b, inits, opts))
+    b.close()
+pool = api.Pool(ctx, slots=4, max_points=4000, scans_per_job=3, chunk=2, opts=opts, prefetch=8)
+tickets = [pool.submit(scans, inits) for scans, inits in jobs]   # every submit returns its ticket: the second job's copy fails LATER, on the service thread
+for k in (0, 2):
+    got, st = pool.wait(tickets[k])
+    assert np.array_equal(got, want[k][0]) and st == want[k][1], k
+try:
+    pool.wait(tickets[1])
+    raise SystemExit("the failed job's wait did not fail")
+except RuntimeError as e:
+    assert "injected failure" in str(e), str(e)
+info = pool.info()
+assert info["free"] == 4 and info["free_regions"] == 12 and info["jobs"] == 0 and info["open"] == 0, info
+t = pool.submit(*jobs[0])   # and the pool goes on
+got, st = pool.wait(t)
+assert np.array_equal(got, want[0][0])
+pool.close()
+ctx.close()
+print("failed copy case ok")
+"""
+
+
+def test_a_failed_copy_fails_its_job_and_not_the_pool(tmp_path):
+    """a copy that fails on the upload service thread used to leave its job at the head of the waiting list for good —
+    every later submit / step / wait returned its error and no slot or region came back. Now the job is FAILED: its scans pass through
+    the pool empty, locgpu_pool_wait(ticket) reports the failure, the jobs before and behind it get the plain batches' bits, every slot
+    and region is free at the end and the pool takes further jobs. (LOCGPU_TEST_FAIL_UPLOAD=2: the second region copy of the process.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FAILED_COPY_CASE], env=dict(os.environ, LOCGPU_TEST_FAIL_UPLOAD="2"), capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "failed copy case ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
