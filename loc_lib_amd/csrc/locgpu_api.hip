@@ -808,6 +808,10 @@ bool IterLauncher::launch(int do_update) {
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
         AccumArgs aa{ctx->d_tree, batch_src(b), b->d_counts, st_local, b->d_nn, b->pitch, b->max_n, b->n_scans, gate, b->d_partials};
         aa.active = active; aa.n_active = n_active;
+        // a rank of a scan-sharded batch splits the partial sums as the WHOLE batch would (points per thread follow the batch's size):
+        // the order of a scan's additions — hence its bits — must not depend on how many ranks share the batch (found by the eight-rank
+        // loopback run of round 6: 32 of 256 scans per rank summed one point per thread where the plain batch sums four)
+        if (b->sharded) aa.split_scans = b->n_total;
         n_partial_blocks = launch_icp_accum(prm.method, aa, s);
     } else {
         mark(true);  // NDT has no separate search kernel: search slot stays empty
@@ -815,7 +819,7 @@ bool IterLauncher::launch(int do_update) {
             launch_inc_accum(ctx->inc, ctx->ndt_opts.res_outlier_th, ctx->ndt_opts.nearby_type == 0 ? 1 : 7, batch_src(b), b->d_counts, st_local,
                              b->max_n, b->n_scans, b->d_partials, s);
         else
-            n_partial_blocks = launch_ndt_accum(ctx->ndt, batch_src(b), b->d_counts, st_local, b->max_n, b->n_scans, b->d_partials, s);
+            n_partial_blocks = launch_ndt_accum(ctx->ndt, batch_src(b), b->d_counts, st_local, b->max_n, b->n_scans, b->d_partials, s, nullptr, 0, b->sharded ? b->n_total : 0);
     }
     mark();
     if (b->sharded) {

@@ -50,6 +50,7 @@ struct Group {
 };
 std::mutex g_mu;
 std::map<uint64_t, std::unique_ptr<Group>> g_groups;
+std::atomic<unsigned long long> g_calls[8];  // collectives entered per rank, over all communicators of the process (loopback_rccl_counts)
 std::atomic<uint64_t> g_next_id{1};
 
 constexpr int kMaxWorld = 8;
@@ -82,6 +83,7 @@ template <typename Before, typename After>
 ncclResult_t rendezvous(Comm* c, size_t bytes, Before before, After after) {
     Group* g = c->g;
     const uint64_t seq = c->seq++;
+    g_calls[c->rank & 7]++;
     const int slot = (int)(seq % kRing);
     if (!before(slot)) return ncclUnhandledCudaError;
     {
@@ -240,6 +242,11 @@ ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataT
             }
             return hipEventRecord(c->done[slot], s) == hipSuccess;
         });
+}
+
+// test hook: collectives each rank has entered so far (the ranks of a correct library make the same number of them)
+void loopback_rccl_counts(unsigned long long out[8]) {
+    for (int r = 0; r < 8; ++r) out[r] = g_calls[r].load();
 }
 
 const char* ncclGetErrorString(ncclResult_t r) {
