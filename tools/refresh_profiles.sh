@@ -1,6 +1,6 @@
-# The ONE entry point that refreshes every profiles/r05_* artefact on one box after the last kernel change:
+# The ONE entry point that refreshes every profiles/r06_* artefact on one box after the last kernel change:
 #     gpurun --timeout 3600 -- 'bash tools/refresh_profiles.sh'
-# Results land in gpurun_out/final (copy what is to be judged into profiles/ as r05_<name>). Every command has its own timeout: a hung
+# Results land in gpurun_out/final (copy what is to be judged into profiles/ as r06_<name>). Every command has its own timeout: a hung
 # kernel must not eat the box. Under rocprofv3 the program itself follows `--` (never a shell or env wrapper).
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
@@ -26,6 +26,9 @@ timeout 600 python bench.py --search grid --steps 10 --warmup 3 --no-cpu-baselin
 # ---- direct NDT: the line with live counters (row 3b), kernel stats below
 timeout 600 python bench.py --method ndt --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | line > $O/bench_ndt_line.json
 timeout 400 python3 tools/collect_pmc.py --out $O/pmc_ndt_kernel.md --scans 64 --method ndt > /dev/null 2>&1
+# ---- the call slam_demo makes (facade ScanMatch: host cloud in, host cloud + pose out), the K1 occupancy point of the shipped shape and of round 5's
+timeout 900 python3 tests/perf/facade_time.py --out $O/facade_time.json > $O/facade_time.md 2>/dev/null
+(timeout 200 python tools/k1_occupancy.py --bytes 5120,5120; LOCGPU_FAST_STACK=15 timeout 200 python tools/k1_occupancy.py --bytes 7680,7680) > $O/k1_shape_ab.txt 2>&1
 # ---- latency, counters, tables, traces
 timeout 200 python tools/latency_microbench.py 2>/dev/null | line > $O/latency.json
 timeout 400 python3 tools/collect_pmc.py --out $O/pmc_kernels.md --scans 64 > /dev/null 2>&1
@@ -53,7 +56,8 @@ stats bench_ndt --method ndt --steps 20 --warmup 5 --pipeline 1
 stats bench_grid --search grid --steps 10 --warmup 3 --pipeline 1
 stats bench_strong_1rank_32_pool --scaling strong --total-scans 32 --steps 160 --warmup 8 --pool-lanes 1
 cd $R
-# ---- parity at length
+# ---- the GPU suite, then parity at length
+timeout 2400 python -m pytest tests -m gpu -q -x > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
 timeout 600 python tools/ndt_determinism.py --reps 5000 > $O/ndt_determinism.log 2>&1
 timeout 500 python tools/fuzz_search.py --cases 300 --seed 4 > $O/fuzz_search.log 2>&1
 timeout 600 python tools/fuzz_ndt.py --cases 900 > $O/fuzz_ndt.log 2>&1
