@@ -21,11 +21,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=256)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--search", default="tree", help="bench.py --search (tree | tree_exact | grid)")
     a = ap.parse_args()
     d = tempfile.mkdtemp(prefix="locgpu_itrace_", dir="/tmp")
     try:
         cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--", "python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
-               "--resident", "--pipeline", "1", "--extra-steps", "1", "--no-cpu-baseline", "--traffic", "none", "--scans-per-gpu", str(a.scans)]
+               "--resident", "--pipeline", "1", "--extra-steps", "1", "--no-cpu-baseline", "--traffic", "none", "--scans-per-gpu", str(a.scans), "--search", a.search]
         subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", timeout=900, check=True)
         f = glob.glob(os.path.join(d, "**", "t_kernel_trace.csv"), recursive=True)[0]
         rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
@@ -33,7 +34,7 @@ def main():
         shutil.rmtree(d, ignore_errors=True)
 
     def key(n):
-        for k, pat in (("walk", "icp_search_walk_kernel"), ("deep", "icp_search_walk_list"), ("redo", "icp_search_redo"),
+        for k, pat in (("ball", "grid_ball_search"), ("walk", "icp_search_walk_kernel"), ("deep", "icp_search_walk_list"), ("redo", "icp_search_redo"),
                        ("refit", "plane_refit"), ("accum", "accum_kernel"), ("solve", "gn_solve")):
             if pat in n:
                 return k
