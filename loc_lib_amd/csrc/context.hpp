@@ -148,7 +148,6 @@ struct locgpu_batch {
     uint32_t* d_nn = nullptr;      // [5][pitch]
     const float4* d_src_ext = nullptr;           // one-scan batches: the points stay where the caller's cloud holds them (no copy into d_src); nullptr = d_src
     bool counters_clean = false;                 // the search stage's work-list counters are known to be zero (the last alignment ran to its end)
-    bool grid_lists_live = false;                // grid mode: d_nn holds the lists of the previous iteration of the alignment in progress
     int last_iterations = -1;                    // one-scan batches: iterations of the previous alignment run on this batch (-1: none yet) — sizes the next first chunk
     double* d_partials = nullptr;  // [n_scans][blocks_per_scan][kAccW]
     double* d_hb = nullptr;        // [n_scans][44]

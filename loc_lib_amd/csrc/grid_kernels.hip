@@ -460,90 +460,6 @@ __global__ __launch_bounds__(64) void grid_tile_search_kernel(GridDev g, const u
     }
 }
 
-// ------------------------------------------------------------------------------------------------ the ball kernel (round 6)
-// Exact k-NN from the second Gauss–Newton iteration of an alignment on. The k leaves the PREVIOUS iteration found for a source point are
-// map points, so the largest of their float32 distances to the point's NEW position, B, bounds its new k-th distance from above: every
-// new neighbour lies in the ball of radius √B — with the pose moving by millimetres to centimetres per iteration that is a handful of
-// cells instead of the 27 (then 125) the tile kernel stages, and no binning of the queries by tile is needed at all. One thread per
-// query: the cells the ball's bounding box touches (tile hash → tile record → the cell's run of the (tile, cell)-sorted leaves), the
-// reference's distance expression, candidates beyond B skipped, the rest through the same branch-free result set as the tile kernel
-// (ties → the tree, whose heap decides their order). A query whose ball touches more than kBallCells cells — the first iterations of
-// a far start — goes to the tree as well: such a query's first list entry is set to kNeedsTree and the walk kernel launched behind
-// this one (SearchArgs::marked_only) searches exactly the marked queries.
-constexpr int kBallCells = 64;
-template <int K>
-__global__ __launch_bounds__(kBlock) void grid_ball_search_kernel(GridDev g, const uint2* __restrict__ tree, const float4* __restrict__ src,
-                                                                  const int* __restrict__ counts, const PoseState* __restrict__ st, uint32_t* __restrict__ nn,
-                                                                  size_t nn_pitch, int max_n, int skip_nonfinite, unsigned long long* __restrict__ search_stats,
-                                                                  const int* __restrict__ active, const int* __restrict__ src_of) {
-    const int scan = active ? active[blockIdx.y] : (int)blockIdx.y;
-    if (st[scan].done) return;  // uniform per block
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const size_t gi = (size_t)scan * max_n + i;
-    bool to_tree = false, counted = false;
-    if (i < counts[scan]) {
-        const float4 p = src[(size_t)(src_of ? src_of[scan] : scan) * max_n + i];
-        if (skip_nonfinite && !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {  // pcl::isFinite, icp cpp:64 (P2P only)
-#pragma unroll
-            for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = kInvalidSlot;
-        } else {
-            counted = true;
-            const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
-            const float qx = (float)qs.x, qy = (float)qs.y, qz = (float)qs.z;
-            // B: the previous iteration's k leaves at the new position (a list that is not there — k > size_, a non-finite point of an
-            // earlier pose — leaves B infinite: the tree answers)
-            float B = 0.f;
-            bool have = qx == qx && qy == qy && qz == qz;
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const uint32_t slot = nn[(size_t)j * nn_pitch + gi];
-                have = have && slot != kInvalidSlot;
-                const uint2 a = tree[slot != kInvalidSlot ? slot : 0u], b2 = tree[slot != kInvalidSlot ? slot + 1u : 1u];  // a leaf: {x, idx}{y, z}
-                const float dx = qx - __uint_as_float(a.x), dy = qy - __uint_as_float(b2.x), dz = qz - __uint_as_float(b2.y);
-                B = fmaxf(B, dx * dx + (dy * dy + dz * dz));
-            }
-            have = have && B < 3.0e38f;
-            const float r = sqrtf(B) * 1.00002f + 1e-30f;  // |q − p| ≤ √B on every axis, with room for the roundings of B and of the square root
-            const int x0 = max(cell_coord(qx - r, g.ox, g.inv_cell), 0), x1 = min(cell_coord(qx + r, g.ox, g.inv_cell), g.nx - 1);
-            const int y0 = max(cell_coord(qy - r, g.oy, g.inv_cell), 0), y1 = min(cell_coord(qy + r, g.oy, g.inv_cell), g.ny - 1);
-            const int z0 = max(cell_coord(qz - r, g.oz, g.inv_cell), 0), z1 = min(cell_coord(qz + r, g.oz, g.inv_cell), g.nz - 1);
-            const long long ncell = (long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1);
-            if (!have || x1 < x0 || y1 < y0 || z1 < z0 || ncell > kBallCells) {
-                to_tree = true;
-            } else {
-                TopK<K> set;
-                set.init();
-                for (int cz = z0; cz <= z1; ++cz)
-                    for (int cy = y0; cy <= y1; ++cy)
-                        for (int cx = x0; cx <= x1; ++cx) {
-                            const uint2 c = cell_lookup(g, cx, cy, cz);
-                            for (uint32_t pi = c.x; pi < c.x + c.y; ++pi) {
-                                const float4 pt = g.pts[pi];
-                                const float dx = qx - pt.x, dy = qy - pt.y, dz = qz - pt.z;
-                                const float d2 = dx * dx + (dy * dy + dz * dz);  // Eigen squaredNorm order, no FMA (-ffp-contract=off)
-                                if (d2 <= B) set.offer(d2, __float_as_uint(pt.w));
-                            }
-                        }
-                const bool tie = set.finish();
-                if (set.full() && !tie) {
-#pragma unroll
-                    for (int j = 0; j < K; ++j) nn[(size_t)j * nn_pitch + gi] = set.id[j];
-                } else {
-                    to_tree = true;
-                }
-            }
-        }
-    }
-    if (to_tree) nn[gi] = kNeedsTree;  // the walk kernel behind this one answers the marked queries (SearchArgs::marked_only)
-    if (search_stats) {
-        const unsigned long long m = __ballot(counted), mt = __ballot(to_tree);
-        if ((int)__lane_id() == 0) {
-            if (m) atomicAdd(&search_stats[0], (unsigned long long)__popcll(m));
-            if (mt) atomicAdd(&search_stats[2], (unsigned long long)__popcll(mt));
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ ring walk (locgpu_knn only)
 // Plain exact k-NN over given queries (locgpu_knn with LOCGPU_SEARCH_GRID_EXACT). out_idx[i*k] = -2 marks a query the caller
 // must answer with the tree kernel.
@@ -570,17 +486,6 @@ static GridDev to_dev(const GridView& v) {
 
 template <int K>
 static bool search_grid_k(const GridView& grid, const GridDev& g, const SearchArgs& a, const GridSearchScratch& sc, hipStream_t s) {
-    static const int ball = [] { const char* e = getenv("LOCGPU_GRID_BALL"); return e ? atoi(e) : 1; }();  // 0: the round-2 tile pipeline on every iteration (A/B)
-    if (ball) {
-        // the first iteration of an alignment has no lists to bound anything with: the exact tree search (the walk kernel with alpha = 1)
-        if (!a.prev_lists) return launch_icp_search(a, s);
-        const dim3 bb((a.max_n + kBlock - 1) / kBlock, a.active ? a.n_active : a.n_scans);
-        hipLaunchKernelGGL((grid_ball_search_kernel<K>), bb, dim3(kBlock), 0, s, g, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n, a.skip_nonfinite,
-                           a.search_stats, a.active, a.src_of);
-        SearchArgs rest = a;  // a.alpha_eff = 1: the exact tree search (walk → deep pass → redo) over the marked queries only
-        rest.marked_only = true;
-        return launch_icp_search(rest, s);
-    }
     const dim3 blocks((a.max_n + kBlock - 1) / kBlock, a.n_scans);
     // work lists: redo_list2 = queries for the fast tree traversal, redo_list = what that hands to the exact redo kernel
     (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned int), s);

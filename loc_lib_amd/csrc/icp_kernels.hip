@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
                                                              unsigned int tree_bytes, uint32_t dummy, int skip_nonfinite, uint32_t* __restrict__ redo_list,
                                                              unsigned int* __restrict__ redo_count, uint32_t* __restrict__ deep_list,
                                                              unsigned int* __restrict__ deep_count, unsigned long long* __restrict__ search_stats,
-                                                             const int* __restrict__ active, const int* __restrict__ src_of, int marked_only) {
+                                                             const int* __restrict__ active, const int* __restrict__ src_of) {
     extern __shared__ uint2 s_dyn[];
     constexpr int ROWB = LANES * 8;
     static_assert(DF * ROWB >= 64 * 2 * 8, "exact stack columns do not fit");
@@ -134,15 +134,8 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     const float4 p = load_once(&src[(size_t)(src_of ? src_of[scan] : scan) * max_n + i]);
     // pcl::isFinite, icp cpp:64 (P2P only): such a point has no neighbours; its lane stays in the wave with nothing to do (the list
     // it stores at the end is the empty one)
-    bool finite = !skip_nonfinite || (isfinite(p.x) && isfinite(p.y) && isfinite(p.z));
-    // behind the exact grid search's ball kernel (SearchArgs::marked_only): only the queries it marked; the others keep their lists
-    bool run = true;
-    if (marked_only) {
-        run = nn[gi] == kNeedsTree;
-        if (__ballot(run) == 0ull) return;
-        finite = finite && run;
-    }
-    if (search_stats && finite && !marked_only) atomicAdd(&search_stats[0], 1ull);
+    const bool finite = !skip_nonfinite || (isfinite(p.x) && isfinite(p.y) && isfinite(p.z));
+    if (search_stats && finite) atomicAdd(&search_stats[0], 1ull);
     const D3 qs = se3_apply(st[scan].q, st[scan].t, D3{(double)p.x, (double)p.y, (double)p.z});
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tree, 0, (int)tree_bytes, 0x00020000);
     Walk<K> w;
@@ -159,7 +152,7 @@ __global__ __launch_bounds__(64) void icp_search_walk_kernel(const uint2* __rest
     }
     const bool deep = w.c3n == 1u;
     const bool slow = !deep && w.slow != 0u;
-    if (run && !deep && !slow) {
+    if (!deep && !slow) {
 #pragma unroll
         for (int j = 0; j < K; ++j) __builtin_nontemporal_store(w.id[j], &nn[(size_t)j * nn_pitch + gi]);
     }
@@ -845,7 +838,7 @@ static bool launch_walk_kd(const SearchArgs& a, hipStream_t s) {
         // 16-lane kernel answers its ties itself: no redo launch on the latency path
         dim3 g1((a.max_n + 15) / 16, n_launch);
         hipLaunchKernelGGL((icp_search_walk_kernel<K, D + 2, 16>), g1, dim3(64), (D + 2) * 16 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.alpha_eff, 0, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of, a.marked_only ? 1 : 0);
+                           a.alpha_eff, 0, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of);
         return true;
     }
     // rows 0/1 of the DF stored rows hold the candidates of the un-stored levels, the other DF-2 rows one level each. Queries whose
@@ -865,10 +858,10 @@ static bool launch_walk_kd(const SearchArgs& a, hipStream_t s) {
     if (lds_knob) { const char* e = getenv("LOCGPU_K1_LDS_BYTES"); lds_bytes = (unsigned)std::max(e ? atoi(e) : 0, DF * 64 * 8); }
     if (stamp)  // diagnostic build: counts rounds per lane and per wave (search_stats[4], [9], [12], [13]; per query at redo_list[pitch + gi]); timing meaningless
         hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, 64, true, WIN>), g2, dim3(64), DF * 64 * 8, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.alpha_eff, Tw, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of, a.marked_only ? 1 : 0);
+                           a.alpha_eff, Tw, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of);
     else
         hipLaunchKernelGGL((icp_search_walk_kernel<K, DF, 64, false, WIN>), g2, dim3(64), lds_bytes, s, a.tree, a.src, a.counts, a.st, a.nn, a.nn_pitch, a.max_n,
-                           a.alpha_eff, Tw, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of, a.marked_only ? 1 : 0);
+                           a.alpha_eff, Tw, rsrc_bytes, dummy, a.skip_nonfinite, a.redo_list, a.redo_count, a.redo_list2, a.redo_count2, a.search_stats, a.active, a.src_of);
     // 2048 one-wave blocks of 17 KB LDS are all resident at once (nine fit a CU): the first iteration's ≈140 k deep queries take one
     // traversal per wave instead of two or three in sequence (search 18.07 → 17.80 ms per 256-scan step; 4608: 17.96)
     hipLaunchKernelGGL((icp_search_walk_list_kernel<K, D, kDeepLanes>), dim3(kDeepWaves), dim3(64), (D + 2) * kDeepLanes * 8, s, a.tree, a.src, a.st, a.nn, a.nn_pitch, a.max_n,

@@ -38,14 +38,7 @@ struct SearchArgs {
     // instrumented pass only: bitmap over the tree's 8-byte slots (one bit each, zeroed by the caller, counted and cleared again
     // by launch_count_touched) — which slots this search launch reads at all
     uint32_t* touched = nullptr;
-    // grid mode (round 6): a.nn still holds the lists of the PREVIOUS Gauss–Newton iteration of this alignment (same tree, same k): the
-    // exact search then only looks inside the ball those k leaves span around the query's new position (grid_kernels.hip, ball kernel)
-    bool prev_lists = false;
-    // ... and the tree search behind the ball kernel: only the queries that kernel marked (first list entry = kNeedsTree) are searched,
-    // the others keep their lists; a wave without a marked query returns at once
-    bool marked_only = false;
 };
-constexpr uint32_t kNeedsTree = 0xFFFFFFFEu;  // not a slot (slots < 2^30), not kInvalidSlot
 
 struct AccumArgs {
     const uint2* tree;

@@ -790,7 +790,6 @@ bool IterLauncher::launch(int do_update) {
         if (grid_mode && !b->d_grid_qkey) { fail(ctx, LOCGPU_ERR_INVALID, "grid search: work list missing (ensure_grid_lists was not called)"); return false; }
         sa.redo_list2 = b->d_redo_list2;
         sa.active = active; sa.n_active = n_active;
-        sa.prev_lists = grid_mode && b->grid_lists_live;  // the lists of this alignment's previous iteration are in b->d_nn
         if (sa.visit_totals && !capturing) {  // instrumented pass: which tree slots does this launch read at all? (bench.py: compulsory bytes)
             const size_t words = (ctx->tree_slots + 2 + 31) / 32;
             if (words > ctx->touched_words) {
@@ -804,7 +803,6 @@ bool IterLauncher::launch(int do_update) {
         const GridSearchScratch gsc{b->d_grid_qkey, b->d_grid_sorted, b->d_grid_tile_count, b->d_grid_scan_temp};
         const bool ok_search = (grid_mode && !sa.visit_totals) ? launch_icp_search_grid(ctx->grid, sa, gsc, s) : launch_icp_search(sa, s);
         if (!ok_search) { fail(ctx, LOCGPU_ERR_DEPTH, "search: unsupported k/depth"); return false; }
-        b->grid_lists_live = grid_mode;
         if (sa.touched) launch_count_touched(sa.touched, (ctx->tree_slots + 2 + 31) / 32, sa.visit_totals, s);
         mark(true);
         const double gate = prm.method == LOCGPU_P2PLANE ? prm.max_plane_distance : (prm.method == LOCGPU_P2LINE ? prm.max_line_distance : prm.max_nn_distance);
@@ -955,7 +953,6 @@ static int capture_chunk(locgpu_ctx* ctx, locgpu_batch* b, const GnParams& prm, 
     IterLauncher it{ctx, b, prm, k, alpha_eff};
     it.ndt = ndt;
     it.capturing = true;
-    b->grid_lists_live = !with_h2d;  // the graph of the first chunk starts an alignment; the graph of a further chunk continues one
     for (int i = 0; ok && i < iters; ++i) ok = it.launch(1);
     ok = ok && hip_ok(ctx, hipMemcpyAsync(b->h_state, b->d_state, b->n_total * sizeof(PoseState), hipMemcpyDeviceToHost, s), "capture D2H");
     const hipError_t e = hipStreamEndCapture(s, &graph);
@@ -1111,7 +1108,6 @@ static int align_begin(locgpu_ctx* ctx, locgpu_batch* b, const double* init_pose
     P.graph = ctx->use_graph && !ctx->count_visits && !b->sharded && prm.max_iteration > 0;
     P.launched = 0;
     P.ev_used = 0;
-    b->grid_lists_live = false;  // grid mode: the first iteration of an alignment has no previous lists (other scans may have been uploaded since)
     P.init_poses.assign(init_poses, init_poses + 7 * (size_t)b->n_total);
     init_states(b, init_poses);
     // the search stage's work-list counters: zero once per alignment, whatever an earlier call that failed between a search and
@@ -1346,7 +1342,6 @@ int locgpu_icp_hb_batch(locgpu_ctx* ctx, locgpu_batch* b, const double* poses, c
     if (b->pending.active) return fail(ctx, LOCGPU_ERR_INVALID, "icp_hb_batch: an alignment of this batch has been begun and not finished");
     init_states(b, poses);
     b->counters_clean = false;
-    b->grid_lists_live = false;
     LOCGPU_HIP(ctx, hipMemsetAsync(b->d_redo_count, 0, 4 * sizeof(unsigned int), b->stream));
     LOCGPU_HIP(ctx, hipMemcpyAsync(b->d_state, b->h_state, b->n_total * sizeof(PoseState), hipMemcpyHostToDevice, b->stream));
     IterLauncher it{ctx, b, prm, k, alpha_eff};
