@@ -843,6 +843,49 @@ def test_paced_one_scan_alignment_equals_the_chunked_one(tmp_path):
     assert np.array_equal(a["stats"], b["stats"], equal_nan=True)
 
 
+def test_source_overwritten_or_freed_right_behind_a_paced_call(api, small_world):
+    """a paced one-scan call returns the moment the solve kernel's post says the scan is done — up to one idle iteration
+    is still queued behind it, and its kernels must test `done` before they touch the counts or the points. So: a resident cloud is
+    OVERWRITTEN (another scan uploaded into it) or DESTROYED right behind the call, and a host array is scribbled over right behind
+    the host-pointer call, forty times each with no pause; every following call must give the bits of the same call on a fresh
+    context, and nothing may fault."""
+    m = small_world["map"]
+    s = small_world["scan10k"]
+    pose = small_world["init_pose"]
+    scans = [np.ascontiguousarray(s[i::3][:3000]) for i in range(3)]
+    opts = api.icp_opts(method=api.P2PLANE)
+    fresh = api.Context(0)
+    fresh.icp_set_target(m)
+    want = [fresh.icp_align(x, pose, opts) for x in scans]
+    fresh.close()
+    ctx = api.Context(0)
+    ctx.icp_set_target(m)
+
+    def xyzi(x):
+        a = np.zeros((len(x), 4), np.float32)
+        a[:, :3] = x[:, :3]
+        return a
+
+    cloud = api.Cloud(ctx, xyzi(scans[0]))
+    for rep in range(40):
+        k = rep % 3
+        got = ctx.icp_align_cloud(cloud, pose, opts)
+        assert np.array_equal(got[0], want[k][0]) and got[1] == want[k][1], (rep, "resident")
+        if rep % 2:
+            cloud.close()                                  # freed right behind the call …
+            cloud = api.Cloud(ctx, xyzi(scans[(k + 1) % 3]))
+        else:
+            cloud.upload(xyzi(scans[(k + 1) % 3]))          # … or overwritten in place
+    cloud.close()
+    for rep in range(40):
+        k = rep % 3
+        buf = scans[k].copy()
+        got = ctx.icp_align(buf, pose, opts)
+        buf[:] = np.nan                                    # the caller's array is the caller's again
+        assert np.array_equal(got[0], want[k][0]) and got[1] == want[k][1], (rep, "host pointer")
+    ctx.close()
+
+
 def test_align_begin_end_two_batches_in_flight(gpu_ctx, api, small_world):
     """locgpu_*_align_batch_begin / locgpu_align_batch_end: two batches (different scans, ragged counts) begun back to back and ended
     in order give bit for bit the poses, iteration counts and stats of the blocking calls — ICP and direct NDT — also when the
