@@ -362,6 +362,25 @@ def test_finished_scan_post_rejects_torn_reads(tmp_path):
     assert r.returncode == 0 and "accepted early 0, wrong content 0, missed 0" in r.stdout and "20000 taken, 0 wrong" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
 
+def test_context_helper_thread_under_tsan(tmp_path):
+    """The context's helper thread (csrc/host_worker.hpp: the output cloud of locgpu_*_scan_match is sized, field-copied and half of
+    its coordinates written there, beside the caller's thread) under ThreadSanitizer: results handed back through wait(), a run() behind
+    a busy job, jobs that capture the caller's stack, destruction while busy / idle / never started (tests/cpp/host_worker_tsan.cpp)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "host_worker_tsan")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-pthread", "-I", os.path.join(ROOT, "loc_lib_amd", "csrc"),
+           os.path.join(ROOT, "tests", "cpp", "host_worker_tsan.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "host_worker: 0 problems" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 # ----------------------------------------------------------------------------------------------- bench.py launcher (no GPU needed)
 def _load_bench():
     import importlib.util
