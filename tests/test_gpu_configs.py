@@ -720,9 +720,9 @@ def test_nothing_leaks_over_create_use_destroy_cycles():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "leak_check.py"), "--reps", "80"], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    m = re.search(r"device memory not returned ([-0-9.]+) MB .* RSS growth ([-0-9.]+) MB", r.stdout)
+    m = re.search(r"device memory not returned ([-0-9.]+) MB .* RSS growth ([-0-9.]+) MB .* threads ([-+0-9]+)", r.stdout)
     assert m, r.stdout[-500:]
-    assert float(m.group(1)) < 2.0 and float(m.group(2)) < 8.0, r.stdout[-500:]
+    assert float(m.group(1)) < 2.0 and float(m.group(2)) < 8.0 and int(m.group(3)) <= 0, r.stdout[-500:]  # round 6: no helper thread left behind either
 
 
 def test_two_matchers_on_one_gpu_concurrently():

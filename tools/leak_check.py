@@ -15,6 +15,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from loc_lib_amd import api, synth  # noqa: E402
 
 
+def n_threads():
+    return len(os.listdir("/proc/self/task"))
+
+
 def rss_mb():
     for ln in open("/proc/self/status"):
         if ln.startswith("VmRSS"):
@@ -45,6 +49,9 @@ def main():
         ctx.ndt_set_target(m)
         ctx.icp_align(scan, init, api.icp_opts(method=api.P2PLANE))
         ctx.ndt_align(scan, init)
+        ctx.icp_scan_match(scan, init, api.icp_opts(method=api.P2PLANE))   # ScanMatch whole: helper thread, piece events, pinned staging
+        ctx.ndt_scan_match(scan, init)
+        ctx.transform_cloud(init, scan)
         b = ctx.batch([scan, scan[::2].copy()])
         ctx.icp_align_batch(b, np.stack([init] * 2), api.icp_opts(method=api.P2LINE))
         ctx.graph_enable(True)
@@ -64,14 +71,14 @@ def main():
 
     for _ in range(5):
         once()  # warm: runtime pools, kernel code objects, the host build pool
-    d0, r0 = dev_free_mb(), rss_mb()
+    d0, r0, t0 = dev_free_mb(), rss_mb(), n_threads()
     for i in range(a.reps):
         once()
         if (i + 1) % 100 == 0:
             print("after %4d: device free %+.1f MB, RSS %+.1f MB" % (i + 1, dev_free_mb() - d0, rss_mb() - r0), flush=True)
     d1, r1 = dev_free_mb(), rss_mb()
-    print("reps %d: device memory not returned %.1f MB (%.3f MB per repetition), RSS growth %.1f MB (%.3f MB per repetition)"
-          % (a.reps, d0 - d1, (d0 - d1) / a.reps, r1 - r0, (r1 - r0) / a.reps))
+    print("reps %d: device memory not returned %.1f MB (%.3f MB per repetition), RSS growth %.1f MB (%.3f MB per repetition), threads %+d"
+          % (a.reps, d0 - d1, (d0 - d1) / a.reps, r1 - r0, (r1 - r0) / a.reps, n_threads() - t0))
 
 
 if __name__ == "__main__":
